@@ -1,0 +1,400 @@
+"""TEST INFRASTRUCTURE ONLY -- generate golden vectors from the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference, imported read-only via
+``oracle/ref_shim.py``); writes small ``tests/golden/*.npz`` fixtures that are
+committed and travel to the GPU box.  Re-run:  ``python oracle/gen_golden.py``.
+
+Every fixture stores its inputs AND the reference's outputs, so tests never
+depend on RNG reproducibility across machines.  What calls what:
+
+  unsup_*        u2pl.utils.loss_helper.compute_unsupervised_loss   (loss_helper.py:30-48)
+  ohem_*         u2pl.utils.loss_helper.CriterionOhem               (loss_helper.py:323-360,451-531)
+  relsplit_*     the inline block train_semi.py:397-465 executed with the same
+                 torch / numpy calls and the reference's label_onehot (utils.py:50-59)
+  contra_*       u2pl.utils.loss_helper.compute_contra_memobank_loss (loss_helper.py:51-235)
+                 incl. memory-bank state before/after and d loss / d rep
+  bank_seq       u2pl.utils.utils.dequeue_and_enqueue sequence        (utils.py:27-47)
+  cutmix         u2pl.dataset.augmentation.generate_unsup_data        (augmentation.py:471-541)
+  pseudo_*       train_semi.py:320-324 (bilinear up, softmax, max)
+  sgd_ema        torch.optim.SGD + LRScheduler (lr_helper.py:78-113) + EMA (train_semi.py:531-548)
+  model_*        u2pl.models.model_helper.ModelBuilder fwd/bwd on tiny inputs with
+                 formula-initialised weights (see formula_state_dict)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+CONTRA_CFG = dict(
+    negative_high_entropy=True, low_rank=3, high_rank=20, current_class_threshold=0.3,
+    current_class_negative_threshold=1, unsupervised_entropy_ignore=80,
+    low_entropy_threshold=20, num_negatives=50, num_queries=256, temperature=0.5,
+)
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def block_labels(B, S, C, gen, ignore_rows=4, cell=8):
+    g = (S + cell - 1) // cell
+    coarse = torch.randint(0, C, (B, 1, g, g), generator=gen).float()
+    lab = F.interpolate(coarse, size=(g * cell, g * cell), mode="nearest")[:, 0, :S, :S].long()
+    lab[:, :ignore_rows] = 255
+    return lab.contiguous()
+
+
+def assert_no_ties(prob, k=4):
+    top = torch.sort(prob, 1, True)[0][:, : k + 1]
+    assert (top[:, :-1] - top[:, 1:]).min() > 0, "tie among top probabilities; change seed"
+
+
+# ----------------------------------------------------------------------------
+def gen_unsup(ns, seed, S, s, C, percent, tag):
+    gen = torch.Generator().manual_seed(seed)
+    low_t = torch.randn(2, C, s, s, generator=gen) * 3
+    low_s = torch.randn(2, C, s, s, generator=gen) * 2
+    pred_teacher = F.interpolate(low_t, (S, S), mode="bilinear", align_corners=True)
+    predict = F.interpolate(low_s, (S, S), mode="bilinear", align_corners=True).requires_grad_(True)
+    target = block_labels(2, S, C, gen)
+    tgt = target.clone()
+    loss = ns.loss_helper.compute_unsupervised_loss(predict, tgt, percent, pred_teacher)
+    loss.backward()
+    prob = torch.softmax(pred_teacher, 1)
+    entropy = -torch.sum(prob * torch.log(prob + 1e-10), dim=1)
+    g = predict.grad
+    save(f"unsup_{tag}", low_teacher=low_t, low_student=low_s, size=np.int64(S),
+         target=target.to(torch.uint8), percent=np.float64(percent), loss=loss,
+         new_target=tgt.to(torch.uint8), grad_sub=g[:, :, ::5, ::5], grad_sum_c=g.double().sum((0, 2, 3)),
+         grad_abs_sum=g.double().abs().sum(), entropy=entropy)
+
+
+def gen_ohem(ns, seed, S, s, C, min_kept, tag, ignore_frac_rows=4):
+    gen = torch.Generator().manual_seed(seed)
+    low = torch.randn(2, C, s, s, generator=gen) * 2
+    low_aux = torch.randn(2, C, s, s, generator=gen) * 2
+    target = block_labels(2, S, C, gen, ignore_rows=ignore_frac_rows)
+    # make the prediction partly agree with the target so p[target] spreads over (0,1)
+    onehot = F.one_hot(torch.where(target == 255, 0, target), C).permute(0, 3, 1, 2).float()
+    main = (F.interpolate(low, (S, S), mode="bilinear", align_corners=True) + 2.5 * onehot).requires_grad_(True)
+    aux = (F.interpolate(low_aux, (S, S), mode="bilinear", align_corners=True) + 1.0 * onehot).requires_grad_(True)
+    crit = ns.loss_helper.CriterionOhem(0.4, thresh=0.7, min_kept=min_kept, ignore_index=255)
+    loss = crit([main, aux], target.clone())
+    loss.backward()
+    crit1 = ns.loss_helper.OhemCrossEntropy2dTensor(255, 0.7, min_kept)
+    loss_main = crit1(main.detach(), target.clone())
+    gm, ga = main.grad, aux.grad
+    save(f"ohem_{tag}", low=low, low_aux=low_aux, size=np.int64(S), target=target.to(torch.uint8),
+         min_kept=np.int64(min_kept), thresh=np.float64(0.7), aux_weight=np.float64(0.4), loss=loss,
+         loss_main=loss_main, grad_main_sub=gm[:, :, ::5, ::5], grad_aux_sub=ga[:, :, ::5, ::5],
+         grad_main_abs_sum=gm.double().abs().sum(), grad_aux_abs_sum=ga.double().abs().sum(),
+         n_kept_main=(gm.abs().sum(1) > 0).sum())
+
+
+def relsplit_reference(ns, pred_u_large_teacher, label_u_aug, label_l, alpha_t, out_hw, C):
+    """train_semi.py:397-465 with the same calls (torch + numpy + reference label_onehot)."""
+    with torch.no_grad():
+        prob = torch.softmax(pred_u_large_teacher, dim=1)
+        entropy = -torch.sum(prob * torch.log(prob + 1e-10), dim=1)
+        low_thresh = np.percentile(entropy[label_u_aug != 255].cpu().numpy().flatten(), alpha_t)
+        low_entropy_mask = entropy.le(low_thresh).float() * (label_u_aug != 255).bool()
+        high_thresh = np.percentile(entropy[label_u_aug != 255].cpu().numpy().flatten(), 100 - alpha_t)
+        high_entropy_mask = entropy.ge(high_thresh).float() * (label_u_aug != 255).bool()
+        low_mask_all = torch.cat(((label_l.unsqueeze(1) != 255).float(), low_entropy_mask.unsqueeze(1)))
+        low_mask_all = F.interpolate(low_mask_all, size=out_hw, mode="nearest")
+        high_mask_all = torch.cat(((label_l.unsqueeze(1) != 255).float(), high_entropy_mask.unsqueeze(1)))
+        high_mask_all = F.interpolate(high_mask_all, size=out_hw, mode="nearest")
+        label_l_small = F.interpolate(ns.utils.label_onehot(label_l, C), size=out_hw, mode="nearest")
+        label_u_small = F.interpolate(ns.utils.label_onehot(label_u_aug, C), size=out_hw, mode="nearest")
+    return dict(entropy=entropy, low_thresh=np.float32(low_thresh), high_thresh=np.float32(high_thresh),
+                low_mask_all=low_mask_all, high_mask_all=high_mask_all,
+                label_l_small=label_l_small.long(), label_u_small=label_u_small.long())
+
+
+def make_step_inputs(seed, B, S, s, C, D=256, cutout=False):
+    """Synthetic tensors shaped like the ones train_semi.py hands to the loss block."""
+    gen = torch.Generator().manual_seed(seed)
+    low_t_train = torch.randn(2 * B, C, s, s, generator=gen) * 3      # teacher (train mode) logits, all images
+    low_t_eval = low_t_train[B:] + 1.5 * torch.randn(B, C, s, s, generator=gen)  # teacher eval logits (unlabeled)
+    label_l = block_labels(B, S, C, gen)
+    conf, label_u = torch.max(torch.softmax(
+        F.interpolate(low_t_eval, (S, S), mode="bilinear", align_corners=True), 1), 1)
+    if cutout:
+        label_u = label_u.clone()
+        label_u[:, S // 3: S // 2, S // 4: S // 2] = 255
+    rep = torch.round(torch.randn(2 * B, D, s, s, generator=gen) * 64) / 64   # coarse grid: fixture compresses
+    rep_t = torch.round(torch.randn(2 * B, D, s, s, generator=gen) * 64) / 64
+    prob_all = torch.softmax(low_t_train, 1)
+    assert_no_ties(prob_all)
+    pred_u_large_teacher = F.interpolate(low_t_train[B:], (S, S), mode="bilinear", align_corners=True)
+    return dict(low_t_train=low_t_train, low_t_eval=low_t_eval, label_l=label_l, label_u_aug=label_u,
+                conf_u=conf, rep=rep, rep_teacher=rep_t, prob_all=prob_all,
+                pred_u_large_teacher=pred_u_large_teacher)
+
+
+def gen_relsplit(ns, seed, B, S, s, C, alpha_t, tag, cutout=False):
+    inp = make_step_inputs(seed, B, S, s, C, D=8, cutout=cutout)
+    out = relsplit_reference(ns, inp["pred_u_large_teacher"], inp["label_u_aug"], inp["label_l"], alpha_t, (s, s), C)
+    out = {k: (v.to(torch.uint8) if isinstance(v, torch.Tensor) and k != "entropy" else v) for k, v in out.items()}
+    save(f"relsplit_{tag}", low_t_train=inp["low_t_train"], label_l=inp["label_l"].to(torch.uint8),
+         label_u_aug=inp["label_u_aug"].to(torch.uint8), size=np.int64(S), alpha_t=np.float64(alpha_t), **out)
+
+
+def formula_bank(c, n, D):
+    """closed-form, machine-independent bank rows (tests rebuild them; not stored)."""
+    r = torch.arange(n, dtype=torch.int64)[:, None]
+    d = torch.arange(D, dtype=torch.int64)[None, :]
+    return (((r * 131 + d * 31 + c * 17 + (r * d) % 7) % 1000).float() / 500.0 - 1.0)
+
+
+def gen_contra(ns, seed, B, S, s, C, alpha_t, tag, prefill=0, steps=1, queue_size=3000, D=256):
+    """steps>1: call the reference repeatedly on fresh inputs (bank carries over)."""
+    torch.manual_seed(seed + 1000)  # global generator used by torch.randint inside the reference
+    memobank = [[torch.zeros(0, D)] for _ in range(C)]
+    if prefill:
+        memobank = [[formula_bank(i, prefill + 3 * i, D)] for i in range(C)]
+    queue_ptrlis = [torch.zeros(1, dtype=torch.long) for _ in range(C)]
+    queue_size_l = [queue_size] * C
+    queue_size_l[0] = queue_size + 500
+    fx = dict(num_steps=np.int64(steps), queue_size=np.array(queue_size_l), alpha_t=np.float64(alpha_t),
+              prefill=np.int64(prefill), D=np.int64(D))
+    for st in range(steps):
+        inp = make_step_inputs(seed + 31 * st, B, S, s, C, D=D)
+        rs = relsplit_reference(ns, inp["pred_u_large_teacher"], inp["label_u_aug"], inp["label_l"], alpha_t, (s, s), C)
+        rep = inp["rep"].clone().requires_grad_(True)
+        rng_state = torch.get_rng_state()
+        new_keys, loss = ns.loss_helper.compute_contra_memobank_loss(
+            rep, rs["label_l_small"], rs["label_u_small"], inp["prob_all"][:B], inp["prob_all"][B:],
+            rs["low_mask_all"], rs["high_mask_all"], CONTRA_CFG, memobank, queue_ptrlis, queue_size_l,
+            inp["rep_teacher"])
+        loss.backward()
+        p = f"s{st}_"
+        fx.update({
+            p + "rep": inp["rep"], p + "rep_teacher": inp["rep_teacher"], p + "prob_all": inp["prob_all"],
+            p + "label_l": inp["label_l"].to(torch.uint8), p + "label_u_aug": inp["label_u_aug"].to(torch.uint8),
+            p + "low_t_train": inp["low_t_train"],
+            p + "low_mask_all": rs["low_mask_all"].to(torch.uint8), p + "high_mask_all": rs["high_mask_all"].to(torch.uint8),
+            p + "label_l_small": rs["label_l_small"].to(torch.uint8), p + "label_u_small": rs["label_u_small"].to(torch.uint8),
+            p + "loss": loss, p + "grad_rep": rep.grad, p + "new_keys": np.array(new_keys),
+            p + "rng_state": rng_state,
+            p + "bank_len": np.array([memobank[c][0].shape[0] for c in range(C)]),
+            p + "queue_ptr": np.array([int(queue_ptrlis[c][0]) for c in range(C)]),
+        })
+        print(tag, "step", st, "loss", float(loss), "new_keys", new_keys)
+    for c in range(C):
+        b = memobank[c][0]
+        fx[f"bankF_{c}_sum"] = b.double().sum(0)
+        fx[f"bankF_{c}_head"] = b[:4]
+        fx[f"bankF_{c}_tail"] = b[-4:]
+    save(f"contra_{tag}", **fx)
+
+
+def gen_bank_seq(ns, seed):
+    gen = torch.Generator().manual_seed(seed)
+    queue = [torch.zeros(0, 16)]
+    ptr = torch.zeros(1, dtype=torch.long)
+    sizes = [5, 0, 7, 30, 3, 64, 1]
+    fx = dict(sizes=np.array(sizes), queue_size=np.int64(40))
+    for i, n in enumerate(sizes):
+        keys = torch.randn(n, 16, generator=gen)
+        ret = ns.utils.dequeue_and_enqueue(keys, queue, ptr, 40)
+        fx[f"keys{i}"] = keys
+        fx[f"queue{i}"] = queue[0].clone()
+        fx[f"ptr{i}"] = np.int64(int(ptr[0]))
+        fx[f"ret{i}"] = np.int64(ret)
+    save("bank_seq", **fx)
+
+
+def gen_cutmix(ns, seed, B, S):
+    gen = torch.Generator().manual_seed(seed)
+    data = torch.randn(B, 3, S, S, generator=gen)
+    target = torch.randint(0, 19, (B, S, S), generator=gen)
+    logits = torch.rand(B, S, S, generator=gen)
+    np.random.seed(seed)
+    state = np.random.get_state()
+    nd, nt, nl = ns.augmentation.generate_unsup_data(data, target.clone(), logits.clone(), mode="cutmix")
+    # recover the boxes the reference drew, by replaying np.random in the same order
+    np.random.set_state(state)
+    boxes = []
+    for _ in range(B):
+        area = S * S / 2
+        w = np.random.randint(S / 2 + 1, S)
+        h = np.round(area / w)
+        x0 = np.random.randint(0, S - w + 1)
+        y0 = np.random.randint(0, S - h + 1)
+        boxes.append((int(y0), int(y0 + h), int(x0), int(x0 + w)))
+    save("cutmix", data=data, target=target, logits=logits, seed=np.int64(seed), boxes=np.array(boxes),
+         new_data=nd, new_target=nt, new_logits=nl)
+
+
+def gen_pseudo(seed, S, s, C):
+    gen = torch.Generator().manual_seed(seed)
+    low = torch.randn(2, C, s, s, generator=gen) * 3
+    large = F.interpolate(low, (S, S), mode="bilinear", align_corners=True)
+    prob = F.softmax(large, dim=1)
+    conf, label = torch.max(prob, dim=1)
+    top2 = torch.sort(large, 1, True)[0][:, :2]
+    save("pseudo_65", low=low, large=large, conf=conf, label=label, gap=(top2[:, 0] - top2[:, 1]))
+
+
+def gen_sgd_ema(ns, seed):
+    gen = torch.Generator().manual_seed(seed)
+    p0 = torch.randn(1000, generator=gen)
+    p1 = torch.randn(500, generator=gen)
+    s0, s1 = torch.nn.Parameter(p0.clone()), torch.nn.Parameter(p1.clone())
+    t0, t1 = p0.clone() * 0.5, p1.clone() * 0.5
+    params = [dict(params=[s0], lr=0.01), dict(params=[s1], lr=0.1)]
+    opt = ns.lr_helper.get_optimizer(params, dict(type="SGD", kwargs=dict(lr=0.01, momentum=0.9, weight_decay=0.0005)))
+    sched = ns.lr_helper.get_scheduler(dict(epochs=2, lr_scheduler=dict(mode="poly", kwargs=dict(power=0.9))), 5, opt, 0)
+    fx = dict(p0=p0, p1=p1, t0=t0.clone(), t1=t1.clone())
+    for it in range(6):
+        sched.step()
+        g0 = torch.randn(1000, generator=gen)
+        g1 = torch.randn(500, generator=gen)
+        s0.grad, s1.grad = g0.clone(), g1.clone()
+        opt.step()
+        d = min(1 - 1 / (it - 5 * 0 + 1), 0.99)  # train_semi.py:533-542 with sup_only_epoch 0
+        t0 = d * t0 + (1 - d) * s0.data
+        t1 = d * t1 + (1 - d) * s1.data
+        fx.update({f"g0_{it}": g0, f"g1_{it}": g1, f"s0_{it}": s0.data.clone(), f"s1_{it}": s1.data.clone(),
+                   f"t0_{it}": t0.clone(), f"t1_{it}": t1.clone(),
+                   f"lr_{it}": np.array([g["lr"] for g in opt.param_groups]), f"ema_{it}": np.float64(d)})
+    save("sgd_ema", **fx)
+
+
+# ----------------------------------------------------------------------------
+def formula_state_dict(model, seed=1234):
+    """Deterministic, machine-independent weights: every tensor is filled from a
+    closed-form function of its name and flat index, so both the reference model
+    (here) and the MI355X model (on the GPU box) can build identical weights
+    without shipping a checkpoint."""
+    sd = model.state_dict()
+    out = {}
+    for k, v in sd.items():
+        if v.dtype == torch.long:
+            out[k] = v.clone()
+            continue
+        h = (sum((i + 1) * ord(c) for i, c in enumerate(k)) * 2654435761 + seed) % (2 ** 31)
+        n = v.numel()
+        idx = torch.arange(n, dtype=torch.float64)
+        u = torch.frac(torch.sin(idx * 12.9898 + (h % 10007) * 0.618) * 43758.5453).abs()  # [0,1)
+        if k.endswith("running_var"):
+            val = 0.5 + u
+        elif k.endswith("running_mean"):
+            val = (u - 0.5) * 0.2
+        elif k.endswith("weight") and v.dim() == 1:
+            val = 0.5 + u
+        elif k.endswith("bias"):
+            val = (u - 0.5) * 0.2
+        else:
+            fan_in = v[0].numel()
+            val = (u - 0.5) * 2 * (3.0 / fan_in) ** 0.5 * 1.4
+        out[k] = val.reshape(v.shape).to(v.dtype)
+    return out
+
+
+def gen_model(ns, tag, arch, S, B, C, aux, seed=5):
+    import copy
+
+    net = dict(
+        num_classes=C, sync_bn=False, ema_decay=0.99,
+        encoder=dict(type=f"u2pl.models.resnet.{arch}",
+                     kwargs=dict(multi_grid=True, zero_init_residual=True, fpn=True,
+                                 replace_stride_with_dilation=[False, True, True], pretrained=False)),
+        decoder=dict(type="u2pl.models.decoder.dec_deeplabv3_plus", kwargs=dict(inner_planes=256, dilations=[12, 24, 36])),
+    )
+    if aux:
+        net["aux_loss"] = dict(aux_plane=1024, loss_weight=0.4)
+    model = ns.model_helper.ModelBuilder(copy.deepcopy(net))
+    model.load_state_dict(formula_state_dict(model))
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0  # CPU mt19937 vs device RNG cannot match: parity mode runs without dropout
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 3, S, S, generator=gen)
+    model.train()
+    out = model(x)
+    gp = torch.randn(out["pred"].shape, generator=gen)
+    gr = torch.randn(out["rep"].shape, generator=gen)
+    loss = (out["pred"] * gp).sum() + (out["rep"] * gr).sum()
+    if aux:
+        ga = torch.randn(out["aux"].shape, generator=gen)
+        loss = loss + (out["aux"] * ga).sum()
+    loss.backward()
+    names = ["encoder.conv1.0.weight", "encoder.layer1.0.conv2.weight", "encoder.layer2.0.downsample.0.weight",
+             "encoder.layer3.1.conv2.weight", "encoder.layer4.2.conv3.weight", "encoder.layer4.2.bn3.weight",
+             "decoder.aspp.conv5.0.weight", "decoder.aspp.conv1.1.weight", "decoder.low_conv.0.bias",
+             "decoder.classifier.8.weight", "decoder.representation.4.bias", "decoder.head.1.bias"]
+    if aux:
+        names.append("auxor.aux.0.weight")
+    params = dict(model.named_parameters())
+    fx = dict(x=x, pred=out["pred"], rep=out["rep"], gp=gp, gr=gr)
+    if aux:
+        fx.update(aux=out["aux"], ga=ga)
+    for n in names:
+        fx["grad__" + n] = params[n].grad
+    bufs = dict(model.named_buffers())
+    for n in ["encoder.bn1.running_mean", "encoder.bn1.running_var", "decoder.aspp.conv1.2.running_var",
+              "encoder.layer4.2.bn3.running_mean"]:
+        fx["buf__" + n] = bufs[n]
+    model.eval()
+    with torch.no_grad():
+        oe = model(x)
+    fx.update(pred_eval=oe["pred"], rep_eval=oe["rep"])
+    fx["grad_names"] = np.array(names)
+    save(f"model_{tag}", **fx)
+
+
+def main():
+    ns = ref_shim.load()
+    which = set(sys.argv[1:])
+
+    def want(k):
+        return not which or k in which
+
+    if want("unsup"):
+        gen_unsup(ns, 11, 65, 17, 19, 80.0, "65_c19")
+        gen_unsup(ns, 12, 97, 25, 21, 86.5, "97_c21")
+    if want("ohem"):
+        gen_ohem(ns, 21, 65, 17, 19, 3000, "65_k3000")
+        gen_ohem(ns, 22, 65, 17, 19, 100000, "65_kbig")   # min_kept > num_valid: no filtering
+        gen_ohem(ns, 23, 65, 17, 19, 60, "65_k60")         # k-th prob below thresh: threshold stays 0.7
+    if want("relsplit"):
+        gen_relsplit(ns, 31, 2, 65, 17, 19, 20.0, "65_a20")
+        gen_relsplit(ns, 32, 2, 97, 25, 21, 13.7, "97_a13")
+        gen_relsplit(ns, 33, 2, 65, 17, 19, 20.0, "65_cutout", cutout=True)
+        gen_relsplit(ns, 34, 3, 65, 17, 19, 7.5, "65_b3")
+    if want("contra"):
+        gen_contra(ns, 41, 2, 65, 17, 19, 20.0, "65_empty", prefill=0, steps=2)
+        gen_contra(ns, 42, 2, 65, 17, 19, 20.0, "65_prefill", prefill=2990, steps=2, D=64)
+    if want("bank"):
+        gen_bank_seq(ns, 51)
+    if want("cutmix"):
+        gen_cutmix(ns, 61, 2, 65)
+    if want("pseudo"):
+        gen_pseudo(71, 65, 17, 19)
+    if want("sgd"):
+        gen_sgd_ema(ns, 81)
+    if want("model"):
+        gen_model(ns, "r50_65", "resnet50", 65, 2, 19, aux=True)
+        gen_model(ns, "r101_33", "resnet101", 33, 2, 21, aux=False)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,179 @@
+"""Pin the CPU oracle (oracle/restate.py, oracle/restate.c) against golden vectors
+produced by the REFERENCE's own functions (oracle/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import restate as R
+from oracle.gen_golden import CONTRA_CFG, formula_bank  # constants/helpers only (no reference import)
+from conftest import golden
+
+
+def _up(low, S):
+    return R.bilinear_ac(low, S, S)
+
+
+@pytest.mark.parametrize("h,H", [(193, 769), (97, 193), (17, 65), (25, 97), (129, 513)])
+def test_bilinear_bitexact_vs_torch(h, H):
+    import torch
+    import torch.nn.functional as F
+
+    x = torch.randn(1, 3, h, h, generator=torch.Generator().manual_seed(h)) * 3
+    ref = F.interpolate(x, (H, H), mode="bilinear", align_corners=True).numpy()
+    assert np.array_equal(ref, R.bilinear_ac(x.numpy(), H, H))
+
+
+@pytest.mark.parametrize("H,h", [(769, 193), (513, 129), (801, 201), (65, 17), (97, 25)])
+def test_nearest_rule_vs_torch(H, h):
+    import torch
+    import torch.nn.functional as F
+
+    x = torch.arange(H * H, dtype=torch.float32).reshape(1, 1, H, H)
+    ref = F.interpolate(x, (h, h), mode="nearest").numpy()
+    assert np.array_equal(ref, R.nearest_down(x.numpy(), h, h))
+
+
+def test_percentile_bitexact_vs_numpy():
+    rng = np.random.default_rng(0)
+    for n in [1, 2, 3, 5, 17, 1000, 4097, 591361, 1182722]:
+        v = rng.random(n).astype(np.float32)
+        for q in [0, 20, 80, 100, 83.5, 16.5, 50, 99.99, 3.3, 20 * (1 - 37 / 200), 100 - 20 * (1 - 37 / 200)]:
+            a, b = np.percentile(v, q), R.percentile_f32(v, q)
+            assert a.dtype == np.float32 and a == b, (n, q, a, b)
+
+
+@pytest.mark.parametrize("tag", ["65_c19", "97_c21"])
+def test_unsup_loss(tag):
+    g = golden("unsup_" + tag)
+    S = int(g["size"])
+    pred_teacher = _up(g["low_teacher"], S)
+    predict = _up(g["low_student"], S)
+    target = g["target"].astype(np.int64)
+    # Tier A: from the reference's entropy -> bit-exact target overwrite
+    loss, new_target, thr = R.unsup_loss(predict, target, float(g["percent"]), pred_teacher, entropy=g["entropy"])
+    assert np.array_equal(new_target, g["new_target"].astype(np.int64))
+    assert abs(loss - float(g["loss"])) < 1e-4
+    # Tier B: oracle's own entropy within 2e-6 and same mask (fixtures have a gap around thr)
+    ent = R.entropy_from_logits(pred_teacher)
+    assert np.abs(ent - g["entropy"]).max() < 2e-6
+    loss_b, new_target_b, _ = R.unsup_loss(predict, target, float(g["percent"]), pred_teacher)
+    assert (new_target_b != g["new_target"]).sum() <= 1
+    assert abs(loss_b - float(g["loss"])) < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["65_k3000", "65_kbig", "65_k60"])
+def test_ohem(tag):
+    g = golden("ohem_" + tag)
+    S = int(g["size"])
+    target = g["target"].astype(np.int64)
+    C = g["low"].shape[1]
+    onehot = np.eye(C, dtype=np.float32)[np.where(target == 255, 0, target)].transpose(0, 3, 1, 2)
+    main = _up(g["low"], S) + np.float32(2.5) * onehot
+    aux = _up(g["low_aux"], S) + np.float32(1.0) * onehot
+    lm, kept, thr = R.ohem_ce(main, target, 0.7, int(g["min_kept"]))
+    la, _, _ = R.ohem_ce(aux, target, 0.7, int(g["min_kept"]))
+    assert abs(lm - float(g["loss_main"])) < 1e-4
+    assert abs(lm + 0.4 * la - float(g["loss"])) < 1e-4
+    assert int((kept != 255).sum()) == int(g["n_kept_main"])
+
+
+@pytest.mark.parametrize("tag", ["65_a20", "97_a13", "65_cutout", "65_b3"])
+def test_reliability_split(tag):
+    g = golden("relsplit_" + tag)
+    S = int(g["size"])
+    B = g["label_l"].shape[0]
+    s = g["low_t_train"].shape[-1]
+    C = g["low_t_train"].shape[1]
+    large = _up(g["low_t_train"][B:], S)
+    out = R.reliability_split(large, g["label_u_aug"].astype(np.int64), g["label_l"].astype(np.int64),
+                              float(g["alpha_t"]), (s, s), C, entropy=g["entropy"])
+    assert out["low_thresh"] == g["low_thresh"] and out["high_thresh"] == g["high_thresh"]
+    for k in ["low_mask_all", "high_mask_all", "label_l_small", "label_u_small"]:
+        assert np.array_equal(out[k].astype(np.uint8), g[k]), k
+    # Q0: only batch slot 0 of each half is ever non-zero
+    assert out["label_l_small"][1:].sum() == 0 and out["label_u_small"][1:].sum() == 0
+
+
+def _torch_randint_stream(state):
+    import torch
+
+    gen = torch.Generator()
+    gen.set_state(torch.from_numpy(state))
+
+    def randint(high, n):
+        return torch.randint(high, size=(n,), generator=gen).numpy()
+
+    return randint
+
+
+@pytest.mark.parametrize("tag", ["65_empty", "65_prefill"])
+def test_contra_memobank(tag):
+    g = golden("contra_" + tag)
+    C = 19
+    D = int(g["D"])
+    qs = [int(x) for x in g["queue_size"]]
+    pre = int(g["prefill"])
+    bank = [[formula_bank(c, pre + 3 * c, D).numpy() if pre else np.zeros((0, D), np.float32)] for c in range(C)]
+    ptr = [[0] for _ in range(C)]
+    for st in range(int(g["num_steps"])):
+        p = f"s{st}_"
+        B = g[p + "label_l"].shape[0]
+        prob = g[p + "prob_all"]
+        keys, loss, grad, info = R.contra_memobank_loss(
+            g[p + "rep"], g[p + "label_l_small"].astype(np.int64), g[p + "label_u_small"].astype(np.int64),
+            prob[:B], prob[B:], g[p + "low_mask_all"].astype(np.float32), g[p + "high_mask_all"].astype(np.float32),
+            CONTRA_CFG, bank, ptr, qs, g[p + "rep_teacher"], _torch_randint_stream(g[p + "rng_state"]))
+        assert list(keys) == list(g[p + "new_keys"])
+        assert abs(loss - float(g[p + "loss"])) < 1e-4
+        assert np.abs(grad - g[p + "grad_rep"]).max() < 1e-5
+        assert [b[0].shape[0] for b in bank] == list(g[p + "bank_len"])
+        assert [int(q[0]) for q in ptr] == list(g[p + "queue_ptr"])
+    for c in range(C):
+        assert np.array_equal(bank[c][0][:4], g[f"bankF_{c}_head"]) and np.array_equal(bank[c][0][-4:], g[f"bankF_{c}_tail"])
+        assert np.allclose(bank[c][0].astype(np.float64).sum(0), g[f"bankF_{c}_sum"], atol=1e-9)
+
+
+def test_bank_sequence():
+    g = golden("bank_seq")
+    q, ptr = [np.zeros((0, 16), np.float32)], [0]
+    for i, n in enumerate(g["sizes"]):
+        ret = R.dequeue_and_enqueue(g[f"keys{i}"], q, ptr, int(g["queue_size"]))
+        assert ret == int(g[f"ret{i}"]) and int(ptr[0]) == int(g[f"ptr{i}"])
+        assert np.array_equal(q[0], g[f"queue{i}"])
+
+
+def test_cutmix():
+    g = golden("cutmix")
+    B, _, S, _ = g["data"].shape
+    np.random.seed(int(g["seed"]))
+    boxes = [R.cutmix_box(S, S, np.random.randint) for _ in range(B)]
+    assert np.array_equal(np.array(boxes), g["boxes"])
+    nd, nt, nl = R.cutmix_apply(g["data"], g["target"], g["logits"], boxes)
+    assert np.array_equal(nd, g["new_data"]) and np.array_equal(nt, g["new_target"]) and np.array_equal(nl, g["new_logits"])
+
+
+def test_pseudo_label():
+    g = golden("pseudo_65")
+    large = _up(g["low"], 65)
+    assert np.array_equal(large, g["large"])
+    conf, label = R.pseudo_label(large)
+    safe = g["gap"] > 1e-5
+    assert np.array_equal(label[safe], g["label"][safe])
+    assert np.abs(conf - g["conf"]).max() < 1e-6
+
+
+def test_sgd_ema_lr():
+    g = golden("sgd_ema")
+    s = [g["p0"].copy(), g["p1"].copy()]
+    t = [g["t0"].copy(), g["t1"].copy()]
+    buf = [None, None]
+    base = [0.01, 0.1]
+    for it in range(6):
+        lrs = [R.poly_lr(b, it, 10, 0.9) for b in base]
+        assert np.allclose(lrs, g[f"lr_{it}"], rtol=0, atol=1e-15)
+        d = R.ema_decay(it, 5, 0, 0.99)
+        assert d == float(g[f"ema_{it}"])
+        for j in range(2):
+            s[j], buf[j] = R.sgd_step(s[j], g[f"g{j}_{it}"], buf[j], lrs[j], 0.9, 0.0005, first=buf[j] is None)
+            t[j] = R.ema_update(t[j], s[j], d)
+            assert np.abs(s[j] - g[f"s{j}_{it}"]).max() < 1e-6
+            assert np.abs(t[j] - g[f"t{j}_{it}"]).max() < 1e-6

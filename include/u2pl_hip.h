@@ -1,0 +1,116 @@
+/* libu2pl_hip.so -- C ABI of the MI355X-native U2PL training hot path.
+ *
+ * The reference (Haochen-Wang409/U2PL) is pure Python/PyTorch and has NO FFI of
+ * its own; its replaceable seams are Python functions.  Each entry point below
+ * names the reference code it replaces (file:line under the reference tree).
+ * The Python seams that sit on top (u2pl_amd/, same names and argument meaning
+ * as the reference) call these through ctypes -- see INTEGRATION.md.
+ *
+ * Conventions (every function):
+ *   - returns 0 on success, a hipError_t value, or U2PL_EINVAL (1001);
+ *   - never allocates, frees, synchronises or throws; the caller owns every
+ *     buffer (device pointers unless stated) and passes the HIP stream;
+ *   - tensors are float32 / int64 / uint32 as in the reference; "NCHW" means
+ *     contiguous planar, "rows" means a (pixels, D) view with leading dim ld
+ *     (NHWC activations), strides are in ELEMENTS.
+ */
+#ifndef U2PL_HIP_H
+#define U2PL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define U2PL_SEL_MAX_SLOTS 8 /* 2 order statistics per selection spec, <= 4 specs */
+/* select workspace words (uint32): [0] n_valid  [1] n_total  [56+j] threshold j (float bits) */
+#define U2PL_SEL_WORD_NVALID 0
+#define U2PL_SEL_WORD_NTOTAL 1
+#define U2PL_SEL_WORD_VAL 40
+#define U2PL_SEL_WORD_THR 56
+
+/* ---- reliability.hip ------------------------------------------------------ */
+/* F.interpolate(mode="bilinear", align_corners=True): train_semi.py:320-322,345-350,355,372-374 */
+int u2pl_bilinear_up_f32(const float* in, long sn, long sc, long sh, long sw, int N, int C, int h, int w,
+                         float* out_nchw, int H, int W, hipStream_t stream);
+/* autograd of the above for the student branches (train_semi.py:345-355 under loss.backward(), :527) */
+int u2pl_bilinear_up_bwd_f32(const float* gout_nchw, int N, int C, int H, int W, float* gin, long sn, long sc,
+                             long sh, long sw, int h, int w, hipStream_t stream);
+/* F.softmax + torch.max -> (confidence, pseudo label): train_semi.py:323-324 */
+int u2pl_pseudo_label_f32(const float* logits_nchw, int N, int C, int H, int W, float* conf, long long* label,
+                          hipStream_t stream);
+/* entropy = -sum(p*log(p+1e-10)); NaN where label==ignore; *nvalid += #valid:
+ * train_semi.py:402-403, loss_helper.py:35-36 (label may be NULL) */
+int u2pl_entropy_f32(const float* logits_nchw, const long long* label, int ignore, int N, int C, int H, int W,
+                     float* entropy, unsigned* nvalid, hipStream_t stream);
+/* np.percentile(entropy[valid], q) x nspec (exact order statistics + numpy float32 lerp),
+ * train_semi.py:405-407,412-415, loss_helper.py:38-40; spec kind 1 = OHEM k-th smallest
+ * (loss_helper.py:521-526).  ws must be zeroed, then ws[0]=n_valid, ws[1]=n_total. */
+size_t u2pl_select_workspace_bytes(void);
+int u2pl_select_f32(const float* values, long n, int nspec, const int* spec_kind_dev, const float* q32_dev,
+                    const long long* kparam_dev, const float* fparam_dev, unsigned* ws, hipStream_t stream);
+/* target[entropy >= thresh] = 255 and count of kept pixels: loss_helper.py:41-44 */
+int u2pl_apply_drop_i64(const float* entropy, const unsigned* thr_bits, long long* target, int ignore, long n,
+                        unsigned* nkept, hipStream_t stream);
+/* low/high entropy masks, nearest down-sampling, label_onehot (batch-slot-0 quirk) as class
+ * bitmasks for the concatenated batch: train_semi.py:408-465, utils.py:50-59 */
+int u2pl_reliability_masks(const float* entropy, const unsigned* thr_lo_bits, const unsigned* thr_hi_bits,
+                           const long long* label_l, const long long* label_u, int ignore, int B, int H, int W,
+                           int h, int w, int negative_high_entropy, float* low_mask, float* high_mask,
+                           unsigned* lbits, hipStream_t stream);
+int u2pl_pack_class_bits(const long long* onehot, int N, int C, int h, int w, unsigned* bits, hipStream_t stream);
+int u2pl_unpack_class_bits(const unsigned* bits, int N, int C, int h, int w, long long* onehot,
+                           hipStream_t stream);
+
+/* ---- contrast.hip --------------------------------------------------------- */
+/* loss_helper.py:103-141 per-pixel masks (anchor / low-valid / negative) as class bitmasks */
+int u2pl_contra_classify(const float* prob, long sn, long sc, long sp, const unsigned* lbits,
+                         const float* low_mask, const float* high_mask, int N2, int num_labeled, int C, int h,
+                         int w, float thr_p, float thr_n, int low_rank, int high_rank, unsigned* abits,
+                         unsigned* lowbits, unsigned* nbits, hipStream_t stream);
+/* boolean-mask indexing order (loss_helper.py:115-116,119-123,142): idx int32 [3][32][cap], counts u32 [3][32] */
+size_t u2pl_compact_workspace_bytes(long P);
+int u2pl_compact_lists(const unsigned* abits, const unsigned* lowbits, const unsigned* nbits, long P, int C,
+                       void* workspace, int* idx, long cap, unsigned* counts, hipStream_t stream);
+/* torch.mean(rep_teacher[low_valid], dim=0): loss_helper.py:119-123 */
+size_t u2pl_proto_workspace_bytes(long P, int C, int D);
+int u2pl_class_prototypes(const float* rows, long ld, int D, const int* idx, long cap, const unsigned* counts,
+                          int C, long P, void* workspace, float* proto, hipStream_t stream);
+/* keys = rep_teacher[negative_mask]: loss_helper.py:142 */
+int u2pl_gather_rows_f32(const float* rows, long ld, int D, const int* list, long n, float* out,
+                         hipStream_t stream);
+/* dequeue_and_enqueue FIFO (utils.py:27-47) on a device ring; tail=(head+len)%cap */
+int u2pl_bank_append_f32(float* bank, long cap, long tail, int D, const float* rows, long ld, const int* list,
+                         long n_new, hipStream_t stream);
+/* cosine_similarity / temp + cross_entropy(target 0): loss_helper.py:173-230 */
+size_t u2pl_infonce_job_bytes(void);
+int u2pl_infonce_f32(const void* jobs_dev, int njobs, const float* rep, long ld, int D, int Q, int K,
+                     float temp, float* loss_q, float* ganchor, int* anchor_pix, hipStream_t stream);
+int u2pl_infonce_reduce_f32(const float* loss_q, int njobs, int Q, float inv_valid_seg, float* loss,
+                            hipStream_t stream);
+int u2pl_scatter_add_rows_f32(float* dst, long ld, int D, const int* pix, const float* src, long n,
+                              const float* gout_dev, float scale, hipStream_t stream);
+
+/* ---- losses.hip ----------------------------------------------------------- */
+/* F.cross_entropy(ignore_index=255) fwd/bwd: loss_helper.py:46, 295-320, 531 */
+size_t u2pl_ce_workspace_bytes(void);
+int u2pl_ce_fwd_f32(const float* logits_nchw, const long long* target, int ignore, int N, int C, int H, int W,
+                    int unsup_weight, void* workspace, float* out3, hipStream_t stream);
+int u2pl_ce_bwd_f32(const float* logits_nchw, const long long* target, int ignore, int N, int C, int H, int W,
+                    const float* out3_dev, const float* gout_dev, float gmul, float* grad, hipStream_t stream);
+/* OhemCrossEntropy2dTensor: loss_helper.py:502-531 */
+int u2pl_ohem_prob_f32(const float* logits_nchw, const long long* target, int ignore, int N, int C, int H,
+                       int W, float* mask_prob, unsigned* nvalid, hipStream_t stream);
+int u2pl_ohem_apply_i64(const float* mask_prob, const unsigned* thr_bits, const long long* target, int ignore,
+                        long n, long long* kept_target, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* U2PL_HIP_H */

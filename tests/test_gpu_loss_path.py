@@ -1,0 +1,304 @@
+"""-m gpu parity tests of the loss / reliability / contrastive HIP path against
+the CPU oracle (oracle/restate.py) and the reference-generated goldens."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import restate as R
+from oracle.gen_golden import CONTRA_CFG, formula_bank
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t.to(dtype) if dtype is not None else t
+
+
+def hip():
+    from u2pl_amd import hipops as H
+    return H
+
+
+# ------------------------------------------------------------------ bilinear
+@pytest.mark.parametrize("h,S,C", [(17, 65, 19), (25, 97, 21), (193, 769, 19), (97, 769, 19), (129, 513, 21)])
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_bilinear_up_bitexact(h, S, C, layout):
+    H = hip()
+    x = torch.randn(2, C, h, h, generator=torch.Generator().manual_seed(h)) * 3
+    ref = R.bilinear_ac(x.numpy(), S, S)
+    xd = x.to(DEV)
+    if layout == "nhwc":
+        xd = xd.contiguous(memory_format=torch.channels_last)
+    out = H.bilinear_up(xd, (S, S))
+    assert out.is_contiguous()
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_bilinear_up_backward():
+    import torch.nn.functional as F
+    H = hip()
+    x = torch.randn(2, 5, 17, 17, generator=torch.Generator().manual_seed(3))
+    g = torch.randn(2, 5, 65, 65, generator=torch.Generator().manual_seed(4))
+    xr = x.clone().requires_grad_(True)
+    F.interpolate(xr, (65, 65), mode="bilinear", align_corners=True).backward(g)
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        xd = x.to(DEV).contiguous(memory_format=fmt).requires_grad_(True)
+        H.bilinear_up(xd, (65, 65)).backward(g.to(DEV))
+        assert torch.allclose(xd.grad.cpu(), xr.grad, atol=2e-5, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ pseudo label / entropy
+def test_pseudo_label_golden():
+    H = hip()
+    g = golden("pseudo_65")
+    large = H.bilinear_up(T(g["low"]), (65, 65))
+    assert np.array_equal(large.cpu().numpy(), g["large"])
+    conf, label = H.pseudo_label(large)
+    safe = g["gap"] > 1e-5
+    assert np.array_equal(label.cpu().numpy()[safe], g["label"][safe])
+    assert np.abs(conf.cpu().numpy() - g["conf"]).max() < 1e-6
+
+
+def test_entropy_tier_b():
+    H = hip()
+    g = golden("unsup_65_c19")
+    S = int(g["size"])
+    large = H.bilinear_up(T(g["low_teacher"]), (S, S))
+    tgt = T(g["target"], torch.int64)
+    ws = H.new_select_ws(DEV, tgt.numel())
+    ent = H.entropy_map(large, tgt, ws).cpu().numpy()
+    valid = g["target"] != 255
+    assert np.isnan(ent[~valid]).all()
+    assert np.abs(ent[valid] - g["entropy"][valid]).max() < 2e-6
+    assert int(ws[0]) == int(valid.sum())
+
+
+# ------------------------------------------------------------------ exact selection
+@pytest.mark.parametrize("n", [1, 2, 5, 1000, 65537, 1182722])
+def test_select_percentiles_bitexact(n):
+    H = hip()
+    rng = np.random.default_rng(n)
+    v = rng.random(n).astype(np.float32)
+    if n > 100:
+        v[rng.integers(0, n, n // 7)] = np.float32(0.25)  # heavy ties
+        v[: n // 50] *= -1                                # negatives
+    nanmask = rng.random(n) < 0.1 if n > 10 else np.zeros(n, bool)
+    vd = v.copy()
+    vd[nanmask] = np.nan
+    valid = v[~nanmask]
+    for qs in ([20.0, 80.0], [16.5], [0.0, 100.0, 50.0, 83.7]):
+        ws = H.new_select_ws(DEV, n)
+        ws[0] = int(valid.size)
+        thr = H.run_select(T(vd), ws, [("pct", q) for q in qs]).cpu().numpy()
+        ref = np.array([np.percentile(valid, q) for q in qs], dtype=np.float32)
+        assert np.array_equal(thr.view(np.uint32), ref.view(np.uint32)), (n, qs, thr, ref)
+
+
+def test_select_kth_ohem_rule():
+    H = hip()
+    rng = np.random.default_rng(5)
+    v = rng.random(50000).astype(np.float32)
+    srt = np.sort(v)
+    for k, floor in [(100, 0.7), (45000, 0.7), (50000, 0.0), (80000, 0.7)]:
+        ws = H.new_select_ws(DEV, v.size)
+        ws[0] = 50000 if k != 80000 else 50000
+        thr = H.run_select(T(v), ws, [("kth", k, floor)]).cpu().numpy()[0]
+        if k > 50000:
+            assert np.isinf(thr)
+        else:
+            kth = srt[min(v.size, k) - 1]
+            assert thr == (kth if kth > np.float32(floor) else np.float32(floor))
+
+
+# ------------------------------------------------------------------ unsup loss (a11)
+@pytest.mark.parametrize("tag", ["65_c19", "97_c21"])
+def test_unsup_loss_golden(tag):
+    from u2pl_amd.utils.loss_helper import compute_unsupervised_loss
+    H = hip()
+    g = golden("unsup_" + tag)
+    S = int(g["size"])
+    pred_teacher = H.bilinear_up(T(g["low_teacher"]), (S, S))
+    low_s = T(g["low_student"]).requires_grad_(True)
+    predict = H.bilinear_up(low_s, (S, S))
+    predict.retain_grad()
+    target = T(g["target"], torch.int64)
+    loss = compute_unsupervised_loss(predict, target, float(g["percent"]), pred_teacher)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-4
+    assert (target.cpu().numpy() != g["new_target"]).sum() <= 1          # Tier B (from logits)
+    gr = predict.grad.cpu().numpy()
+    assert np.abs(gr[:, :, ::5, ::5] - g["grad_sub"]).max() < 1e-6
+    assert abs(np.abs(gr.astype(np.float64)).sum() - float(g["grad_abs_sum"])) < 1e-4 * max(1.0, float(g["grad_abs_sum"]))
+    assert low_s.grad is not None and torch.isfinite(low_s.grad).all()
+    # Tier A: reference entropy as fixed input -> bit-exact target overwrite
+    ent = g["entropy"].copy()
+    ent[g["target"] == 255] = np.nan
+    ws = H.new_select_ws(DEV, ent.size)
+    ws[0] = int((g["target"] != 255).sum())
+    thr = H.run_select(T(ent), ws, [("pct", float(g["percent"]))])
+    t2 = T(g["target"], torch.int64)
+    nk = H.drop_high_entropy_(t2, T(ent), thr)
+    assert np.array_equal(t2.cpu().numpy(), g["new_target"].astype(np.int64))
+    assert int(nk) == int((g["new_target"] != 255).sum())
+
+
+# ------------------------------------------------------------------ reliability split (a12/a13)
+@pytest.mark.parametrize("tag", ["65_a20", "97_a13", "65_cutout", "65_b3"])
+def test_reliability_split_golden(tag):
+    H = hip()
+    g = golden("relsplit_" + tag)
+    B = g["label_l"].shape[0]
+    s = g["low_t_train"].shape[-1]
+    C = g["low_t_train"].shape[1]
+    lab_u, lab_l = g["label_u_aug"].astype(np.int64), g["label_l"].astype(np.int64)
+    ent = g["entropy"].copy()
+    ent[lab_u == 255] = np.nan            # Tier A: reference entropy is the fixed input
+    ws = H.new_select_ws(DEV, ent.size)
+    ws[0] = int((lab_u != 255).sum())
+    a = float(g["alpha_t"])
+    thr = H.run_select(T(ent), ws, [("pct", a), ("pct", 100 - a)])
+    tn = thr.cpu().numpy()
+    assert tn[0] == g["low_thresh"] and tn[1] == g["high_thresh"]
+    low, high, lbits = H.reliability_masks(T(ent), thr[0:1], thr[1:2], T(lab_l), T(lab_u), (s, s))
+    assert np.array_equal(low.cpu().numpy().astype(np.uint8), g["low_mask_all"])
+    assert np.array_equal(high.cpu().numpy().astype(np.uint8), g["high_mask_all"])
+    oh = H.unpack_class_bits(lbits, C).cpu().numpy()
+    assert np.array_equal(oh[:B].astype(np.uint8), g["label_l_small"])
+    assert np.array_equal(oh[B:].astype(np.uint8), g["label_u_small"])
+    assert np.array_equal(H.pack_class_bits(T(oh)).cpu().numpy(), lbits.cpu().numpy())
+    # Tier B: entropy recomputed on the device from the logits
+    S = int(g["size"])
+    large = H.bilinear_up(T(g["low_t_train"][B:]), (S, S))
+    ws2 = H.new_select_ws(DEV, ent.size)
+    ent_d = H.entropy_map(large, T(lab_u), ws2)
+    thr2 = H.run_select(ent_d, ws2, [("pct", a), ("pct", 100 - a)])
+    low2, high2, _ = H.reliability_masks(ent_d, thr2[0:1], thr2[1:2], T(lab_l), T(lab_u), (s, s))
+    assert (low2.cpu().numpy().astype(np.uint8) != g["low_mask_all"]).sum() <= 1
+    assert (high2.cpu().numpy().astype(np.uint8) != g["high_mask_all"]).sum() <= 1
+
+
+# ------------------------------------------------------------------ OHEM (a10)
+@pytest.mark.parametrize("tag", ["65_k3000", "65_kbig", "65_k60"])
+def test_ohem_golden(tag):
+    from u2pl_amd.utils.loss_helper import CriterionOhem
+    H = hip()
+    g = golden("ohem_" + tag)
+    S = int(g["size"])
+    target = g["target"].astype(np.int64)
+    C = g["low"].shape[1]
+    onehot = np.eye(C, dtype=np.float32)[np.where(target == 255, 0, target)].transpose(0, 3, 1, 2)
+    main = (H.bilinear_up(T(g["low"]), (S, S)) + 2.5 * T(onehot)).requires_grad_(True)
+    aux = (H.bilinear_up(T(g["low_aux"]), (S, S)) + 1.0 * T(onehot)).requires_grad_(True)
+    crit = CriterionOhem(0.4, thresh=0.7, min_kept=int(g["min_kept"]), ignore_index=255)
+    loss = crit([main, aux], T(target))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-4
+    gm = main.grad.cpu().numpy()
+    assert np.abs(gm[:, :, ::5, ::5] - g["grad_main_sub"]).max() < 1e-6
+    assert np.abs(aux.grad.cpu().numpy()[:, :, ::5, ::5] - g["grad_aux_sub"]).max() < 1e-6
+    assert abs(int((np.abs(gm).sum(1) > 0).sum()) - int(g["n_kept_main"])) <= 1
+
+
+# ------------------------------------------------------------------ memory bank (a15)
+def test_bank_sequence_golden():
+    H = hip()
+    g = golden("bank_seq")
+    bank = H.DeviceMemoryBank(1, [int(g["queue_size"])], feat_dim=16, device=DEV)
+    for i, n in enumerate(g["sizes"]):
+        keys = T(g[f"keys{i}"])
+        bank.append_rows(0, keys if n else torch.zeros(1, 16, device=DEV), 16, int(n))
+        assert np.array_equal(bank.logical(0).cpu().numpy(), g[f"queue{i}"])
+        assert bank.ptr[0] == int(g[f"ptr{i}"])
+
+
+# ------------------------------------------------------------------ contrastive loss (a14-a16)
+@pytest.mark.parametrize("tag", ["65_empty", "65_prefill"])
+@pytest.mark.parametrize("api", ["device_bank", "reference_lists"])
+def test_contra_memobank_golden(tag, api):
+    from u2pl_amd.utils.loss_helper import compute_contra_memobank_loss
+    H = hip()
+    g = golden("contra_" + tag)
+    C, D = 19, int(g["D"])
+    qs = [int(x) for x in g["queue_size"]]
+    pre = int(g["prefill"])
+    if api == "device_bank":
+        bank = H.DeviceMemoryBank(C, qs, D, DEV)
+        for c in range(C):
+            if pre:
+                bank.load_logical(c, formula_bank(c, pre + 3 * c, D).to(DEV))
+        ptrs = [torch.zeros(1, dtype=torch.long) for _ in range(C)]
+    else:
+        bank = [[formula_bank(c, pre + 3 * c, D) if pre else torch.zeros(0, D)] for c in range(C)]
+        ptrs = [torch.zeros(1, dtype=torch.long) for _ in range(C)]
+    for st in range(int(g["num_steps"])):
+        p = f"s{st}_"
+        B = g[p + "label_l"].shape[0]
+        prob = T(g[p + "prob_all"])
+        for fmt in ([torch.channels_last] if st else [torch.contiguous_format]):
+            rep = T(g[p + "rep"]).contiguous(memory_format=fmt).requires_grad_(True)
+            rep_t = T(g[p + "rep_teacher"]).contiguous(memory_format=fmt)
+            torch.set_rng_state(torch.from_numpy(g[p + "rng_state"]))
+            new_keys, loss = compute_contra_memobank_loss(
+                rep, T(g[p + "label_l_small"], torch.int64), T(g[p + "label_u_small"], torch.int64), prob[:B], prob[B:],
+                T(g[p + "low_mask_all"], torch.float32), T(g[p + "high_mask_all"], torch.float32), CONTRA_CFG, bank, ptrs,
+                qs, rep_t)
+            loss.backward()
+        assert list(new_keys) == list(g[p + "new_keys"])
+        assert abs(float(loss) - float(g[p + "loss"])) < 1e-4
+        assert np.abs(rep.grad.cpu().numpy() - g[p + "grad_rep"]).max() < 1e-5
+        lens = [bank[c][0].shape[0] for c in range(C)]
+        assert lens == list(g[p + "bank_len"])
+        assert [int(q[0]) for q in ptrs] == list(g[p + "queue_ptr"])
+    for c in range(C):
+        b = bank[c][0].cpu().numpy()
+        assert np.array_equal(b[:4], g[f"bankF_{c}_head"]) and np.array_equal(b[-4:], g[f"bankF_{c}_tail"])
+        assert np.allclose(b.astype(np.float64).sum(0), g[f"bankF_{c}_sum"], atol=1e-9)
+
+
+def test_contra_single_class_returns_zero_with_zero_grads():
+    from u2pl_amd.utils.loss_helper import compute_contra_memobank_loss
+    H = hip()
+    C, D, s, B = 19, 64, 9, 2
+    rep = torch.randn(2 * B, D, s, s, device=DEV, requires_grad=True)
+    lab = torch.zeros(B, C, s, s, dtype=torch.int64, device=DEV)
+    lab[0, 3] = 1  # a single class present
+    prob = torch.softmax(torch.randn(2 * B, C, s, s, device=DEV), 1)
+    ones = torch.ones(2 * B, 1, s, s, device=DEV)
+    bank = H.DeviceMemoryBank(C, [50] * C, D, DEV)
+    keys, loss = compute_contra_memobank_loss(rep, lab, torch.zeros_like(lab), prob[:B], prob[B:], ones, ones,
+                                              CONTRA_CFG, bank, None, [50] * C, rep.detach())
+    loss.backward()
+    assert float(loss) == 0.0 and rep.grad is not None and float(rep.grad.abs().sum()) == 0.0
+
+
+# ------------------------------------------------------------------ full-size properties (769^2)
+def test_full_size_reliability_properties():
+    """BASELINE config-3 sizes: size-independent properties instead of a CPU oracle pass:
+    exact thresholds vs numpy on the device entropy, mask fractions == alpha, Q0 structure."""
+    H = hip()
+    B, C, S, s = 2, 19, 769, 193
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    low = torch.randn(2 * B, C, s, s, device=DEV, generator=gen) * 3
+    low = low.contiguous(memory_format=torch.channels_last)
+    large = H.bilinear_up(low[B:], (S, S))
+    conf, label_u = H.pseudo_label(large + 0.5 * torch.randn(large.shape, device=DEV, generator=gen))
+    label_l = torch.randint(0, C, (B, S, S), device=DEV, generator=gen)
+    label_l[:, :8] = 255
+    ws = H.new_select_ws(DEV, B * S * S)
+    ent = H.entropy_map(large, label_u, ws)
+    thr = H.run_select(ent, ws, [("pct", 20.0), ("pct", 80.0), ("pct", 80.0)])
+    e = ent.cpu().numpy().ravel()
+    ref = np.array([np.percentile(e, 20.0), np.percentile(e, 80.0)], dtype=np.float32)
+    assert np.array_equal(thr.cpu().numpy()[:2], ref) and thr[1] == thr[2]
+    lo, hi, lbits = H.reliability_masks(ent, thr[0:1], thr[1:2], label_l, label_u, (s, s))
+    iy = R.nearest_src_index(np.arange(s), S, s)
+    e2 = ent.cpu().numpy()[:, iy[:, None], iy[None, :]]
+    assert np.array_equal(lo[B:, 0].cpu().numpy() > 0, e2 <= ref[0])
+    assert np.array_equal(hi[B:, 0].cpu().numpy() > 0, e2 >= ref[1])
+    assert abs(float((e <= ref[0]).mean()) - 0.2) < 1e-3
+    lb = lbits.cpu().numpy()
+    assert (lb[1] == 0).all() and (lb[3] == 0).all() and (lb[2] != 0).all()
+    assert (lb[0][8 // 4 + 1:] != 0).all() and (lb[0][0] == 0).all()

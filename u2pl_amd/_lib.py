@@ -1,0 +1,104 @@
+"""ctypes loader for libu2pl_hip.so (the C ABI declared in include/u2pl_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing the
+import raises, and every op raises if it is handed a non-GPU tensor.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libu2pl_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "u2pl_hip.h")
+
+_CT = {
+    "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
+    "size_t": ctypes.c_size_t, "long long": ctypes.c_longlong, "unsigned": ctypes.c_uint,
+    "hipStream_t": ctypes.c_void_p,
+}
+
+
+def parse_header(path=HEADER_PATH):
+    """-> {name: (restype, [argtypes], [argnames])} for every declared entry point."""
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(int|size_t)\s+(u2pl_\w+)\s*\(([^)]*)\)\s*;", txt):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        at, an = [], []
+        for a in [x.strip() for x in args.split(",")]:
+            if a in ("void", ""):
+                continue
+            if "*" in a:
+                at.append(ctypes.c_void_p)
+                an.append(a.split("*")[-1].strip())
+            else:
+                toks = a.split()
+                ty = " ".join(t for t in toks[:-1] if t != "const")
+                at.append(_CT[ty])
+                an.append(toks[-1])
+        out[name] = (_CT[ret], at, an)
+    return out
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -m u2pl_amd.build_ext` "
+                "(hipcc --offload-arch=gfx950).  u2pl_amd has no CPU/PyTorch fallback."
+            )
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        self.decls = parse_header()
+        for name, (ret, at, _) in self.decls.items():
+            fn = getattr(self.cdll, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = ret
+            fn.argtypes = at
+
+    def __getattr__(self, name):
+        return getattr(self.cdll, name)
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = _Lib()
+    return _LIB
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        if not x.is_cuda:
+            raise HipError("u2pl_amd HIP op got a non-GPU tensor (no CPU fallback exists)")
+        return x.data_ptr()
+    return x
+
+
+def stream_ptr():
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Call entry point `name`; tensors are passed as device pointers; the HIP
+    stream (torch's current stream) is appended automatically."""
+    L = lib()
+    fn = getattr(L.cdll, name)
+    conv = [_ptr(a) for a in args]
+    rc = fn(*conv, stream_ptr())
+    if rc != 0:
+        raise HipError(f"{name} failed with code {rc}")
+
+
+def query(name, *args):
+    return getattr(lib().cdll, name)(*args)

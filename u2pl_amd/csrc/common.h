@@ -1,0 +1,78 @@
+// Shared device helpers for libu2pl_hip.so (gfx950 / CDNA4 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define U2PL_API extern "C" __attribute__((visibility("default")))
+
+#define U2PL_LAUNCH_CHECK()                      \
+    do {                                         \
+        hipError_t e__ = hipGetLastError();      \
+        if (e__ != hipSuccess) return (int)e__;  \
+    } while (0)
+
+#define U2PL_EINVAL 1001  // bad argument (reported before any launch)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline int grid_for(long n, int block, int max_blocks = 256 * 16) {
+    long g = (n + block - 1) / block;
+    if (g > max_blocks) g = max_blocks;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---- wave64 reductions ------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_sum_u(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// order-preserving float -> uint key (NaN (positive quiet) sorts above +inf)
+__device__ __forceinline__ unsigned f32_key(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(unsigned k) {
+    unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+// align_corners=True source coordinate pieces (torch CPU arithmetic, Q8)
+struct AcCoord {
+    int i0, i1;
+    float l0, l1;
+};
+__device__ __forceinline__ AcCoord ac_coord(int dst, float scale, int in_size) {
+    AcCoord c;
+    float src = __fmul_rn((float)dst, scale);
+    c.i0 = (int)src;  // src >= 0: trunc == floor
+    if (c.i0 > in_size - 1) c.i0 = in_size - 1;
+    c.i1 = c.i0 + (c.i0 < in_size - 1 ? 1 : 0);
+    c.l1 = __fsub_rn(src, (float)c.i0);
+    c.l0 = __fsub_rn(1.0f, c.l1);
+    return c;
+}
+static inline float ac_scale_host(long in, long out) {
+    return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.0f;
+}
+// legacy nearest: src = min(floor(dst * float32(in/out)), in-1)
+__device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
+    int s = (int)floorf(__fmul_rn((float)dst, scale));
+    return s < in_size - 1 ? s : in_size - 1;
+}

@@ -1,0 +1,363 @@
+"""Thin torch <-> C-ABI glue for the loss/reliability/contrastive kernels.
+
+Everything numeric happens in libu2pl_hip.so; torch supplies device memory,
+the current HIP stream and the autograd tape (torch.autograd.Function)."""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, query
+
+SEL_WORD_VAL = 40
+SEL_WORD_THR = 56
+MAXC = 32
+
+
+def _f32c(x):
+    if x.dtype != torch.float32:
+        raise _lib.HipError("expected float32 tensor")
+    return x
+
+
+def _chk_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.HipError("u2pl_amd ops need GPU tensors; there is no CPU fallback")
+
+
+def _strides_nchw(x):
+    """(sn, sc, sh, sw) in elements of a 4-d tensor."""
+    return x.stride(0), x.stride(1), x.stride(2), x.stride(3)
+
+
+# --------------------------------------------------------------------------- bilinear
+class _BilinearUp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, H, W):
+        _chk_cuda(x)
+        N, C, h, w = x.shape
+        out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+        call("u2pl_bilinear_up_f32", _f32c(x), *_strides_nchw(x), N, C, h, w, out, H, W)
+        ctx.in_meta = (x.shape, x.stride())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, stride = ctx.in_meta
+        N, C, h, w = shape
+        g = g.contiguous()
+        gin = torch.empty_strided(shape, stride, dtype=torch.float32, device=g.device)
+        call("u2pl_bilinear_up_bwd_f32", g, N, C, g.shape[2], g.shape[3], gin, *stride, h, w)
+        return gin, None, None
+
+
+def bilinear_up(x, size):
+    """F.interpolate(x, size, mode='bilinear', align_corners=True) -> NCHW contiguous."""
+    return _BilinearUp.apply(x, int(size[0]), int(size[1]))
+
+
+# --------------------------------------------------------------------------- pseudo label
+def pseudo_label(logits_large):
+    """softmax + max over classes (train_semi.py:323-324) -> (conf, label int64)."""
+    _chk_cuda(logits_large)
+    x = _f32c(logits_large).contiguous()
+    N, C, H, W = x.shape
+    conf = torch.empty((N, H, W), dtype=torch.float32, device=x.device)
+    label = torch.empty((N, H, W), dtype=torch.int64, device=x.device)
+    call("u2pl_pseudo_label_f32", x, N, C, H, W, conf, label)
+    return conf, label
+
+
+# --------------------------------------------------------------------------- selection
+def new_select_ws(device, n_total):
+    words = query("u2pl_select_workspace_bytes") // 4
+    ws = torch.zeros(words, dtype=torch.int32, device=device)
+    ws[1] = int(n_total)
+    return ws
+
+
+def percentile_q32(q):
+    """numpy: q = np.true_divide(q, float32(100)) with a python-float q (weak scalar)."""
+    return np.float32(q) / np.float32(100)
+
+
+def run_select(values, ws, specs):
+    """specs: list of ('pct', q) | ('kth', k, floor_thr).  Thresholds land in
+    ws[SEL_WORD_THR + j] (float bits); returns a float32 view of them."""
+    n = len(specs)
+    kind = np.zeros(n, np.int32)
+    q32 = np.zeros(n, np.float32)
+    kp = np.zeros(n, np.int64)
+    fp = np.zeros(n, np.float32)
+    for j, s in enumerate(specs):
+        if s[0] == "pct":
+            q32[j] = percentile_q32(s[1])
+        else:
+            kind[j] = 1
+            kp[j] = int(s[1])
+            fp[j] = np.float32(s[2])
+    dev = values.device
+    # one H2D copy; the 8-byte field goes first so every array stays naturally aligned
+    buf = torch.from_numpy(np.concatenate([kp.view(np.uint8), kind.view(np.uint8), q32.view(np.uint8),
+                                           fp.view(np.uint8)])).to(dev, non_blocking=True)
+    base = buf.data_ptr()
+    call("u2pl_select_f32", values, values.numel(), n, base + 8 * n, base + 12 * n, base, base + 16 * n, ws)
+    return ws[SEL_WORD_THR:SEL_WORD_THR + n].view(torch.float32)
+
+
+def entropy_map(logits_large, label, ws, ignore=255):
+    """per-pixel entropy (NaN on ignored pixels); accumulates #valid into ws[0]."""
+    x = _f32c(logits_large).contiguous()
+    N, C, H, W = x.shape
+    ent = torch.empty((N, H, W), dtype=torch.float32, device=x.device)
+    call("u2pl_entropy_f32", x, label, ignore, N, C, H, W, ent, ws)
+    return ent
+
+
+# --------------------------------------------------------------------------- cross entropy
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore, unsup_weight, gmul):
+        _chk_cuda(logits, target)
+        x = _f32c(logits).contiguous()
+        N, C, H, W = x.shape
+        work = torch.empty(query("u2pl_ce_workspace_bytes"), dtype=torch.uint8, device=x.device)
+        out3 = torch.empty(3, dtype=torch.float32, device=x.device)
+        call("u2pl_ce_fwd_f32", x, target, ignore, N, C, H, W, int(unsup_weight), work, out3)
+        ctx.save_for_backward(x, target, out3)
+        ctx.ignore, ctx.gmul = ignore, gmul
+        return out3[0].clone() * gmul if gmul != 1.0 else out3[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, target, out3 = ctx.saved_tensors
+        N, C, H, W = x.shape
+        grad = torch.empty_like(x)
+        call("u2pl_ce_bwd_f32", x, target, ctx.ignore, N, C, H, W, out3, g.contiguous(), float(ctx.gmul), grad)
+        return grad, None, None, None, None
+
+
+def cross_entropy(logits, target, ignore_index=255, unsup_weight=False, scale=1.0):
+    """F.cross_entropy(logits, target, ignore_index) [* B*H*W/n_valid if unsup_weight] * scale."""
+    if target.dtype != torch.int64 or not target.is_contiguous():
+        target = target.long().contiguous()
+    return _CrossEntropy.apply(logits, target, int(ignore_index), bool(unsup_weight), float(scale))
+
+
+def ohem_kept_target(pred, target, thresh, min_kept, ignore_index=255):
+    """OhemCrossEntropy2dTensor target rewrite (loss_helper.py:502-529), no host sync."""
+    x = _f32c(pred.detach()).contiguous()
+    N, C, H, W = x.shape
+    target = target.long().contiguous()
+    ws = new_select_ws(x.device, N * H * W)
+    mp = torch.empty((N, H, W), dtype=torch.float32, device=x.device)
+    call("u2pl_ohem_prob_f32", x, target, ignore_index, N, C, H, W, mp, ws)
+    thr = run_select(mp, ws, [("kth", int(min_kept), float(thresh))])
+    kept = torch.empty_like(target)
+    call("u2pl_ohem_apply_i64", mp, thr, target, ignore_index, target.numel(), kept)
+    return kept
+
+
+# --------------------------------------------------------------------------- reliability split
+def drop_high_entropy_(target, entropy, thr_bits, ignore=255):
+    """target[entropy >= thr] = ignore, in place (loss_helper.py:41-43)."""
+    nk = torch.zeros(1, dtype=torch.int32, device=target.device)
+    call("u2pl_apply_drop_i64", entropy, thr_bits, target, ignore, target.numel(), nk)
+    return nk
+
+
+def reliability_masks(entropy, thr_lo, thr_hi, label_l, label_u_aug, out_hw, negative_high_entropy=True,
+                      ignore=255):
+    """train_semi.py:408-465 -> low_mask_all, high_mask_all (2B,1,h,w) float and
+    the (quirky) multi-hot labels as class bitmasks (2B,h,w) int32."""
+    B, H, W = label_u_aug.shape
+    h, w = out_hw
+    dev = entropy.device
+    low = torch.empty((2 * B, 1, h, w), dtype=torch.float32, device=dev)
+    high = torch.empty((2 * B, 1, h, w), dtype=torch.float32, device=dev)
+    lbits = torch.empty((2 * B, h, w), dtype=torch.int32, device=dev)
+    call("u2pl_reliability_masks", entropy, thr_lo, thr_hi, label_l.contiguous(), label_u_aug.contiguous(),
+         ignore, B, H, W, h, w, int(bool(negative_high_entropy)), low, high, lbits)
+    return low, high, lbits
+
+
+def pack_class_bits(onehot):
+    N, C, h, w = onehot.shape
+    bits = torch.empty((N, h, w), dtype=torch.int32, device=onehot.device)
+    call("u2pl_pack_class_bits", onehot.long().contiguous(), N, C, h, w, bits)
+    return bits
+
+
+def unpack_class_bits(bits, C):
+    N, h, w = bits.shape
+    oh = torch.empty((N, C, h, w), dtype=torch.int64, device=bits.device)
+    call("u2pl_unpack_class_bits", bits, N, C, h, w, oh)
+    return oh
+
+
+# --------------------------------------------------------------------------- memory bank
+class DeviceMemoryBank:
+    """Per-class FIFO of negative keys resident in HBM (replaces the reference's
+    list of CPU tensors, train_semi.py:161-169 / utils.py:27-47).  Logical row j
+    of class c lives at physical slot (head[c] + j) % cap[c]."""
+
+    def __init__(self, num_classes, queue_size, feat_dim=256, device="cuda"):
+        self.C, self.D = num_classes, feat_dim
+        self.cap = [int(q) for q in queue_size]
+        self.buf = [torch.zeros((q, feat_dim), dtype=torch.float32, device=device) for q in self.cap]
+        self.head = [0] * num_classes
+        self.length = [0] * num_classes
+        self.ptr = [0] * num_classes  # reference's queue_ptr bookkeeping (utils.py:36-45)
+
+    def append_rows(self, c, rows, ld, n_new, idx_list=None):
+        """append n_new rows (rows base pointer/tensor, leading dim ld, optional int32 index list)."""
+        if n_new <= 0:
+            self._book(c, 0)
+            return
+        cap = self.cap[c]
+        tail = (self.head[c] + self.length[c]) % cap
+        call("u2pl_bank_append_f32", self.buf[c], cap, tail, self.D, rows, ld, idx_list, n_new)
+        tot = self.length[c] + n_new
+        new_tail = (tail + n_new) % cap
+        self.length[c] = min(tot, cap)
+        self.head[c] = (new_tail - self.length[c]) % cap
+        self._book(c, n_new)
+
+    def _book(self, c, bs):
+        if self.length[c] >= self.cap[c]:
+            self.ptr[c] = self.cap[c]
+        else:
+            self.ptr[c] = (self.ptr[c] + bs) % self.cap[c]
+
+    def logical(self, c):
+        n, h, cap = self.length[c], self.head[c], self.cap[c]
+        if h + n <= cap:
+            return self.buf[c][h:h + n]
+        return torch.cat((self.buf[c][h:], self.buf[c][: (h + n) % cap]))
+
+    def load_logical(self, c, rows):
+        n = min(rows.shape[0], self.cap[c])
+        self.buf[c][:n].copy_(rows[-n:])
+        self.head[c], self.length[c] = 0, n
+
+    def __len__(self):
+        return self.C
+
+    def __getitem__(self, c):  # memobank[c][0] compatibility
+        return [self.logical(c)]
+
+
+# --------------------------------------------------------------------------- contrastive core
+class ContraPhase1:
+    """Outputs of phase 1 (loss_helper.py:80-154) living on the device."""
+    __slots__ = ("idx", "counts", "proto", "cap", "counts_host")
+
+
+def contra_phase1(rep_teacher_rows, ld, D, prob, prob_strides, lbits, low_mask, high_mask, num_labeled, C, h, w,
+                  cfg):
+    """classify + compaction + prototypes.  prob_strides = (sn, sc, sp)."""
+    dev = lbits.device
+    N2 = lbits.shape[0]
+    P = N2 * h * w
+    abits = torch.empty(P, dtype=torch.int32, device=dev)
+    lowbits = torch.empty(P, dtype=torch.int32, device=dev)
+    nbits = torch.empty(P, dtype=torch.int32, device=dev)
+    call("u2pl_contra_classify", prob, *prob_strides, lbits, low_mask, high_mask, N2, num_labeled, C, h, w,
+         float(cfg["current_class_threshold"]), float(cfg["current_class_negative_threshold"]),
+         int(cfg["low_rank"]), int(cfg["high_rank"]), abits, lowbits, nbits)
+    out = ContraPhase1()
+    out.cap = P
+    out.idx = torch.empty((3, MAXC, P), dtype=torch.int32, device=dev)
+    out.counts = torch.empty((3, MAXC), dtype=torch.int32, device=dev)
+    work = torch.empty(query("u2pl_compact_workspace_bytes", P), dtype=torch.uint8, device=dev)
+    call("u2pl_compact_lists", abits, lowbits, nbits, P, C, work, out.idx, P, out.counts)
+    pw = torch.empty(query("u2pl_proto_workspace_bytes", P, C, D), dtype=torch.uint8, device=dev)
+    out.proto = torch.empty((C, D), dtype=torch.float32, device=dev)
+    call("u2pl_class_prototypes", rep_teacher_rows, ld, D, out.idx, P, out.counts, C, P, pw, out.proto)
+    out.counts_host = None
+    return out
+
+
+class _InfoNCE(torch.autograd.Function):
+    """rep_rows: (P, D) contiguous view of the student features (requires grad)."""
+
+    @staticmethod
+    def forward(ctx, rep_rows, jobs_dev, njobs, Q, K, temp, valid_seg, keepalive):
+        P, D = rep_rows.shape
+        dev = rep_rows.device
+        loss_q = torch.empty((njobs, Q), dtype=torch.float32, device=dev)
+        ganchor = torch.empty((njobs, Q, D), dtype=torch.float32, device=dev)
+        apix = torch.empty((njobs, Q), dtype=torch.int32, device=dev)
+        call("u2pl_infonce_f32", jobs_dev, njobs, rep_rows, D, D, Q, K, float(temp), loss_q, ganchor, apix)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        call("u2pl_infonce_reduce_f32", loss_q, njobs, Q, 1.0 / valid_seg, loss)
+        ctx.save_for_backward(ganchor, apix)
+        ctx.meta = (P, D, njobs * Q, 1.0 / (Q * valid_seg))
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        ganchor, apix = ctx.saved_tensors
+        P, D, n, scale = ctx.meta
+        grad = torch.zeros((P, D), dtype=torch.float32, device=g.device)
+        call("u2pl_scatter_add_rows_f32", grad, D, D, apix, ganchor, n, g.contiguous(), float(scale))
+        return grad, None, None, None, None, None, None, None
+
+
+class _ZeroTimesSum(torch.autograd.Function):
+    """`0 * rep.sum()` of the reference (loss_helper.py:160-162,187; Q13):
+    a zero loss that still hands ZERO (not None) gradients to the rep head."""
+
+    @staticmethod
+    def forward(ctx, rep):
+        ctx.meta = (rep.shape, None)
+        return torch.zeros((), dtype=torch.float32, device=rep.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, stride = ctx.meta
+        return torch.zeros(shape, dtype=torch.float32, device=g.device)
+
+
+def zero_times_sum(rep):
+    return _ZeroTimesSum.apply(rep)
+
+
+def infonce_loss(rep_rows, ph1, bank, valid_classes, counts_host, cfg, randint=None):
+    """Phase 2 (loss_helper.py:156-233) incl. the class-index mismatch (Q1).
+    randint(high, n) defaults to torch.randint on the global CPU generator."""
+    Q, K = int(cfg["num_queries"]), int(cfg["num_negatives"])
+    valid_seg = len(valid_classes)
+    if randint is None:
+        def randint(high, n):
+            return torch.randint(high, size=(n,))
+    jobs, idx_chunks = [], []
+    for i in range(valid_seg):
+        n_cand = int(counts_host[0][i])
+        vc = valid_classes[i]
+        if n_cand > 0 and bank.length[vc] > 0:
+            ia = randint(n_cand, Q)
+            inn = randint(bank.length[vc], Q * K)
+            jobs.append((i, vc))
+            idx_chunks += [ia.to(torch.int64), inn.to(torch.int64)]
+    if not jobs:
+        return None
+    dev = rep_rows.device
+    idx_all = torch.cat(idx_chunks).to(dev, non_blocking=True)
+    base = idx_all.data_ptr()
+    D = rep_rows.shape[1]
+    jb = np.zeros((len(jobs), 7), dtype=np.int64)
+    off = 0
+    for j, (i, vc) in enumerate(jobs):
+        jb[j, 0] = ph1.idx.data_ptr() + (0 * MAXC + i) * ph1.cap * 4
+        jb[j, 1] = base + off * 8
+        jb[j, 2] = base + (off + Q) * 8
+        jb[j, 3] = ph1.proto.data_ptr() + i * D * 4
+        jb[j, 4] = bank.buf[vc].data_ptr()
+        jb[j, 5] = bank.cap[vc]
+        jb[j, 6] = bank.head[vc]
+        off += Q + Q * K
+    assert query("u2pl_infonce_job_bytes") == 56
+    jobs_dev = torch.from_numpy(jb).to(dev, non_blocking=True)
+    return _InfoNCE.apply(rep_rows, jobs_dev, len(jobs), Q, K, float(cfg["temperature"]), valid_seg,
+                          (idx_all, ph1))

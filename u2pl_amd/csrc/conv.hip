@@ -1,0 +1,451 @@
+// Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32,
+// exact f32 == fmaf chain) for the dilated ResNet-101 + DeepLabv3+ stack
+// (reference u2pl/models/{resnet,base,decoder}.py run
+// through torch/cuDNN).  Activations are NHWC "rows" (pixel-major, channel
+// contiguous, leading dim ld so channel slices of concat buffers work in place);
+// weights are [Cout][R][S][Cin] (torch OIHW storage in channels_last format).
+//
+//   conv_igemm : Y[m][co] = sum_{r,s,ci} X[gather(m,r,s)][ci] * W[co][r][s][ci]
+//                forward (gather: o*stride - pad + r*dil) and data-gradient
+//                (gather: (i + pad - r*dil)/stride with divisibility test, weights
+//                pre-transposed to [Cin][R][S][Cout]) share one kernel.
+//   conv_wgrad : dW[co][r][s][ci] = sum_m dY[m][co] * X[gather(m,r,s)][ci]
+//                split over pixel ranges -> partial slabs -> ordered reduce
+//                (deterministic; no float atomics).
+//
+// Tiling: 256 threads = 4 waves (2x2), each wave owns (32*TM)x(32*TN) outputs as
+// TM*TN 32x32 MFMA accumulators; BK = 32; LDS double-buffered, global->register
+// prefetch of the next K chunk overlaps the MFMAs of the current one.  K order
+// inside an 8-wide group is permuted (lane half h supplies k = 4h+j at step j) so
+// each lane fetches its four A / B operands with one ds_read_b128.
+#include "common.h"
+#include "u2pl_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BK 32
+#define LDP (BK + 4)  // LDS row pitch (floats): 16 B aligned, breaks the 128 B stride
+
+struct ConvGeom {
+    int N, Hin, Win, Cin, Hout, Wout, Cout, R, S;
+    int mul, off_h, off_w, step, log2div;  // gather: (o*mul + off + r*step) >> log2div
+};
+
+__device__ __forceinline__ bool gather_coord(int base, int tap, int step, int log2div, int lim, int& out) {
+    int v = base + tap * step;
+    if (v < 0) return false;
+    if (log2div) {
+        if (v & ((1 << log2div) - 1)) return false;
+        v >>= log2div;
+    }
+    out = v;
+    return v < lim;
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__ x, long ldx,
+                                                       const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                       long ldy, ConvGeom g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int RA = BM / 32, RB = BN / 32;  // rows per thread per chunk
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                  // [2][BM][LDP]
+    float* Bs = smem + 2 * BM * LDP;   // [2][BN][LDP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long M = (long)g.N * g.Hout * g.Wout;
+    const int K = g.R * g.S * g.Cin;
+    const int nk = K / BK;
+    const int cpt = g.Cin / BK;  // chunks per tap
+    // M tiles fastest: concurrently resident blocks share the same weight tile (L2 reuse)
+    const long m0 = (long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    const int kq = tid & 7, r0 = tid >> 3;
+    int bh[RA], bw[RA];
+    long nb[RA];
+    bool mv[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        long m = m0 + r0 + 32 * i;
+        mv[i] = m < M;
+        long mm = mv[i] ? m : 0;
+        int wo = (int)(mm % g.Wout);
+        long t = mm / g.Wout;
+        int ho = (int)(t % g.Hout);
+        int n = (int)(t / g.Hout);
+        bh[i] = ho * g.mul + g.off_h;
+        bw[i] = wo * g.mul + g.off_w;
+        nb[i] = (long)n * g.Hin * g.Win;
+    }
+    float4 ra[RA], rb[RB];
+    auto load_chunk = [&](int kc) {
+        const int tap = kc / cpt, c0 = (kc - tap * cpt) * BK;
+        const int r = tap / g.S, s = tap - r * g.S;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            int ih, iw;
+            bool ok = mv[i] && gather_coord(bh[i], r, g.step, g.log2div, g.Hin, ih) &&
+                      gather_coord(bw[i], s, g.step, g.log2div, g.Win, iw);
+            ra[i] = ok ? *(const float4*)(x + (nb[i] + (long)ih * g.Win + iw) * ldx + c0 + kq * 4)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            int co = n0 + r0 + 32 * i;
+            rb[i] = co < g.Cout ? *(const float4*)(w + (long)co * K + (long)kc * BK + kq * 4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *(float4*)(As + ((long)buf * BM + r0 + 32 * i) * LDP + kq * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *(float4*)(Bs + ((long)buf * BN + r0 + 32 * i) * LDP + kq * 4) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    const int li = lane & 31, lh = lane >> 5;
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) load_chunk(kc + 1);
+        const float* Ab = As + ((long)buf * BM + wm * 32 * TM + li) * LDP + 4 * lh;
+        const float* Bb = Bs + ((long)buf * BN + wn * 32 * TN + li) * LDP + 4 * lh;
+#pragma unroll
+        for (int gk = 0; gk < BK / 8; ++gk) {
+            float4 a4[TM], b4[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) a4[a] = *(const float4*)(Ab + a * 32 * LDP + gk * 8);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) b4[b] = *(const float4*)(Bb + b * 32 * LDP + gk * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        const float av = j == 0 ? a4[a].x : j == 1 ? a4[a].y : j == 2 ? a4[a].z : a4[a].w;
+                        const float bv = j == 0 ? b4[b].x : j == 1 ? b4[b].y : j == 2 ? b4[b].z : b4[b].w;
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
+                    }
+        }
+        if (kc + 1 < nk) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int co = n0 + wn * 32 * TN + b * 32 + li;
+            if (co >= g.Cout) continue;
+            const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long m = m0 + wm * 32 * TM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m < M) y[m * ldy + co] = acc[a][b][e] + bv;
+            }
+        }
+}
+
+template <int TM, int TN>
+static int launch_igemm(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
+                        const ConvGeom& g, hipStream_t stream) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    const long M = (long)g.N * g.Hout * g.Wout;
+    const size_t lds = (size_t)2 * (BM + BN) * LDP * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)k_conv_igemm<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)cdiv(M, BM), (unsigned)cdiv(g.Cout, BN));
+    hipLaunchKernelGGL((k_conv_igemm<TM, TN>), grid, dim3(256), lds, stream, x, ldx, w, bias, y, ldy, g);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+static int log2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+static int run_igemm(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
+                     const ConvGeom& g, hipStream_t stream) {
+    if (g.Cin % BK) return U2PL_EINVAL;
+    if (g.Cout > 64) return launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, stream);
+    return launch_igemm<2, 1>(x, ldx, w, bias, y, ldy, g, stream);
+}
+
+// nn.Conv2d forward: resnet.py:25-41,178-186; base.py:23-83; decoder.py:60-106,132-138
+U2PL_API int u2pl_conv2d_fwd_f32(const float* x, long ldx, const float* w, const float* bias, float* y,
+                                 long ldy, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
+                                 int R, int S, int stride, int pad, int dil, hipStream_t stream) {
+    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
+    return run_igemm(x, ldx, w, bias, y, ldy, g, stream);
+}
+
+// data gradient: dX[n,hi,wi,ci] = sum_{r,s,co} dY[n,(hi+pad-r*dil)/st,(wi+pad-s*dil)/st,co] * W[co][r][s][ci]
+// wT = weights transposed to [Cin][R][S][Cout] (u2pl_weight_transpose_f32)
+U2PL_API int u2pl_conv2d_dgrad_f32(const float* dy, long lddy, const float* wT, float* dx, long lddx, int N,
+                                   int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S,
+                                   int stride, int pad, int dil, hipStream_t stream) {
+    int l2 = log2_exact(stride);
+    if (l2 < 0) return U2PL_EINVAL;
+    // roles swap: the "input" of the gather is dY (Hout x Wout x Cout), the output is dX
+    ConvGeom g = {N, Hout, Wout, Cout, Hin, Win, Cin, R, S, 1, pad, pad, -dil, l2};
+    return run_igemm(dy, lddy, wT, nullptr, dx, lddx, g, stream);
+}
+
+// [A][T][B] -> [B][T][A]   (A = Cout, T = R*S, B = Cin)
+__global__ void k_weight_transpose(const float* __restrict__ w, float* __restrict__ wt, int A, int T, int B) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        int a = a0 + i, b = b0 + threadIdx.x;
+        tile[i][threadIdx.x] = (a < A && b < B) ? w[((long)a * T + t) * B + b] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        int b = b0 + i, a = a0 + threadIdx.x;
+        if (a < A && b < B) wt[((long)b * T + t) * A + a] = tile[threadIdx.x][i];
+    }
+}
+U2PL_API int u2pl_weight_transpose_f32(const float* w, float* wt, int Cout, int RS, int Cin, hipStream_t stream) {
+    dim3 grid(cdiv(Cin, 32), cdiv(Cout, 32), RS);
+    hipLaunchKernelGGL(k_weight_transpose, grid, dim3(32, 8), 0, stream, w, wt, Cout, RS, Cin);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient.  GEMM view per tap: A^T = dY (pixels x Cout), B = gathered X
+// (pixels x Cin), reduction over pixels.  LDS tiles are [k = pixel][i] so the
+// MFMA operand fetch (lane l -> row k = 2*kk + (l>>5), column l&31) is a
+// conflict-free ds_read_b32.
+// ---------------------------------------------------------------------------
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad(const float* __restrict__ dy, long lddy,
+                                                       const float* __restrict__ x, long ldx,
+                                                       float* __restrict__ part, ConvGeom g, int ctiles,
+                                                       int chunks_per_split) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int PA = BM + 4, PB = BN + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [2][BK][PA]
+    float* Bs = smem + 2 * BK * PA;   // [2][BK][PB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long M = (long)g.N * g.Hout * g.Wout;
+    const int co0 = blockIdx.y * BM;
+    const int tap = blockIdx.x / ctiles, ci0 = (blockIdx.x - tap * ctiles) * BN;
+    const int r = tap / g.S, s = tap - r * g.S;
+    const long nchunks = (M + BK - 1) / BK;
+    const long c_begin = (long)blockIdx.z * chunks_per_split;
+    const long c_end = min(nchunks, c_begin + chunks_per_split);
+
+    const int prow = tid >> 3, q = tid & 7;  // pixel row in chunk, float4 lane within 32 channels
+    constexpr int JA = BM / 32, JB = BN / 32;
+    float4 ra[JA], rb[JB];
+    auto load_chunk = [&](long ch) {
+        const long m = ch * BK + prow;
+        const bool mv = m < M;
+        const long mm = mv ? m : 0;
+        const int wo = (int)(mm % g.Wout);
+        const long t = mm / g.Wout;
+        const int ho = (int)(t % g.Hout);
+        const int n = (int)(t / g.Hout);
+        int ih, iw;
+        const bool ok = mv && gather_coord(ho * g.mul + g.off_h, r, g.step, 0, g.Hin, ih) &&
+                        gather_coord(wo * g.mul + g.off_w, s, g.step, 0, g.Win, iw);
+        const float* dyr = dy + mm * lddy;
+        const float* xr = x + ((long)n * g.Hin * g.Win + (ok ? (long)ih * g.Win + iw : 0)) * ldx;
+#pragma unroll
+        for (int j = 0; j < JA; ++j) {
+            int co = co0 + j * 32 + q * 4;
+            ra[j] = (mv && co + 3 < g.Cout) ? *(const float4*)(dyr + co)
+                    : make_float4(mv && co < g.Cout ? dyr[co] : 0.f, mv && co + 1 < g.Cout ? dyr[co + 1] : 0.f,
+                                  mv && co + 2 < g.Cout ? dyr[co + 2] : 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            int ci = ci0 + j * 32 + q * 4;
+            rb[j] = (ok && ci < g.Cin) ? *(const float4*)(xr + ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < JA; ++j) *(float4*)(As + ((long)buf * BK + prow) * PA + j * 32 + q * 4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < JB; ++j) *(float4*)(Bs + ((long)buf * BK + prow) * PB + j * 32 + q * 4) = rb[j];
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    const int li = lane & 31, lh = lane >> 5;
+    if (c_begin < c_end) {
+        load_chunk(c_begin);
+        store_chunk(0);
+        __syncthreads();
+        for (long ch = c_begin; ch < c_end; ++ch) {
+            const int buf = (int)((ch - c_begin) & 1);
+            if (ch + 1 < c_end) load_chunk(ch + 1);
+            const float* Ab = As + (long)buf * BK * PA + wm * 32 * TM + li;
+            const float* Bb = Bs + (long)buf * BK * PB + wn * 32 * TN + li;
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                float av[TM], bv[TN];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) av[a] = Ab[(2 * kk + lh) * PA + a * 32];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bv[b] = Bb[(2 * kk + lh) * PB + b * 32];
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+            }
+            if (ch + 1 < c_end) store_chunk(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // partial slab [split][Cout][R*S*Cin]
+    const long wsz = (long)g.Cout * g.R * g.S * g.Cin;
+    float* out = part + (long)blockIdx.z * wsz;
+    const long rowlen = (long)g.R * g.S * g.Cin;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int ci = ci0 + wn * 32 * TN + b * 32 + li;
+            if (ci >= g.Cin) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + wm * 32 * TM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (co < g.Cout) out[(long)co * rowlen + (long)tap * g.Cin + ci] = acc[a][b][e];
+            }
+        }
+}
+
+// dW = (accumulate ? dW : 0) + sum_z part[z]   (ordered => deterministic)
+__global__ void k_wgrad_reduce(const float* __restrict__ part, long wsz, int nsplit, int accumulate,
+                               float* __restrict__ dw) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < wsz; i += (long)gridDim.x * blockDim.x) {
+        float acc = accumulate ? dw[i] : 0.f;
+        for (int z = 0; z < nsplit; ++z) acc += part[(long)z * wsz + i];
+        dw[i] = acc;
+    }
+}
+
+static void wgrad_plan(const ConvGeom& g, int BM, int BN, int& ctiles, int& nsplit, int& cps) {
+    const long M = (long)g.N * g.Hout * g.Wout;
+    const long nchunks = (M + BK - 1) / BK;
+    ctiles = cdiv(g.Cin, BN);
+    const long tiles = (long)cdiv(g.Cout, BM) * ctiles * g.R * g.S;
+    long want = (1024 + tiles - 1) / tiles;          // aim for >= 1024 blocks (2 per CU x 2 rounds)
+    long maxsplit = (nchunks + 7) / 8;               // >= 8 chunks (256 pixels) per split
+    if (want > maxsplit) want = maxsplit;
+    if (want < 1) want = 1;
+    cps = (int)((nchunks + want - 1) / want);
+    nsplit = (int)((nchunks + cps - 1) / cps);
+}
+
+U2PL_API size_t u2pl_conv2d_wgrad_workspace_bytes(int N, int Hout, int Wout, int Cin, int Cout, int R, int S) {
+    ConvGeom g = {N, 0, 0, Cin, Hout, Wout, Cout, R, S, 1, 0, 0, 1, 0};
+    int ct, ns, cps;
+    wgrad_plan(g, Cout > 64 ? 128 : 64, Cin > 64 ? 128 : 64, ct, ns, cps);
+    return (size_t)ns * Cout * R * S * Cin * sizeof(float);
+}
+
+template <int TM, int TN>
+static int launch_wgrad(const float* dy, long lddy, const float* x, long ldx, float* part, const ConvGeom& g,
+                        int ctiles, int nsplit, int cps, hipStream_t stream) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    const size_t lds = (size_t)2 * BK * (BM + 4 + BN + 4) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)k_conv_wgrad<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(ctiles * g.R * g.S), (unsigned)cdiv(g.Cout, BM), (unsigned)nsplit);
+    hipLaunchKernelGGL((k_conv_wgrad<TM, TN>), grid, dim3(256), lds, stream, dy, lddy, x, ldx, part, g, ctiles, cps);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+// weight gradient of nn.Conv2d (autograd of the reference's loss.backward(), train_semi.py:527)
+U2PL_API int u2pl_conv2d_wgrad_f32(const float* dy, long lddy, const float* x, long ldx, float* dw,
+                                   void* workspace, int accumulate, int N, int Hin, int Win, int Cin, int Hout,
+                                   int Wout, int Cout, int R, int S, int stride, int pad, int dil,
+                                   hipStream_t stream) {
+    if (Cin % 4) return U2PL_EINVAL;
+    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
+    const int BM = Cout > 64 ? 128 : 64, BN = Cin > 64 ? 128 : 64;
+    int ct, ns, cps;
+    wgrad_plan(g, BM, BN, ct, ns, cps);
+    float* part = (float*)workspace;
+    int rc;
+    if (BM == 128 && BN == 128) rc = launch_wgrad<2, 2>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
+    else if (BM == 128) rc = launch_wgrad<2, 1>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
+    else if (BN == 128) rc = launch_wgrad<1, 2>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
+    else rc = launch_wgrad<1, 1>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
+    if (rc) return rc;
+    const long wsz = (long)Cout * R * S * Cin;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(grid_for(wsz, 256)), dim3(256), 0, stream, part, wsz, ns, accumulate, dw);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// im2col for the 3-channel stem conv (resnet.py:178): rows [M][Kp] with
+// k = (r*S + s)*Cin + ci, zero padded to Kp (multiple of 32); the conv then runs
+// as a 1x1 implicit GEMM over the patch matrix.
+// ---------------------------------------------------------------------------
+__global__ void k_im2col(const float* __restrict__ x, long ldx, float* __restrict__ col, ConvGeom g, int Kp) {
+    const long M = (long)g.N * g.Hout * g.Wout;
+    const long total = M * Kp;
+    const int K = g.R * g.S * g.Cin;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kp);
+        const long m = i / Kp;
+        float v = 0.f;
+        if (k < K) {
+            const int ci = k % g.Cin, tap = k / g.Cin;
+            const int r = tap / g.S, s = tap % g.S;
+            const int wo = (int)(m % g.Wout);
+            const long t = m / g.Wout;
+            const int ho = (int)(t % g.Hout), n = (int)(t / g.Hout);
+            int ih, iw;
+            if (gather_coord(ho * g.mul + g.off_h, r, g.step, 0, g.Hin, ih) &&
+                gather_coord(wo * g.mul + g.off_w, s, g.step, 0, g.Win, iw))
+                v = x[((long)n * g.Hin * g.Win + (long)ih * g.Win + iw) * ldx + ci];
+        }
+        col[i] = v;
+    }
+}
+U2PL_API int u2pl_im2col_f32(const float* x, long ldx, float* col, int Kp, int N, int Hin, int Win, int Cin,
+                             int Hout, int Wout, int R, int S, int stride, int pad, int dil, hipStream_t stream) {
+    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, 0, R, S, stride, -pad, -pad, dil, 0};
+    const long total = (long)N * Hout * Wout * Kp;
+    hipLaunchKernelGGL(k_im2col, dim3(grid_for(total, 256, 1 << 16)), dim3(256), 0, stream, x, ldx, col, g, Kp);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}

@@ -110,6 +110,74 @@ int u2pl_ohem_prob_f32(const float* logits_nchw, const long long* target, int ig
 int u2pl_ohem_apply_i64(const float* mask_prob, const unsigned* thr_bits, const long long* target, int ignore,
                         long n, long long* kept_target, hipStream_t stream);
 
+/* ---- conv.hip (implicit GEMM on v_mfma_f32_32x32x2_f32) -------------------- */
+/* nn.Conv2d forward (NHWC rows, weights [Cout][R][S][Cin]): resnet.py:25-41,178-186;
+ * base.py:23-83; decoder.py:60-106,132-138.  Cin % 32 == 0 (3-channel stem: u2pl_im2col_f32) */
+int u2pl_conv2d_fwd_f32(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, int N,
+                        int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S, int stride,
+                        int pad, int dil, hipStream_t stream);
+/* autograd of nn.Conv2d under loss.backward() (train_semi.py:527): data and weight gradients */
+int u2pl_conv2d_dgrad_f32(const float* dy, long lddy, const float* wT, float* dx, long lddx, int N, int Hin,
+                          int Win, int Cin, int Hout, int Wout, int Cout, int R, int S, int stride, int pad,
+                          int dil, hipStream_t stream);
+int u2pl_weight_transpose_f32(const float* w, float* wt, int Cout, int RS, int Cin, hipStream_t stream);
+size_t u2pl_conv2d_wgrad_workspace_bytes(int N, int Hout, int Wout, int Cin, int Cout, int R, int S);
+int u2pl_conv2d_wgrad_f32(const float* dy, long lddy, const float* x, long ldx, float* dw, void* workspace,
+                          int accumulate, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R,
+                          int S, int stride, int pad, int dil, hipStream_t stream);
+int u2pl_im2col_f32(const float* x, long ldx, float* col, int Kp, int N, int Hin, int Win, int Cin, int Hout,
+                    int Wout, int R, int S, int stride, int pad, int dil, hipStream_t stream);
+
+/* ---- nn.hip ----------------------------------------------------------------- */
+/* nn.SyncBatchNorm / BatchNorm2d (base.py:6-8 get_syncbn): statistics, apply (+residual, ReLU,
+ * Dropout2d scale: resnet.py:120-140, decoder.py:79-104), backward; sums are double [2][C] so the
+ * cross-rank exchange is one small all-reduce per layer */
+size_t u2pl_colreduce_workspace_bytes(long Mseg, int nseg, int C);
+int u2pl_bn_stats_f32(const float* x, long ld, long M, int C, const float* pivot, void* workspace, double* sums,
+                      hipStream_t stream);
+int u2pl_colsum_f32(const float* x, long ld, long Mseg, int nseg, int C, void* workspace, double* sums,
+                    hipStream_t stream);
+int u2pl_bn_bwd_sums_f32(const float* dy, long lddy, const float* x, long ldx, const float* y, long ldy,
+                         const float* mean, const float* invstd, const float* drop, long rows_per_image, long M,
+                         int C, void* workspace, double* sums, hipStream_t stream);
+int u2pl_bn_finalize_f32(const double* sums, double count, const float* pivot, int C, float eps, float momentum,
+                         float* mean, float* invstd, float* running_mean, float* running_var, hipStream_t stream);
+int u2pl_bn_eval_invstd_f32(const float* running_var, int C, float eps, float* invstd, hipStream_t stream);
+int u2pl_bn_apply_f32(const float* x, long ldx, const float* mean, const float* invstd, const float* gamma,
+                      const float* beta, const float* res, long ldr, int relu, const float* drop,
+                      long rows_per_image, float* y, long ldy, long M, int C, hipStream_t stream);
+int u2pl_bn_bwd_apply_f32(const float* dy, long lddy, const float* x, long ldx, const float* y, long ldy,
+                          const float* mean, const float* invstd, const float* gamma, const float* drop,
+                          long rows_per_image, const double* sums, double count, float* dx, long lddx, float* dres,
+                          long lddr, long M, int C, hipStream_t stream);
+int u2pl_sums_to_f32(const double* sums, int n, float scale, int accumulate, float* out, hipStream_t stream);
+/* nn.MaxPool2d(3,2,1,ceil_mode=True): resnet.py:189-191 */
+int u2pl_maxpool3s2_fwd_f32(const float* x, long ldx, int N, int H, int W, int C, int Ho, int Wo, float* y, long ldy,
+                            unsigned char* tap, hipStream_t stream);
+int u2pl_maxpool3s2_bwd_f32(const float* dy, long lddy, const unsigned char* tap, int N, int H, int W, int C, int Ho,
+                            int Wo, float* dx, long lddx, hipStream_t stream);
+/* torch.cat / slices (base.py:99, decoder.py:117), 1x1 -> HxW bilinear broadcast (base.py:92-94) */
+int u2pl_copy_rows_f32(const float* src, long lds, float* dst, long ldd, long M, int C, int accumulate,
+                       hipStream_t stream);
+int u2pl_copy_cols_f32(const float* src, long lds, float* dst, long ldd, long M, int C, hipStream_t stream);
+int u2pl_broadcast_rows_f32(const float* v, long ldv, float scale, float* dst, long ldd, long rows_per_image, long M,
+                            int C, hipStream_t stream);
+/* F.interpolate(bilinear, align_corners=True) on feature maps: decoder.py:114-116 */
+int u2pl_bilinear_rows_fwd_f32(const float* x, long ldx, int N, int h, int w, int C, int H, int W, float* y, long ldy,
+                               hipStream_t stream);
+int u2pl_bilinear_rows_bwd_f32(const float* dy, long lddy, int N, int h, int w, int C, int H, int W, float* dx,
+                               long lddx, hipStream_t stream);
+/* F.softmax(pred_all_teacher, dim=1): train_semi.py:365 */
+int u2pl_softmax_rows_f32(const float* x, long ldx, float* y, long ldy, long M, int C, hipStream_t stream);
+/* torch.optim.SGD step on a flat arena with 3 lr segments (lr_helper.py:18-19, train_semi.py:100-112,528)
+ * and the teacher EMA (train_semi.py:531-548) */
+int u2pl_sgd_step_f32(float* p, const float* g, float* buf, long n, long b1, long b2, float lr0, float lr1, float lr2,
+                      float momentum, float weight_decay, int first, float grad_scale, hipStream_t stream);
+int u2pl_ema_update_f32(float* t, const float* s, long n, float decay, float one_minus_decay, hipStream_t stream);
+/* generate_unsup_data(mode="cutmix"): augmentation.py:498-541 */
+int u2pl_cutmix_f32(const float* img, const long long* label, const float* conf, const int* boxes_dev, int B, int C,
+                    int H, int W, float* out_img, long long* out_label, float* out_conf, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -348,7 +348,9 @@ def gen_model(ns, tag, arch, S, B, C, aux, seed=5):
     if aux:
         fx.update(aux=out["aux"], ga=ga)
     for n in names:
-        fx["grad__" + n] = params[n].grad
+        g = params[n].grad.flatten()
+        fx["grad__" + n] = g[:: max(1, g.numel() // 4096)][:4096]   # strided sample (logical OIHW order)
+        fx["gabs__" + n] = g.double().abs().sum()
     bufs = dict(model.named_buffers())
     for n in ["encoder.bn1.running_mean", "encoder.bn1.running_var", "decoder.aspp.conv1.2.running_var",
               "encoder.layer4.2.bn3.running_mean"]:

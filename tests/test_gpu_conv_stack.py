@@ -1,0 +1,259 @@
+"""-m gpu numerics tests of the conv / norm / pooling HIP kernels against plain
+PyTorch fp32 (CPU) references of the same op, and of the whole ModelBuilder
+forward/backward against goldens generated from the reference model."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from conftest import golden
+from model_utils import formula_state_dict, net_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+CL = torch.channels_last
+
+
+def K():
+    from u2pl_amd import nn as Kn
+    return Kn
+
+
+def _close(a, b, rtol=2e-4, atol=2e-5, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= atol + rtol * ref, f"{what}: max err {err:.3e} vs ref max {ref:.3e}"
+
+
+CONV_CASES = [
+    # Cin, Cout, k, stride, dil, H, bias
+    (64, 64, 3, 1, 1, 33, False),
+    (64, 128, 3, 1, 1, 21, False),
+    (128, 128, 3, 2, 1, 33, False),     # layer2 stride-2 3x3
+    (256, 512, 1, 2, 1, 33, False),     # layer2 downsample
+    (256, 256, 3, 1, 2, 25, False),     # layer3 dilation 2
+    (512, 512, 3, 1, 16, 25, False),    # layer4 multi-grid (halo larger than the map)
+    (2048, 256, 3, 1, 36, 13, False),   # ASPP d36
+    (1024, 256, 1, 1, 1, 17, False),
+    (512, 256, 3, 1, 1, 19, True),      # decoder tower with bias
+    (256, 19, 1, 1, 1, 19, True),       # classifier (narrow N)
+    (3, 64, 3, 2, 1, 33, False),        # stem (im2col path)
+    (1280, 256, 3, 1, 1, 9, False),
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,dil,H,bias", CONV_CASES)
+def test_conv2d_fwd_bwd_vs_torch(Cin, Cout, k, stride, dil, H, bias):
+    Kn = K()
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + k + dil)
+    N, W = 2, H + 2
+    pad = dil * (k // 2)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    ref = nn.Conv2d(Cin, Cout, k, stride=stride, padding=pad, dilation=dil, bias=bias)
+    with torch.no_grad():
+        ref.weight.copy_(torch.randn(ref.weight.shape, generator=g) / (Cin * k * k) ** 0.5)
+        if bias:
+            ref.bias.copy_(torch.randn(Cout, generator=g))
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    mine = Kn.Conv2d(Cin, Cout, k, stride=stride, padding=pad, dilation=dil, bias=bias).to(DEV)
+    with torch.no_grad():
+        mine.weight.copy_(ref.weight.detach().to(DEV))
+        if bias:
+            mine.bias.copy_(ref.bias.detach().to(DEV))
+    xd = x.to(DEV).contiguous(memory_format=CL).requires_grad_(Cin != 3)
+    yd = mine(xd)
+    assert yd.shape == yr.shape
+    _close(yd, yr, what="fwd")
+    yd.backward(gy.to(DEV).contiguous(memory_format=CL))
+    if Cin != 3:
+        _close(xd.grad, xr.grad, what="dgrad")
+    _close(mine.weight.grad, ref.weight.grad, rtol=3e-4, what="wgrad")
+    if bias:
+        _close(mine.bias.grad, ref.bias.grad, rtol=3e-4, what="bgrad")
+
+
+def test_conv_large_pixel_count_splitk():
+    """many pixels (split-K wgrad with several slabs) and M not a multiple of the tile"""
+    Kn = K()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 64, 97, 101, generator=g)
+    ref = nn.Conv2d(64, 64, 3, padding=1, bias=False)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    mine = Kn.Conv2d(64, 64, 3, padding=1, bias=False).to(DEV)
+    with torch.no_grad():
+        mine.weight.copy_(ref.weight.detach().to(DEV))
+    xd = x.to(DEV).contiguous(memory_format=CL).requires_grad_(True)
+    yd = mine(xd)
+    yd.backward(gy.to(DEV).contiguous(memory_format=CL))
+    _close(yd, yr, what="fwd")
+    _close(xd.grad, xr.grad, what="dgrad")
+    _close(mine.weight.grad, ref.weight.grad, rtol=5e-4, what="wgrad")
+
+
+@pytest.mark.parametrize("C,H,relu,res,drop", [(64, 17, True, False, False), (256, 9, True, True, False),
+                                               (1280, 5, False, False, False), (256, 11, True, False, True),
+                                               (2048, 3, True, True, True)])
+def test_batchnorm_train_fwd_bwd_vs_torch(C, H, relu, res, drop):
+    Kn = K()
+    g = torch.Generator().manual_seed(C + H)
+    N = 3
+    x = torch.randn(N, C, H, H, generator=g) * 2 + 0.7
+    r = torch.randn(N, C, H, H, generator=g) if res else None
+    dm = ((torch.rand(N, C, generator=g) > 0.3).float() / 0.7) if drop else None
+    ref = nn.BatchNorm2d(C)
+    with torch.no_grad():
+        ref.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        ref.bias.copy_(torch.randn(C, generator=g) * 0.1)
+        ref.running_mean.copy_(torch.randn(C, generator=g) * 0.1)
+    mine = Kn.BatchNorm2d(C).to(DEV)
+    mine.load_state_dict(ref.state_dict())
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    yr = ref(xr)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    if drop:
+        yr = yr * dm[:, :, None, None]
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = x.to(DEV).contiguous(memory_format=CL).requires_grad_(True)
+    rd = r.to(DEV).contiguous(memory_format=CL).requires_grad_(True) if res else None
+    yd = mine(xd, res=rd, relu=relu, drop=dm.to(DEV) if drop else None)
+    yd.backward(gy.to(DEV).contiguous(memory_format=CL))
+    _close(yd, yr, what="fwd")
+    _close(xd.grad, xr.grad, rtol=5e-4, what="dx")
+    if res:
+        _close(rd.grad, rr.grad, what="dres")
+    _close(mine.weight.grad, ref.weight.grad, rtol=5e-4, atol=1e-4, what="dgamma")
+    _close(mine.bias.grad, ref.bias.grad, rtol=5e-4, atol=1e-4, what="dbeta")
+    _close(mine.running_mean, ref.running_mean, what="running_mean")
+    _close(mine.running_var, ref.running_var, what="running_var")
+    # eval mode
+    ref.eval(), mine.eval()
+    _close(mine(xd.detach()), ref(x), what="eval fwd")
+
+
+def test_batchnorm_on_channel_slice_and_single_pixel():
+    Kn = K()
+    g = torch.Generator().manual_seed(5)
+    big = torch.randn(2, 512, 7, 7, generator=g).to(DEV).contiguous(memory_format=CL)
+    sl = big[:, 128:384]
+    ref = nn.BatchNorm2d(256)
+    mine = Kn.BatchNorm2d(256).to(DEV)
+    _close(mine(sl, relu=True), F.relu(ref(sl.cpu().contiguous())), what="slice")
+    x1 = torch.randn(4, 256, 1, 1, generator=g)
+    ref2, mine2 = nn.BatchNorm2d(256), Kn.BatchNorm2d(256).to(DEV)
+    _close(mine2(x1.to(DEV), relu=True), F.relu(ref2(x1)), what="1x1")
+
+
+@pytest.mark.parametrize("H,W", [(33, 35), (65, 65), (385, 385)])
+def test_maxpool_ceil_vs_torch(H, W):
+    Kn = K()
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(2, 128, H, W, generator=g)
+    x[0, :, 3, 3] = x[0, :, 3, 4]  # ties
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1, ceil_mode=True)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = x.to(DEV).contiguous(memory_format=CL).requires_grad_(True)
+    yd = Kn.MaxPool3x3s2Ceil()(xd)
+    assert yd.shape == yr.shape
+    yd.backward(gy.to(DEV).contiguous(memory_format=CL))
+    assert torch.equal(yd.cpu(), yr.detach())
+    _close(xd.grad, xr.grad, rtol=1e-6, atol=1e-6, what="maxpool bwd")
+
+
+def test_gap_broadcast_upsample_cat():
+    Kn = K()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 256, 13, 11, generator=g)
+    xr = x.clone().requires_grad_(True)
+    pr = F.adaptive_avg_pool2d(xr, 1)
+    ur = F.interpolate(pr, (13, 11), mode="bilinear", align_corners=True)
+    u2r = F.interpolate(xr, (25, 21), mode="bilinear", align_corners=True)
+    cr = torch.cat((ur, xr), 1)
+    gc = torch.randn(cr.shape, generator=g)
+    g2 = torch.randn(u2r.shape, generator=g)
+    (cr * gc).sum().backward(retain_graph=True)
+    (u2r * g2).sum().backward()
+    xd = x.to(DEV).contiguous(memory_format=CL).requires_grad_(True)
+    pd = Kn.global_avg_pool(xd)
+    ud = Kn.upsample_bilinear(pd, (13, 11))
+    u2d = Kn.upsample_bilinear(xd, (25, 21))
+    cd = Kn.cat_channels((ud, xd))
+    _close(pd, pr, what="gap")
+    _close(cd, cr, what="cat")
+    assert torch.equal(u2d.cpu(), u2r.detach()), "feature bilinear must be bit-exact (FMA form)"
+    (cd * gc.to(DEV)).sum().backward(retain_graph=True)
+    (u2d * g2.to(DEV)).sum().backward()
+    _close(xd.grad, xr.grad, rtol=3e-4, what="combined backward")
+
+
+def test_sgd_ema_arena_golden():
+    from u2pl_amd.nn import ParamArena
+    g = golden("sgd_ema")
+    s = [nn.Parameter(torch.from_numpy(g["p0"]).to(DEV)), nn.Parameter(torch.from_numpy(g["p1"]).to(DEV))]
+    t = [nn.Parameter(torch.from_numpy(g["t0"]).to(DEV)), nn.Parameter(torch.from_numpy(g["t1"]).to(DEV))]
+    sa, ta = ParamArena([[s[0]], [s[1]]]), ParamArena([[t[0]], [t[1]]], with_grad=False)
+    for it in range(6):
+        sa.zero_grad()
+        s[0].grad.copy_(torch.from_numpy(g[f"g0_{it}"]).to(DEV))
+        s[1].grad.copy_(torch.from_numpy(g[f"g1_{it}"]).to(DEV))
+        sa.sgd_step([float(x) for x in g[f"lr_{it}"]], 0.9, 0.0005)
+        ta.ema_from(sa, float(g[f"ema_{it}"]))
+        for j in range(2):
+            assert np.abs(s[j].detach().cpu().numpy() - g[f"s{j}_{it}"]).max() < 1e-6
+            assert np.abs(t[j].detach().cpu().numpy() - g[f"t{j}_{it}"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("tag,arch,S,C,aux", [("r50_65", "resnet50", 65, 19, True), ("r101_33", "resnet101", 33, 21, False)])
+def test_model_builder_vs_reference_golden(tag, arch, S, C, aux):
+    """Whole ModelBuilder (train-mode fwd, bwd, buffers, eval fwd) vs the reference model's
+    outputs (formula weights, dropout disabled on both sides)."""
+    from u2pl_amd.models.model_helper import ModelBuilder
+    g = golden("model_" + tag)
+    model = ModelBuilder(net_cfg(arch, C, aux))
+    model.load_state_dict(formula_state_dict(model))
+    model = model.to(DEV)
+    for m in model.modules():
+        if isinstance(m, nn.Dropout2d):
+            m.p = 0.0
+    model.train()
+    x = torch.from_numpy(g["x"]).to(DEV)
+    out = model(x)
+    _close(out["pred"], torch.from_numpy(g["pred"]), rtol=1e-3, atol=1e-4, what="pred")
+    _close(out["rep"], torch.from_numpy(g["rep"]), rtol=1e-3, atol=1e-4, what="rep")
+    loss = (out["pred"] * torch.from_numpy(g["gp"]).to(DEV)).sum() + (out["rep"] * torch.from_numpy(g["gr"]).to(DEV)).sum()
+    if aux:
+        _close(out["aux"], torch.from_numpy(g["aux"]), rtol=1e-3, atol=1e-4, what="aux")
+        loss = loss + (out["aux"] * torch.from_numpy(g["ga"]).to(DEV)).sum()
+    loss.backward()
+    params = dict(model.named_parameters())
+    for n in g["grad_names"]:
+        n = str(n)
+        gr = params[n].grad.detach().cpu().contiguous().flatten()
+        sub = gr[:: max(1, gr.numel() // 4096)][:4096]
+        ref = torch.from_numpy(g["grad__" + n])
+        scale = float(g["gabs__" + n]) / gr.numel() + 1e-12
+        err = (sub - ref).abs().max().item()
+        assert err <= 5e-3 * max(scale, ref.abs().max().item()) + 1e-5, (n, err, scale)
+    bufs = dict(model.named_buffers())
+    for k in g.files:
+        if k.startswith("buf__"):
+            _close(bufs[k[5:]], torch.from_numpy(g[k]), rtol=1e-4, atol=1e-5, what=k)
+    model.eval()
+    with torch.no_grad():
+        oe = model(x)
+    _close(oe["pred"], torch.from_numpy(g["pred_eval"]), rtol=1e-3, atol=1e-4, what="pred_eval")
+    _close(oe["rep"], torch.from_numpy(g["rep_eval"]), rtol=1e-3, atol=1e-4, what="rep_eval")

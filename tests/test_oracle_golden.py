@@ -177,3 +177,15 @@ def test_sgd_ema_lr():
             t[j] = R.ema_update(t[j], s[j], d)
             assert np.abs(s[j] - g[f"s{j}_{it}"]).max() < 1e-6
             assert np.abs(t[j] - g[f"t{j}_{it}"]).max() < 1e-6
+
+
+def test_formula_state_dict_in_sync():
+    """tests/model_utils.formula_state_dict must equal oracle/gen_golden.formula_state_dict"""
+    import torch
+    import torch.nn as nn
+    from model_utils import formula_state_dict as a
+    from oracle.gen_golden import formula_state_dict as b
+
+    m = nn.Sequential(nn.Conv2d(3, 8, 3), nn.BatchNorm2d(8))
+    sa, sb = a(m), b(m)
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)

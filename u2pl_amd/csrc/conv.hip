@@ -168,7 +168,7 @@ static int launch_igemm(const float* x, long ldx, const float* w, const float* b
     const size_t lds = (size_t)2 * (BM + BN) * LDP * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)k_conv_igemm<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_conv_igemm<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid((unsigned)cdiv(M, BM), (unsigned)cdiv(g.Cout, BN));
@@ -382,7 +382,7 @@ static int launch_wgrad(const float* dy, long lddy, const float* x, long ldx, fl
     const size_t lds = (size_t)2 * BK * (BM + 4 + BN + 4) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)k_conv_wgrad<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_conv_wgrad<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid((unsigned)(ctiles * g.R * g.S), (unsigned)cdiv(g.Cout, BM), (unsigned)nsplit);

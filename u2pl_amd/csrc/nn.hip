@@ -1,0 +1,560 @@
+// Memory-bound layers of the ResNet-101 / DeepLabv3+ stack on NHWC "rows"
+// (8a rows a2-a6): (Sync)BatchNorm statistics /
+// apply / backward fused with residual-add, ReLU and Dropout2d scaling,
+// ceil-mode max-pool, global average pool, bilinear feature up-sampling,
+// channel-slice copies (concat).  All accesses are float4 along the channel
+// axis (lane-contiguous), reductions are two-stage and ordered (deterministic).
+#include "common.h"
+#include "u2pl_hip.h"
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// ---------------------------------------------------------------------------
+// Column reduction skeleton: for rows [seg*Mseg, (seg+1)*Mseg) accumulate two
+// per-channel sums produced by Op::get(row, col4, &v0, &v1).
+//   partial: float [seg][nblk][2][C]   ->   out: double [seg][2][C]
+// ---------------------------------------------------------------------------
+struct StatOp {  // v0 = x - pivot, v1 = (x - pivot)^2     (BN forward statistics)
+    const float* x; long ld; const float* pivot;
+    __device__ __forceinline__ void get(long row, int c4, float4& v0, float4& v1) const {
+        float4 v = *(const float4*)(x + row * ld + c4 * 4);
+        if (pivot) v = f4sub(v, *(const float4*)(pivot + c4 * 4));
+        v0 = v; v1 = f4mul(v, v);
+    }
+};
+struct SumOp {  // v0 = x, v1 = 0     (global average pool / bias gradient)
+    const float* x; long ld;
+    __device__ __forceinline__ void get(long row, int c4, float4& v0, float4& v1) const {
+        v0 = *(const float4*)(x + row * ld + c4 * 4); v1 = f4zero();
+    }
+};
+struct BnBwdOp {  // g = dy*[y>0]*drop ; v0 = g, v1 = g * xhat     (BN backward sums)
+    const float* dy; long lddy; const float* x; long ldx; const float* y; long ldy;
+    const float* mean; const float* invstd; const float* drop; long rows_per_image; int C;
+    __device__ __forceinline__ void get(long row, int c4, float4& v0, float4& v1) const {
+        float4 g = *(const float4*)(dy + row * lddy + c4 * 4);
+        if (y) {
+            float4 yy = *(const float4*)(y + row * ldy + c4 * 4);
+            g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+            g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+        }
+        if (drop) g = f4mul(g, *(const float4*)(drop + (row / rows_per_image) * C + c4 * 4));
+        float4 xv = *(const float4*)(x + row * ldx + c4 * 4);
+        float4 xh = f4mul(f4sub(xv, *(const float4*)(mean + c4 * 4)), *(const float4*)(invstd + c4 * 4));
+        v0 = g; v1 = f4mul(g, xh);
+    }
+};
+
+template <class Op>
+__global__ void k_colreduce_partial(Op op, long Mseg, int C, float* __restrict__ partial) {
+    __shared__ float4 sh0[256], sh1[256];
+    const int C4 = C >> 2;
+    const int tc = C4 < 256 ? C4 : 256, tr = 256 / tc;
+    const int tid = threadIdx.x, cl = tid % tc, rg = tid / tc;
+    const int nblk = gridDim.x, seg = blockIdx.y;
+    const long per = (Mseg + nblk - 1) / nblk;
+    const long rb = seg * Mseg + blockIdx.x * per, re = min(seg * Mseg + Mseg, rb + per);
+    float* out = partial + ((long)seg * nblk + blockIdx.x) * 2 * C;
+    for (int cb = 0; cb < C4; cb += tc) {
+        const int c4 = cb + cl;
+        float4 a0 = f4zero(), a1 = f4zero();
+        if (rg < tr && c4 < C4)
+            for (long r = rb + rg; r < re; r += tr) {
+                float4 v0, v1;
+                op.get(r, c4, v0, v1);
+                a0 = f4add(a0, v0); a1 = f4add(a1, v1);
+            }
+        sh0[tid] = a0; sh1[tid] = a1;
+        __syncthreads();
+        if (rg == 0 && c4 < C4) {
+            for (int k = 1; k < tr; ++k) { a0 = f4add(a0, sh0[k * tc + cl]); a1 = f4add(a1, sh1[k * tc + cl]); }
+            *(float4*)(out + c4 * 4) = a0;
+            *(float4*)(out + C + c4 * 4) = a1;
+        }
+        __syncthreads();
+    }
+}
+__global__ void k_colreduce_final(const float* __restrict__ partial, int nblk, int C, double* __restrict__ out) {
+    const int seg = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * C; i += gridDim.x * blockDim.x) {
+        double acc = 0.0;
+        for (int b = 0; b < nblk; ++b) acc += (double)partial[((long)seg * nblk + b) * 2 * C + i];
+        out[(long)seg * 2 * C + i] = acc;
+    }
+}
+static int colreduce_blocks(long Mseg) {
+    long b = (Mseg + 63) / 64;
+    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+}
+U2PL_API size_t u2pl_colreduce_workspace_bytes(long Mseg, int nseg, int C) {
+    return (size_t)nseg * colreduce_blocks(Mseg) * 2 * C * sizeof(float);
+}
+template <class Op>
+static int run_colreduce(Op op, long Mseg, int nseg, int C, void* ws, double* out, hipStream_t stream) {
+    if (C % 4 || Mseg <= 0) return U2PL_EINVAL;
+    const int nblk = colreduce_blocks(Mseg);
+    hipLaunchKernelGGL((k_colreduce_partial<Op>), dim3(nblk, nseg), dim3(256), 0, stream, op, Mseg, C, (float*)ws);
+    U2PL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_colreduce_final, dim3(cdiv(2 * C, 256), nseg), dim3(256), 0, stream, (const float*)ws, nblk, C, out);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+// nn.SyncBatchNorm / nn.BatchNorm2d training statistics (base.py:6-8): local
+// shifted sums  S1 = sum(x - pivot), S2 = sum((x - pivot)^2)  -> out double [2][C]
+U2PL_API int u2pl_bn_stats_f32(const float* x, long ld, long M, int C, const float* pivot, void* workspace,
+                               double* sums, hipStream_t stream) {
+    StatOp op = {x, ld, pivot};
+    return run_colreduce(op, M, 1, C, workspace, sums, stream);
+}
+// per-image channel sums (AdaptiveAvgPool2d numerator base.py:24; conv bias gradient with nseg=1)
+U2PL_API int u2pl_colsum_f32(const float* x, long ld, long Mseg, int nseg, int C, void* workspace, double* sums,
+                             hipStream_t stream) {
+    SumOp op = {x, ld};
+    return run_colreduce(op, Mseg, nseg, C, workspace, sums, stream);
+}
+U2PL_API int u2pl_bn_bwd_sums_f32(const float* dy, long lddy, const float* x, long ldx, const float* y, long ldy,
+                                  const float* mean, const float* invstd, const float* drop, long rows_per_image,
+                                  long M, int C, void* workspace, double* sums, hipStream_t stream) {
+    BnBwdOp op = {dy, lddy, x, ldx, y, ldy, mean, invstd, drop, rows_per_image, C};
+    return run_colreduce(op, M, 1, C, workspace, sums, stream);
+}
+
+// sums (global, already all-reduced over ranks) -> mean, invstd, running stats.
+// torch semantics: biased var for normalisation, unbiased var into running_var,
+// running = (1-momentum)*running + momentum*batch.
+__global__ void k_bn_finalize(const double* __restrict__ sums, double count, const float* __restrict__ pivot, int C,
+                              float eps, float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                              float* __restrict__ running_mean, float* __restrict__ running_var) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        const double m1 = sums[c] / count, m2 = sums[C + c] / count;
+        const double p = pivot ? (double)pivot[c] : 0.0;
+        double var = m2 - m1 * m1;
+        if (var < 0.0) var = 0.0;
+        const double mu = p + m1;
+        mean[c] = (float)mu;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+        }
+    }
+}
+U2PL_API int u2pl_bn_finalize_f32(const double* sums, double count, const float* pivot, int C, float eps,
+                                  float momentum, float* mean, float* invstd, float* running_mean,
+                                  float* running_var, hipStream_t stream) {
+    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, stream, sums, count, pivot, C, eps, momentum,
+                       mean, invstd, running_mean, running_var);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+// eval mode: invstd from running_var
+__global__ void k_bn_eval_prep(const float* __restrict__ rv, int C, float eps, float* __restrict__ invstd) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x)
+        invstd[c] = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
+}
+U2PL_API int u2pl_bn_eval_invstd_f32(const float* running_var, int C, float eps, float* invstd, hipStream_t stream) {
+    hipLaunchKernelGGL(k_bn_eval_prep, dim3(cdiv(C, 256)), dim3(256), 0, stream, running_var, C, eps, invstd);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+// y = [relu]( (x - mean)*invstd*gamma + beta [+ res] ) [* drop[n][c]]
+__global__ void k_bn_apply(const float* __restrict__ x, long ldx, const float* __restrict__ mean,
+                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                           const float* __restrict__ beta, const float* __restrict__ res, long ldr, int relu,
+                           const float* __restrict__ drop, long rows_per_image, float* __restrict__ y, long ldy,
+                           long M, int C) {
+    const int C4 = C >> 2;
+    const long total = M * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C4;
+        const int c = (int)(i % C4) * 4;
+        float4 v = *(const float4*)(x + r * ldx + c);
+        const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c);
+        const float4 ga = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
+        v.x = (v.x - mu.x) * is.x * ga.x + be.x; v.y = (v.y - mu.y) * is.y * ga.y + be.y;
+        v.z = (v.z - mu.z) * is.z * ga.z + be.z; v.w = (v.w - mu.w) * is.w * ga.w + be.w;
+        if (res) v = f4add(v, *(const float4*)(res + r * ldr + c));
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (drop) v = f4mul(v, *(const float4*)(drop + (r / rows_per_image) * C + c));
+        *(float4*)(y + r * ldy + c) = v;
+    }
+}
+U2PL_API int u2pl_bn_apply_f32(const float* x, long ldx, const float* mean, const float* invstd, const float* gamma,
+                               const float* beta, const float* res, long ldr, int relu, const float* drop,
+                               long rows_per_image, float* y, long ldy, long M, int C, hipStream_t stream) {
+    if (C % 4) return U2PL_EINVAL;
+    hipLaunchKernelGGL(k_bn_apply, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, x, ldx, mean, invstd, gamma,
+                       beta, res, ldr, relu, drop, rows_per_image, y, ldy, M, C);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+// g = dy*[y>0]*drop ; dres = g ; dx = gamma*invstd*(g - S0/cnt - xhat*S1/cnt)  (train)
+//                                dx = gamma*invstd*g                           (eval: sums == NULL)
+__global__ void k_bn_bwd_apply(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
+                               const float* __restrict__ y, long ldy, const float* __restrict__ mean,
+                               const float* __restrict__ invstd, const float* __restrict__ gamma,
+                               const float* __restrict__ drop, long rows_per_image,
+                               const double* __restrict__ sums, double count, float* __restrict__ dx, long lddx,
+                               float* __restrict__ dres, long lddr, long M, int C) {
+    const int C4 = C >> 2;
+    const long total = M * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C4;
+        const int c = (int)(i % C4) * 4;
+        float4 g = *(const float4*)(dy + r * lddy + c);
+        if (y) {
+            const float4 yy = *(const float4*)(y + r * ldy + c);
+            g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+            g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+        }
+        if (drop) g = f4mul(g, *(const float4*)(drop + (r / rows_per_image) * C + c));
+        if (dres) *(float4*)(dres + r * lddr + c) = g;
+        const float4 is = *(const float4*)(invstd + c), ga = *(const float4*)(gamma + c);
+        float4 o;
+        if (sums) {
+            const float4 xv = *(const float4*)(x + r * ldx + c), mu = *(const float4*)(mean + c);
+            const float m0x = (float)(sums[c] / count), m0y = (float)(sums[c + 1] / count);
+            const float m0z = (float)(sums[c + 2] / count), m0w = (float)(sums[c + 3] / count);
+            const float m1x = (float)(sums[C + c] / count), m1y = (float)(sums[C + c + 1] / count);
+            const float m1z = (float)(sums[C + c + 2] / count), m1w = (float)(sums[C + c + 3] / count);
+            o.x = ga.x * is.x * (g.x - m0x - (xv.x - mu.x) * is.x * m1x);
+            o.y = ga.y * is.y * (g.y - m0y - (xv.y - mu.y) * is.y * m1y);
+            o.z = ga.z * is.z * (g.z - m0z - (xv.z - mu.z) * is.z * m1z);
+            o.w = ga.w * is.w * (g.w - m0w - (xv.w - mu.w) * is.w * m1w);
+        } else {
+            o = f4mul(f4mul(ga, is), g);
+        }
+        *(float4*)(dx + r * lddx + c) = o;
+    }
+}
+U2PL_API int u2pl_bn_bwd_apply_f32(const float* dy, long lddy, const float* x, long ldx, const float* y, long ldy,
+                                   const float* mean, const float* invstd, const float* gamma, const float* drop,
+                                   long rows_per_image, const double* sums, double count, float* dx, long lddx,
+                                   float* dres, long lddr, long M, int C, hipStream_t stream) {
+    if (C % 4) return U2PL_EINVAL;
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, dy, lddy, x, ldx, y, ldy,
+                       mean, invstd, gamma, drop, rows_per_image, sums, count, dx, lddx, dres, lddr, M, C);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+// dgamma = S1 (sum g*xhat), dbeta = S0 (sum g): double -> float (optionally accumulate)
+__global__ void k_sums_to_f32(const double* __restrict__ s, int n, float scale, int accumulate, float* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[i] = (accumulate ? out[i] : 0.f) + (float)(s[i] * (double)scale);
+}
+U2PL_API int u2pl_sums_to_f32(const double* sums, int n, float scale, int accumulate, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_sums_to_f32, dim3(cdiv(n, 256)), dim3(256), 0, stream, sums, n, scale, accumulate, out);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// nn.MaxPool2d(3, 2, 1, ceil_mode=True)  (resnet.py:189-191); tap index saved
+// ---------------------------------------------------------------------------
+__global__ void k_maxpool_fwd(const float* __restrict__ x, long ldx, int N, int H, int W, int C, int Ho, int Wo,
+                              float* __restrict__ y, long ldy, unsigned char* __restrict__ tap) {
+    const int C4 = C >> 2;
+    const long total = (long)N * Ho * Wo * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        long p = i / C4;
+        const int wo = (int)(p % Wo);
+        long t = p / Wo;
+        const int ho = (int)(t % Ho), n = (int)(t / Ho);
+        float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        uchar4 bt = make_uchar4(0, 0, 0, 0);
+        bool first = true;
+        for (int r = 0; r < 3; ++r) {
+            const int ih = ho * 2 - 1 + r;
+            if (ih < 0 || ih >= H) continue;
+            for (int s = 0; s < 3; ++s) {
+                const int iw = wo * 2 - 1 + s;
+                if (iw < 0 || iw >= W) continue;
+                const float4 v = *(const float4*)(x + ((long)(n * H + ih) * W + iw) * ldx + c);
+                const unsigned char k = (unsigned char)(r * 3 + s);
+                if (first || v.x > best.x || v.x != v.x) { best.x = v.x; bt.x = k; }
+                if (first || v.y > best.y || v.y != v.y) { best.y = v.y; bt.y = k; }
+                if (first || v.z > best.z || v.z != v.z) { best.z = v.z; bt.z = k; }
+                if (first || v.w > best.w || v.w != v.w) { best.w = v.w; bt.w = k; }
+                first = false;
+            }
+        }
+        *(float4*)(y + p * ldy + c) = best;
+        *(uchar4*)(tap + p * C + c) = bt;
+    }
+}
+U2PL_API int u2pl_maxpool3s2_fwd_f32(const float* x, long ldx, int N, int H, int W, int C, int Ho, int Wo, float* y,
+                                     long ldy, unsigned char* tap, hipStream_t stream) {
+    if (C % 4) return U2PL_EINVAL;
+    hipLaunchKernelGGL(k_maxpool_fwd, dim3(grid_for((long)N * Ho * Wo * (C / 4), 256)), dim3(256), 0, stream, x, ldx, N, H,
+                       W, C, Ho, Wo, y, ldy, tap);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+// gather form: every input pixel checks the <= 4 windows that cover it
+__global__ void k_maxpool_bwd(const float* __restrict__ dy, long lddy, const unsigned char* __restrict__ tap, int N,
+                              int H, int W, int C, int Ho, int Wo, float* __restrict__ dx, long lddx) {
+    const int C4 = C >> 2;
+    const long total = (long)N * H * W * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        long p = i / C4;
+        const int iw = (int)(p % W);
+        long t = p / W;
+        const int ih = (int)(t % H), n = (int)(t / H);
+        float4 acc = f4zero();
+        for (int ho = ih / 2; ho <= (ih + 1) / 2; ++ho) {
+            if (ho >= Ho) continue;
+            const int r = ih - (ho * 2 - 1);
+            if (r < 0 || r > 2) continue;
+            for (int wo = iw / 2; wo <= (iw + 1) / 2; ++wo) {
+                if (wo >= Wo) continue;
+                const int s = iw - (wo * 2 - 1);
+                if (s < 0 || s > 2) continue;
+                const long q = ((long)n * Ho + ho) * Wo + wo;
+                const uchar4 k = *(const uchar4*)(tap + q * C + c);
+                const float4 g = *(const float4*)(dy + q * lddy + c);
+                const unsigned char me = (unsigned char)(r * 3 + s);
+                if (k.x == me) acc.x += g.x;
+                if (k.y == me) acc.y += g.y;
+                if (k.z == me) acc.z += g.z;
+                if (k.w == me) acc.w += g.w;
+            }
+        }
+        *(float4*)(dx + p * lddx + c) = acc;
+    }
+}
+U2PL_API int u2pl_maxpool3s2_bwd_f32(const float* dy, long lddy, const unsigned char* tap, int N, int H, int W, int C,
+                                     int Ho, int Wo, float* dx, long lddx, hipStream_t stream) {
+    hipLaunchKernelGGL(k_maxpool_bwd, dim3(grid_for((long)N * H * W * (C / 4), 256)), dim3(256), 0, stream, dy, lddy, tap, N,
+                       H, W, C, Ho, Wo, dx, lddx);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// row utilities: strided copy (concat / slice), per-image broadcast of a
+// [N][C] vector (bilinear up-sampling of a 1x1 map, base.py:92-94, and the
+// backward of the global average pool), scaled
+// ---------------------------------------------------------------------------
+__global__ void k_copy_rows(const float* __restrict__ src, long lds, float* __restrict__ dst, long ldd, long M, int C,
+                            int accumulate) {
+    const int C4 = C >> 2;
+    const long total = M * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C4;
+        const int c = (int)(i % C4) * 4;
+        float4 v = *(const float4*)(src + r * lds + c);
+        if (accumulate) v = f4add(v, *(const float4*)(dst + r * ldd + c));
+        *(float4*)(dst + r * ldd + c) = v;
+    }
+}
+U2PL_API int u2pl_copy_rows_f32(const float* src, long lds, float* dst, long ldd, long M, int C, int accumulate,
+                                hipStream_t stream) {
+    if (C % 4) return U2PL_EINVAL;
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(k_copy_rows, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, src, lds, dst, ldd, M, C, accumulate);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+// scalar variant for narrow rows (C = num_classes, ld not 16 B aligned): dst[r][c] = src[r][c], c < C
+__global__ void k_copy_cols(const float* __restrict__ src, long lds, float* __restrict__ dst, long ldd, long M, int C) {
+    const long total = M * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C;
+        const int c = (int)(i % C);
+        dst[r * ldd + c] = src[r * lds + c];
+    }
+}
+U2PL_API int u2pl_copy_cols_f32(const float* src, long lds, float* dst, long ldd, long M, int C, hipStream_t stream) {
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(k_copy_cols, dim3(grid_for(M * C, 256)), dim3(256), 0, stream, src, lds, dst, ldd, M, C);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void k_broadcast_rows(const float* __restrict__ v, long ldv, float scale, float* __restrict__ dst, long ldd,
+                                 long rows_per_image, long M, int C) {
+    const int C4 = C >> 2;
+    const long total = M * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C4;
+        const int c = (int)(i % C4) * 4;
+        float4 a = *(const float4*)(v + (r / rows_per_image) * ldv + c);
+        a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
+        *(float4*)(dst + r * ldd + c) = a;
+    }
+}
+U2PL_API int u2pl_broadcast_rows_f32(const float* v, long ldv, float scale, float* dst, long ldd, long rows_per_image,
+                                     long M, int C, hipStream_t stream) {
+    if (C % 4) return U2PL_EINVAL;
+    hipLaunchKernelGGL(k_broadcast_rows, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, v, ldv, scale, dst, ldd,
+                       rows_per_image, M, C);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// bilinear (align_corners=True) up-sampling of NHWC feature maps
+// (decoder.py:114-116: 97^2 -> 193^2, 256 channels) forward / backward
+// ---------------------------------------------------------------------------
+__global__ void k_bilinear_rows_fwd(const float* __restrict__ x, long ldx, int N, int h, int w, int C, int H, int W,
+                                    float sy, float sx, float* __restrict__ y, long ldy) {
+    const int C4 = C >> 2;
+    const long total = (long)N * H * W * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        long p = i / C4;
+        const int ox = (int)(p % W);
+        long t = p / W;
+        const int oy = (int)(t % H), n = (int)(t / H);
+        const AcCoord cy = ac_coord(oy, sy, h), cx = ac_coord(ox, sx, w);
+        const float* b = x + (long)n * h * w * ldx + c;
+        const float4 v00 = *(const float4*)(b + ((long)cy.i0 * w + cx.i0) * ldx), v01 = *(const float4*)(b + ((long)cy.i0 * w + cx.i1) * ldx);
+        const float4 v10 = *(const float4*)(b + ((long)cy.i1 * w + cx.i0) * ldx), v11 = *(const float4*)(b + ((long)cy.i1 * w + cx.i1) * ldx);
+        float4 o;
+#define BL(f) o.f = __fmaf_rn(cy.l0, __fmaf_rn(cx.l0, v00.f, __fmul_rn(cx.l1, v01.f)), __fmul_rn(cy.l1, __fmaf_rn(cx.l0, v10.f, __fmul_rn(cx.l1, v11.f))))
+        BL(x); BL(y); BL(z); BL(w);
+#undef BL
+        *(float4*)(y + p * ldy + c) = o;
+    }
+}
+U2PL_API int u2pl_bilinear_rows_fwd_f32(const float* x, long ldx, int N, int h, int w, int C, int H, int W, float* y,
+                                        long ldy, hipStream_t stream) {
+    if (C % 4) return U2PL_EINVAL;
+    hipLaunchKernelGGL(k_bilinear_rows_fwd, dim3(grid_for((long)N * H * W * (C / 4), 256)), dim3(256), 0, stream, x, ldx, N, h,
+                       w, C, H, W, ac_scale_host(h, H), ac_scale_host(w, W), y, ldy);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void k_bilinear_rows_bwd(const float* __restrict__ dy, long lddy, int N, int h, int w, int C, int H, int W,
+                                    float sy, float sx, float* __restrict__ dx, long lddx) {
+    const int C4 = C >> 2;
+    const long total = (long)N * h * w * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        long p = i / C4;
+        const int ix = (int)(p % w);
+        long t = p / w;
+        const int iy = (int)(t % h), n = (int)(t / h);
+        int oy_lo = sy > 0 ? (int)floorf((iy - 1) / sy) - 1 : 0, oy_hi = sy > 0 ? (int)ceilf((iy + 1) / sy) + 1 : H - 1;
+        int ox_lo = sx > 0 ? (int)floorf((ix - 1) / sx) - 1 : 0, ox_hi = sx > 0 ? (int)ceilf((ix + 1) / sx) + 1 : W - 1;
+        oy_lo = max(oy_lo, 0); ox_lo = max(ox_lo, 0);
+        oy_hi = min(oy_hi, H - 1); ox_hi = min(ox_hi, W - 1);
+        float4 acc = f4zero();
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            const AcCoord cy = ac_coord(oy, sy, h);
+            if (cy.i0 != iy && cy.i1 != iy) continue;
+            const float wy = (cy.i0 == iy ? cy.l0 : 0.f) + (cy.i1 == iy ? cy.l1 : 0.f);
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                const AcCoord cx = ac_coord(ox, sx, w);
+                if (cx.i0 != ix && cx.i1 != ix) continue;
+                const float ww = wy * ((cx.i0 == ix ? cx.l0 : 0.f) + (cx.i1 == ix ? cx.l1 : 0.f));
+                const float4 g = *(const float4*)(dy + (((long)n * H + oy) * W + ox) * lddy + c);
+                acc.x += ww * g.x; acc.y += ww * g.y; acc.z += ww * g.z; acc.w += ww * g.w;
+            }
+        }
+        *(float4*)(dx + p * lddx + c) = acc;
+    }
+}
+U2PL_API int u2pl_bilinear_rows_bwd_f32(const float* dy, long lddy, int N, int h, int w, int C, int H, int W, float* dx,
+                                        long lddx, hipStream_t stream) {
+    if (C % 4) return U2PL_EINVAL;
+    hipLaunchKernelGGL(k_bilinear_rows_bwd, dim3(grid_for((long)N * h * w * (C / 4), 256)), dim3(256), 0, stream, dy, lddy, N,
+                       h, w, C, H, W, ac_scale_host(h, H), ac_scale_host(w, W), dx, lddx);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// softmax over the channel axis of strided low-res logits (train_semi.py:365)
+// ---------------------------------------------------------------------------
+__global__ void k_softmax_rows(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy, long M, int C) {
+    for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < M; r += (long)gridDim.x * blockDim.x) {
+        const float* b = x + r * ldx;
+        float m = b[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, b[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(b[c] - m);
+        for (int c = 0; c < C; ++c) y[r * ldy + c] = expf(b[c] - m) / s;
+    }
+}
+U2PL_API int u2pl_softmax_rows_f32(const float* x, long ldx, float* y, long ldy, long M, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(k_softmax_rows, dim3(grid_for(M, 256)), dim3(256), 0, stream, x, ldx, y, ldy, M, C);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// optimizer / EMA on flat parameter arenas
+//   torch.optim.SGD: g += wd*p ; buf = first ? g : mom*buf + g ; p -= lr*buf
+//   (lr_helper.py:18-19), per-segment lr (3 param groups, train_semi.py:100-110)
+//   EMA: t = d*t + (1-d)*s   (train_semi.py:543-548)
+// ---------------------------------------------------------------------------
+__global__ void k_sgd(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long n, long b1,
+                      long b2, float lr0, float lr1, float lr2, float mom, float wd, int first, float gscale) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float lr = i < b1 ? lr0 : (i < b2 ? lr1 : lr2);
+        const float pv = p[i];
+        const float gv = __fadd_rn(__fmul_rn(g[i], gscale), __fmul_rn(wd, pv));
+        const float bv = first ? gv : __fadd_rn(__fmul_rn(mom, buf[i]), gv);
+        buf[i] = bv;
+        p[i] = __fsub_rn(pv, __fmul_rn(lr, bv));
+    }
+}
+U2PL_API int u2pl_sgd_step_f32(float* p, const float* g, float* buf, long n, long b1, long b2, float lr0, float lr1,
+                               float lr2, float momentum, float weight_decay, int first, float grad_scale,
+                               hipStream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_sgd, dim3(grid_for(n, 256)), dim3(256), 0, stream, p, g, buf, n, b1, b2, lr0, lr1, lr2, momentum,
+                       weight_decay, first, grad_scale);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void k_ema(float* __restrict__ t, const float* __restrict__ s, long n, float d, float omd) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        t[i] = __fadd_rn(__fmul_rn(d, t[i]), __fmul_rn(omd, s[i]));
+}
+U2PL_API int u2pl_ema_update_f32(float* t, const float* s, long n, float decay, float one_minus_decay,
+                                 hipStream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_ema, dim3(grid_for(n, 256)), dim3(256), 0, stream, t, s, n, decay, one_minus_decay);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// CutMix (augmentation.py:498-541): dst[i] = box_i ? src[(i+1)%B] : src[i]
+// for image (float, C planes), label (int64) and confidence (float)
+// boxes: int32 [B][4] = y0,y1,x0,x1 (device)
+// ---------------------------------------------------------------------------
+__global__ void k_cutmix(const float* __restrict__ img, const long long* __restrict__ lab, const float* __restrict__ conf,
+                         const int* __restrict__ boxes, int B, int C, int H, int W, float* __restrict__ oimg,
+                         long long* __restrict__ olab, float* __restrict__ oconf) {
+    const long HW = (long)H * W, total = (long)B * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const long q = i % HW;
+        const int yy = (int)(q / W), xx = (int)(q % W);
+        const int* bx = boxes + 4 * b;
+        const bool in = yy >= bx[0] && yy < bx[1] && xx >= bx[2] && xx < bx[3];
+        const int sb = in ? (b + 1) % B : b;
+        for (int c = 0; c < C; ++c) oimg[((long)b * C + c) * HW + q] = img[((long)sb * C + c) * HW + q];
+        olab[i] = lab[(long)sb * HW + q];
+        oconf[i] = conf[(long)sb * HW + q];
+    }
+}
+U2PL_API int u2pl_cutmix_f32(const float* img, const long long* label, const float* conf, const int* boxes_dev, int B,
+                             int C, int H, int W, float* out_img, long long* out_label, float* out_conf,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(k_cutmix, dim3(grid_for((long)B * H * W, 256)), dim3(256), 0, stream, img, label, conf, boxes_dev, B, C,
+                       H, W, out_img, out_label, out_conf);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,504 @@
+"""Layer modules of the MI355X-native DeepLabv3+ / dilated ResNet stack.
+
+Each module keeps torch's parameter/buffer NAMES (checkpoint wire format of the
+reference: ``encoder.layer3.5.conv2.weight`` ...) but its math is a HIP kernel
+from libu2pl_hip.so reached through a ``torch.autograd.Function``.  Activations
+are logical NCHW tensors stored channels_last (NHWC "rows"); conv weights are
+logical OIHW stored channels_last ([Cout][R][S][Cin]) so 1x1 convs are plain
+GEMMs and state_dicts stay interchangeable with the reference.
+
+``nn.ReLU`` / ``nn.Dropout2d`` / ``nn.AdaptiveAvgPool2d`` instances inside
+``nn.Sequential`` containers are only *markers* (they keep the reference's
+Sequential indices); ``run_seq`` fuses them into the BatchNorm apply kernel.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from ._lib import HipError, call, query
+
+_CL = torch.channels_last
+
+
+# ------------------------------------------------------------------ layout helpers
+def as_rows(t):
+    """logical (N,C,H,W) -> (tensor, ld) such that pixel p / channel c lives at
+    base + p*ld + c.  Accepts channels_last tensors and channel slices of them
+    (ld = row pitch of the parent buffer); anything else is re-laid-out once."""
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise HipError("u2pl_amd layers need float32 GPU tensors (no CPU fallback)")
+    N, C, H, W = t.shape
+    if H * W == 1:
+        return t.reshape(N, C).contiguous().reshape(N, C, 1, 1), C
+    ld = t.stride(3)
+    ok = t.stride(1) == 1 and ld >= C and t.stride(2) == W * ld and t.stride(0) == H * W * ld
+    if not ok:
+        t = t.contiguous(memory_format=_CL)
+        ld = C
+    return t, ld
+
+
+def new_act(N, C, H, W, device):
+    return torch.empty((N, C, H, W), dtype=torch.float32, device=device, memory_format=_CL)
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _grad_sink(p):
+    """Arena gradient view of a parameter (set by ParamArena) or None."""
+    return getattr(p, "_u2pl_grad", None)
+
+
+# ------------------------------------------------------------------ convolution
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil, wsink, bsink):
+        x, ldx = as_rows(x)
+        N, Cin, H, W = x.shape
+        Cout, _, R, S = weight.shape
+        Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dil * (S - 1) - 1) // stride + 1
+        if not weight.is_contiguous(memory_format=_CL) and not (R == 1 and S == 1 and weight.is_contiguous()):
+            raise HipError("conv weight must be stored channels_last ([Cout][R][S][Cin])")
+        y = new_act(N, Cout, Ho, Wo, x.device)
+        col = None
+        if Cin % 32:
+            Kp = ((R * S * Cin + 31) // 32) * 32
+            col = torch.empty((N * Ho * Wo, Kp), dtype=torch.float32, device=x.device)
+            call("u2pl_im2col_f32", x, ldx, col, Kp, N, H, W, Cin, Ho, Wo, R, S, stride, pad, dil)
+            wp = torch.zeros((Cout, Kp), dtype=torch.float32, device=x.device)
+            wp[:, : R * S * Cin] = weight.permute(0, 2, 3, 1).reshape(Cout, R * S * Cin)
+            call("u2pl_conv2d_fwd_f32", col, Kp, wp, bias, y, Cout, N, Ho, Wo, Kp, Ho, Wo, Cout, 1, 1, 1, 0, 1)
+        else:
+            call("u2pl_conv2d_fwd_f32", x, ldx, weight, bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil)
+        ctx.save_for_backward(x, weight, col)
+        ctx.geom = (N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ldx)
+        ctx.has_bias = bias is not None
+        ctx.wsink, ctx.bsink = wsink, bsink
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, col = ctx.saved_tensors
+        N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ldx = ctx.geom
+        gy, ldg = as_rows(gy)
+        dev = gy.device
+        M = N * Ho * Wo
+        Cp = Cout
+        if Cout % 32:  # narrow heads (num_classes outputs): zero-pad the gradient columns once
+            Cp = (Cout + 31) // 32 * 32
+            gp = torch.zeros((M, Cp), dtype=torch.float32, device=dev)
+            call("u2pl_copy_cols_f32", gy, ldg, gp, Cp, M, Cout)
+            gy, ldg = gp, Cp
+            wpad = torch.zeros((Cp, Cin, R, S), dtype=torch.float32, device=dev).contiguous(memory_format=_CL)
+            wpad[:Cout] = weight
+            weight_k = wpad
+        else:
+            weight_k = weight
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wT = torch.empty(Cin * R * S * Cp, dtype=torch.float32, device=dev)
+            call("u2pl_weight_transpose_f32", weight_k, wT, Cp, R * S, Cin)
+            dx = new_act(N, Cin, H, W, dev)
+            call("u2pl_conv2d_dgrad_f32", gy, ldg, wT, dx, Cin, N, H, W, Cin, Ho, Wo, Cp, R, S, stride, pad, dil)
+        if ctx.needs_input_grad[1]:
+            sink = ctx.wsink
+            if col is not None:  # 3-channel stem: gradient of the padded [Cout][Kp] patch-matrix weights
+                Kp = col.shape[1]
+                tmp = torch.empty((Cp, Kp), dtype=torch.float32, device=dev)
+                wsb = _ws(query("u2pl_conv2d_wgrad_workspace_bytes", N, Ho, Wo, Kp, Cp, 1, 1), dev)
+                call("u2pl_conv2d_wgrad_f32", gy, ldg, col, Kp, tmp, wsb, 0, N, Ho, Wo, Kp, Ho, Wo, Cp, 1, 1, 1, 0, 1)
+                g = tmp[:Cout, : R * S * Cin].reshape(Cout, R, S, Cin).permute(0, 3, 1, 2)
+                if sink is not None:
+                    sink.add_(g)
+                else:
+                    dw = g.contiguous(memory_format=_CL)
+            else:
+                wsb = _ws(query("u2pl_conv2d_wgrad_workspace_bytes", N, Ho, Wo, Cin, Cp, R, S), dev)
+                direct = sink is not None and Cp == Cout
+                tgt = sink if direct else torch.empty_like(weight_k)
+                call("u2pl_conv2d_wgrad_f32", gy, ldg, x, ldx, tgt, wsb, int(direct), N, H, W, Cin, Ho, Wo, Cp, R, S,
+                     stride, pad, dil)
+                if not direct:
+                    if sink is not None:
+                        sink.add_(tgt[:Cout])
+                    else:
+                        dw = tgt[:Cout] if Cp != Cout else tgt
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            sums = torch.empty(2 * Cp, dtype=torch.float64, device=dev)
+            wsb = _ws(query("u2pl_colreduce_workspace_bytes", M, 1, Cp), dev)
+            call("u2pl_colsum_f32", gy, ldg, M, 1, Cp, wsb, sums)
+            if ctx.bsink is not None:
+                call("u2pl_sums_to_f32", sums, Cout, 1.0, 1, ctx.bsink)
+            else:
+                db = torch.empty(Cout, dtype=torch.float32, device=dev)
+                call("u2pl_sums_to_f32", sums, Cout, 1.0, 0, db)
+        return dx, dw, db, None, None, None, None, None
+
+
+class Conv2d(nn.Module):
+    """nn.Conv2d(groups=1) with torch's default init, weight stored channels_last."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias=True):
+        super().__init__()
+        k = kernel_size
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.dilation = (k, k), stride, padding, dilation
+        w = torch.empty(out_channels, in_channels, k, k)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))  # == nn.Conv2d.reset_parameters (same RNG draws)
+        self.weight = nn.Parameter(w.contiguous(memory_format=_CL))
+        if bias:
+            fan_in = in_channels * k * k
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            b = torch.empty(out_channels)
+            nn.init.uniform_(b, -bound, bound)
+            self.bias = nn.Parameter(b)
+        else:
+            self.register_parameter("bias", None)
+
+    def forward(self, x):
+        return _ConvFn.apply(x, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                             _grad_sink(self.weight), _grad_sink(self.bias) if self.bias is not None else None)
+
+    def extra_repr(self):
+        return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}, p={self.padding}, d={self.dilation}"
+
+
+# ------------------------------------------------------------------ batch norm (+res +relu +dropout)
+class _BNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, drop, mod, relu, gsink, bsink):
+        x, ldx = as_rows(x)
+        N, C, H, W = x.shape
+        M = N * H * W
+        dev = x.device
+        rr = ldr = None
+        if res is not None:
+            rr, ldr = as_rows(res)
+        y = new_act(N, C, H, W, dev)
+        training = mod.training
+        sync = mod.sync and _world() > 1
+        if training:
+            pivot = mod.running_mean
+            sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+            wsb = _ws(query("u2pl_colreduce_workspace_bytes", M, 1, C), dev)
+            call("u2pl_bn_stats_f32", x, ldx, M, C, pivot, wsb, sums)
+            count = float(M)
+            if sync:
+                sums[2 * C] = float(M)
+                dist.all_reduce(sums)
+                count = float(M * _world())  # equal per-rank shapes (drop_last loaders)
+            mean = torch.empty(C, dtype=torch.float32, device=dev)
+            invstd = torch.empty(C, dtype=torch.float32, device=dev)
+            call("u2pl_bn_finalize_f32", sums, count, pivot, C, mod.eps, mod.momentum, mean, invstd, mod.running_mean,
+                 mod.running_var)
+            mod.num_batches_tracked += 1
+        else:
+            mean = mod.running_mean
+            invstd = torch.empty(C, dtype=torch.float32, device=dev)
+            call("u2pl_bn_eval_invstd_f32", mod.running_var, C, mod.eps, invstd)
+            count = float(M)
+        call("u2pl_bn_apply_f32", x, ldx, mean, invstd, gamma, beta, rr, ldr or 0, int(relu), drop, H * W, y, C, M, C)
+        ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma, drop)
+        ctx.meta = (N, C, H, W, ldx, training, sync, count, res is not None)
+        ctx.gsink, ctx.bsink = gsink, bsink
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, mean, invstd, gamma, drop = ctx.saved_tensors
+        N, C, H, W, ldx, training, sync, count, has_res = ctx.meta
+        M = N * H * W
+        gy, ldg = as_rows(gy)
+        dev = gy.device
+        sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        wsb = _ws(query("u2pl_colreduce_workspace_bytes", M, 1, C), dev)
+        call("u2pl_bn_bwd_sums_f32", gy, ldg, x, ldx, y, C, mean, invstd, drop, H * W, M, C, wsb, sums)
+        dgamma = dbeta = None
+        # parameter gradients are LOCAL sums (DDP averages them later), like torch SyncBN
+        if ctx.needs_input_grad[1]:
+            if ctx.gsink is not None:
+                call("u2pl_sums_to_f32", sums[C:], C, 1.0, 1, ctx.gsink)
+                call("u2pl_sums_to_f32", sums, C, 1.0, 1, ctx.bsink)
+            else:
+                dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+                dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+                call("u2pl_sums_to_f32", sums[C:], C, 1.0, 0, dgamma)
+                call("u2pl_sums_to_f32", sums, C, 1.0, 0, dbeta)
+        if sync and training:
+            dist.all_reduce(sums)
+        dx = new_act(N, C, H, W, dev) if ctx.needs_input_grad[0] else None
+        dres = new_act(N, C, H, W, dev) if has_res and ctx.needs_input_grad[3] else None
+        if dx is not None:
+            call("u2pl_bn_bwd_apply_f32", gy, ldg, x, ldx, y, C, mean, invstd, gamma, drop, H * W,
+                 sums if training else None, count, dx, C, dres, C, M, C)
+        return dx, dgamma, dbeta, dres, None, None, None, None, None
+
+
+class BatchNorm2d(nn.Module):
+    """nn.BatchNorm2d / nn.SyncBatchNorm (base.py:6-8) with torch defaults (eps 1e-5,
+    momentum 0.1, affine, running stats).  `sync=True` exchanges the per-channel
+    sums across ranks (one small all-reduce per layer, fwd and bwd)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, sync=False):
+        super().__init__()
+        self.num_features, self.eps, self.momentum, self.sync = num_features, eps, momentum, sync
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x, res=None, relu=False, drop=None):
+        return _BNFn.apply(x, self.weight, self.bias, res, drop, self, relu, _grad_sink(self.weight),
+                           _grad_sink(self.bias))
+
+
+class SyncBatchNorm(BatchNorm2d):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__(num_features, eps, momentum, sync=True)
+
+
+def dropout2d_scale(p, N, C, device, training):
+    """nn.Dropout2d(p) keep-mask as a per-(n,c) scale (0 or 1/(1-p)); None in eval mode."""
+    if not training or p <= 0:
+        return None
+    keep = (torch.rand((N, C), device=device) >= p).to(torch.float32)
+    return keep.mul_(1.0 / (1.0 - p))
+
+
+def run_seq(seq, x, drop_override=None):
+    """Execute an nn.Sequential of {Conv2d, BatchNorm2d, ReLU, Dropout2d} fusing
+    BN + ReLU + Dropout2d into one kernel (indices/names unchanged)."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, BatchNorm2d):
+            relu, drop, j = False, None, i + 1
+            if j < len(mods) and isinstance(mods[j], nn.ReLU):
+                relu, j = True, j + 1
+            if j < len(mods) and isinstance(mods[j], nn.Dropout2d):
+                if drop_override is not None and id(mods[j]) in drop_override:
+                    drop = drop_override[id(mods[j])]
+                else:
+                    drop = dropout2d_scale(mods[j].p, x.shape[0], x.shape[1], x.device, mods[j].training)
+                j += 1
+            x = m(x, relu=relu, drop=drop)
+            i = j
+        elif isinstance(m, (nn.ReLU, nn.Dropout2d)):
+            raise HipError("un-fused ReLU/Dropout2d marker in Sequential")
+        else:
+            x = m(x)
+            i += 1
+    return x
+
+
+# ------------------------------------------------------------------ pooling / resize / concat
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x, ldx = as_rows(x)
+        N, C, H, W = x.shape
+        Ho = -(-(H + 2 - 3) // 2) + 1
+        Wo = -(-(W + 2 - 3) // 2) + 1
+        if (Ho - 1) * 2 >= H + 1:
+            Ho -= 1
+        if (Wo - 1) * 2 >= W + 1:
+            Wo -= 1
+        y = new_act(N, C, Ho, Wo, x.device)
+        tap = torch.empty((N * Ho * Wo, C), dtype=torch.uint8, device=x.device)
+        call("u2pl_maxpool3s2_fwd_f32", x, ldx, N, H, W, C, Ho, Wo, y, C, tap)
+        ctx.save_for_backward(tap)
+        ctx.meta = (N, C, H, W, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (tap,) = ctx.saved_tensors
+        N, C, H, W, Ho, Wo = ctx.meta
+        gy, ldg = as_rows(gy)
+        dx = new_act(N, C, H, W, gy.device)
+        call("u2pl_maxpool3s2_bwd_f32", gy, ldg, tap, N, H, W, C, Ho, Wo, dx, C)
+        return dx
+
+
+class MaxPool3x3s2Ceil(nn.Module):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1, ceil_mode=True) (resnet.py:189-191)."""
+
+    def forward(self, x):
+        return _MaxPoolFn.apply(x)
+
+
+class _GapFn(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d((1,1)) (base.py:24)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x, ldx = as_rows(x)
+        N, C, H, W = x.shape
+        sums = torch.empty((N, 2, C), dtype=torch.float64, device=x.device)
+        wsb = _ws(query("u2pl_colreduce_workspace_bytes", H * W, N, C), x.device)
+        call("u2pl_colsum_f32", x, ldx, H * W, N, C, wsb, sums)
+        y = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        for n in range(N):
+            call("u2pl_sums_to_f32", sums[n], C, 1.0 / (H * W), 0, y[n])
+        ctx.meta = (N, C, H, W)
+        return y.reshape(N, C, 1, 1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, H, W = ctx.meta
+        g = gy.reshape(N, C).contiguous()
+        dx = new_act(N, C, H, W, g.device)
+        call("u2pl_broadcast_rows_f32", g, C, 1.0 / (H * W), dx, C, H * W, N * H * W, C)
+        return dx
+
+
+def global_avg_pool(x):
+    return _GapFn.apply(x)
+
+
+class _BroadcastFn(torch.autograd.Function):
+    """bilinear(align_corners=True) up-sampling of a 1x1 map == broadcast (base.py:92-94)."""
+
+    @staticmethod
+    def forward(ctx, v, H, W):
+        N, C = v.shape[0], v.shape[1]
+        vv = v.reshape(N, C).contiguous()
+        y = new_act(N, C, H, W, v.device)
+        call("u2pl_broadcast_rows_f32", vv, C, 1.0, y, C, H * W, N * H * W, C)
+        ctx.meta = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, H, W = ctx.meta
+        gy, ldg = as_rows(gy)
+        sums = torch.empty((N, 2, C), dtype=torch.float64, device=gy.device)
+        wsb = _ws(query("u2pl_colreduce_workspace_bytes", H * W, N, C), gy.device)
+        call("u2pl_colsum_f32", gy, ldg, H * W, N, C, wsb, sums)
+        g = torch.empty((N, C), dtype=torch.float32, device=gy.device)
+        for n in range(N):
+            call("u2pl_sums_to_f32", sums[n], C, 1.0, 0, g[n])
+        return g.reshape(N, C, 1, 1), None, None
+
+
+class _UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, H, W):
+        x, ldx = as_rows(x)
+        N, C, h, w = x.shape
+        y = new_act(N, C, H, W, x.device)
+        call("u2pl_bilinear_rows_fwd_f32", x, ldx, N, h, w, C, H, W, y, C)
+        ctx.meta = (N, C, h, w, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, h, w, H, W = ctx.meta
+        gy, ldg = as_rows(gy)
+        dx = new_act(N, C, h, w, gy.device)
+        call("u2pl_bilinear_rows_bwd_f32", gy, ldg, N, h, w, C, H, W, dx, C)
+        return dx, None, None
+
+
+def upsample_bilinear(x, size):
+    """F.interpolate(x, size, mode='bilinear', align_corners=True) on feature maps."""
+    H, W = int(size[0]), int(size[1])
+    if x.shape[2] == 1 and x.shape[3] == 1:
+        return _BroadcastFn.apply(x, H, W)
+    return _UpsampleFn.apply(x, H, W)
+
+
+class _CatFn(torch.autograd.Function):
+    """torch.cat(tensors, dim=1) on NHWC rows: strided row copies into channel slices."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        N, _, H, W = xs[0].shape
+        Cs = [t.shape[1] for t in xs]
+        out = new_act(N, sum(Cs), H, W, xs[0].device)
+        o = 0
+        for t, c in zip(xs, Cs):
+            t, ld = as_rows(t)
+            call("u2pl_copy_rows_f32", t, ld, out[:, o:o + c], sum(Cs), N * H * W, c, 0)
+            o += c
+        ctx.Cs = Cs
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, o = [], 0
+        for c in ctx.Cs:
+            outs.append(g[:, o:o + c])
+            o += c
+        return tuple(outs)
+
+
+def cat_channels(tensors):
+    return _CatFn.apply(*tensors)
+
+
+# ------------------------------------------------------------------ flat parameter arena
+class ParamArena:
+    """All parameters of a model in ONE flat fp32 buffer (+ a same-shaped flat
+    gradient buffer) so the SGD step, the teacher EMA and the DDP gradient
+    all-reduce are single launches over 66.8 M elements instead of ~1100 tiny
+    ones.  Parameter tensors become views of the arena; their
+    layer kernels accumulate weight gradients straight into the gradient view."""
+
+    def __init__(self, groups, with_grad=True):
+        """groups: list of lists of nn.Parameter (each group = one lr segment, kept contiguous)."""
+        self.params = [p for g in groups for p in g]
+        dev = self.params[0].device
+        sizes = [p.numel() for p in self.params]
+        self.n = sum(sizes)
+        self.bounds, acc = [], 0
+        for g in groups:
+            acc += sum(p.numel() for p in g)
+            self.bounds.append(acc)
+        self.flat = torch.empty(self.n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.n, dtype=torch.float32, device=dev) if with_grad else None
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            view = self.flat[off:off + n].as_strided(p.shape, p.stride())
+            view.copy_(p.data)
+            p.data = view
+            if with_grad:
+                gv = self.grad[off:off + n].as_strided(p.shape, p.stride())
+                p._u2pl_grad = gv
+                p.grad = gv
+            off += n
+        self.momentum_buf = None
+        self.steps = 0
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def sgd_step(self, lrs, momentum, weight_decay, grad_scale=1.0):
+        """torch.optim.SGD(momentum, weight_decay) semantics with per-group lr."""
+        if self.momentum_buf is None:
+            self.momentum_buf = torch.zeros_like(self.flat)
+        b = self.bounds + [self.n] * 3
+        lr = list(lrs) + [lrs[-1]] * 3
+        call("u2pl_sgd_step_f32", self.flat, self.grad, self.momentum_buf, self.n, b[0], b[1], float(lr[0]),
+             float(lr[1]), float(lr[2]), float(momentum), float(weight_decay), int(self.steps == 0),
+             float(grad_scale))
+        self.steps += 1
+
+    def ema_from(self, other, decay):
+        """self = decay*self + (1-decay)*other  (train_semi.py:543-548)."""
+        call("u2pl_ema_update_f32", self.flat, other.flat, self.n, float(decay), float(1 - decay))
+
+    def copy_from(self, other):
+        self.flat.copy_(other.flat)

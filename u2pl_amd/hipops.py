@@ -340,6 +340,7 @@ def infonce_loss(rep_rows, ph1, bank, valid_classes, counts_host, cfg, randint=N
             inn = randint(bank.length[vc], Q * K)
             jobs.append((i, vc))
             idx_chunks += [ia.to(torch.int64), inn.to(torch.int64)]
+    infonce_loss.last_njobs = len(jobs)
     if not jobs:
         return None
     dev = rep_rows.device

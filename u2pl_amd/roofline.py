@@ -1,0 +1,110 @@
+"""Roofline accounting for bench.py: per-entry-point HIP-event timing of one extra
+(un-timed) training step on the stream the kernels run on, algorithmic FLOPs /
+bytes from SURVEY.md section 8(d), peaks from MI355X_MICROARCH.md."""
+import os
+import time
+
+import torch
+
+from . import _lib
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0          # HBM3E spec (6290 GB/s measured float4 copy)
+
+# positions of the geometry ints inside each conv entry point's argument list
+_CONV_GEOM = {
+    "u2pl_conv2d_fwd_f32": 6, "u2pl_conv2d_dgrad_f32": 5, "u2pl_conv2d_wgrad_f32": 7,
+}
+
+
+def _conv_flops(name, args):
+    i = _CONV_GEOM[name]
+    N, Hin, Win, Cin, Hout, Wout, Cout, R, S = args[i:i + 9]
+    return 2.0 * N * Hout * Wout * Cout * R * S * Cin
+
+
+def profile_step(step_fn):
+    _lib.PROFILE = []
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+        rec = _lib.PROFILE
+    finally:
+        _lib.PROFILE = None
+    agg = {}
+    for name, args, e0, e1 in rec:
+        d = agg.setdefault(name, dict(ms=0.0, calls=0, flops=0.0))
+        d["ms"] += e0.elapsed_time(e1)
+        d["calls"] += 1
+        if name in _CONV_GEOM:
+            d["flops"] += _conv_flops(name, args)
+    return agg
+
+
+def hbm_algorithmic_bytes(B, C, H, W, h, w, D, stats):
+    """entropy+reliability 4C+24 B/pixel + low-res outputs; contrastive with
+    the Q0 skip (only images {0,B} referenced) from the measured counts."""
+    px = B * H * W
+    rel = px * (4 * C + 24) + (2 * 4 + 8) * 2 * B * h * w
+    Q, K = stats.get("Q", 256), stats.get("K", 50)
+    con = (2 * D * h * w * 4 + 2 * B * C * h * w * 4 + 2 * B * h * w * 9 + stats.get("n_keys", 0) * D * 4
+           + stats.get("njobs", 0) * Q * (2 + K) * D * 4 + stats.get("njobs", 0) * Q * D * 4)
+    return rel, con
+
+
+def measure(trainer, batch, args, ms_per_step):
+    from .utils import loss_helper as LH
+
+    il, ll, iu = batch
+    agg = profile_step(lambda: trainer.train_step(il, ll, iu, epoch=0))
+    out = {}
+    ig = [agg.get("u2pl_conv2d_fwd_f32"), agg.get("u2pl_conv2d_dgrad_f32")]
+    ig = [x for x in ig if x]
+    if ig:
+        fl, t, n = sum(x["flops"] for x in ig), sum(x["ms"] for x in ig), sum(x["calls"] for x in ig)
+        ach = fl / (t * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "k_conv_igemm (conv fwd + dgrad, fp32 MFMA)", "bound": "mfma",
+                           "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": n, "avg_launch_ms": round(t / n, 4),
+                           "algorithmic_tflop_per_step": round(fl / 1e12, 3), "ms_per_step": round(t, 2)}
+    wg = agg.get("u2pl_conv2d_wgrad_f32")
+    if wg:
+        ach = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
+        out["roofline_wgrad"] = {"kernel": "k_conv_wgrad (+ordered slab reduce)", "bound": "mfma",
+                                 "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                                 "launches_per_step": wg["calls"], "ms_per_step": round(wg["ms"], 2)}
+    B, H, W = ll.shape
+    C = trainer.num_classes
+    h, w = (H - 1) // 4 + 1, (W - 1) // 4 + 1
+    rel_names = ["u2pl_entropy_f32", "u2pl_select_f32", "u2pl_apply_drop_i64", "u2pl_reliability_masks"]
+    con_names = ["u2pl_contra_classify", "u2pl_compact_lists", "u2pl_class_prototypes", "u2pl_bank_append_f32",
+                 "u2pl_infonce_f32", "u2pl_infonce_reduce_f32", "u2pl_scatter_add_rows_f32"]
+    rel_b, con_b = hbm_algorithmic_bytes(B, C, H, W, h, w, 256, LH.LAST_STATS)
+    t_rel = sum(agg[n]["ms"] for n in rel_names if n in agg)
+    t_con = sum(agg[n]["ms"] for n in con_names if n in agg)
+    if t_rel > 0 and t_con > 0:
+        ach = (rel_b + con_b) / ((t_rel + t_con) * 1e-3) / 1e9
+        out["roofline_hbm"] = {"kernel": "entropy + exact select + masks + contrastive (classify/compact/proto/bank/InfoNCE)",
+                               "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                               "algorithmic_MB": round((rel_b + con_b) / 1e6, 1), "reliability_us": round(t_rel * 1e3, 1),
+                               "contrastive_us": round(t_con * 1e3, 1), "stats": dict(LH.LAST_STATS)}
+    top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]
+    out["kernel_ms_per_step"] = {k: round(v["ms"], 2) for k, v in top}
+    out["kernel_ms_total_profiled"] = round(sum(v["ms"] for v in agg.values()), 2)
+    return out
+
+
+def cpu_baseline(args):
+    """Oracle ("port") timed on this box's host cores: one reference-equivalent CPU
+    training step (torch-CPU model restatement + numpy loss path) on a bounded sample."""
+    import importlib
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    step_ref = importlib.import_module("oracle.step_ref")
+    return step_ref.timed_cpu_baseline(crop=args.crop, arch=args.arch)

@@ -1,0 +1,208 @@
+"""The U2PL semi-supervised training step on one MI355X per rank.
+
+This is the reference's hot loop ``train_semi.py:train()`` (lines 272-561)
+re-expressed around device-resident state: every tensor op is a HIP kernel
+(u2pl_amd.nn / u2pl_amd.hipops), the memory bank lives in HBM, entropy and the
+three percentile thresholds are computed once and selected exactly on device,
+parameters / gradients / momentum live in flat arenas (one SGD launch, one EMA
+launch, one gradient all-reduce).  The only host synchronisation per step is the
+read-back of ~60 list lengths that bound the reference's CPU ``torch.randint``
+anchor / negative sampling (kept for bit-identical sampling).
+
+Reference behaviours reproduced on purpose: label_onehot
+batch-slot-0 quirk (Q0), class-index mismatch (Q1), bank update before
+sampling (Q3), contrastive gradient scaled by an extra 1/world (Q5), teacher
+aliasing in the first semi epoch (Q6), per-rank thresholds (Q7), LR set before
+the forward (Q9), zero (not None) grads for unused heads (Q13).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import hipops as H
+from . import nn as K
+from .utils import loss_helper as LH
+from .utils.lr_helper import poly_lr
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def generate_cutmix_boxes(B, im_h, im_w, ratio=2):
+    """Host-side rectangle draws, same np.random call order as the reference
+    (augmentation.py:471-485): w, x_start, y_start per sample."""
+    boxes = []
+    for _ in range(B):
+        area = im_h * im_w / ratio
+        w = np.random.randint(im_w / ratio + 1, im_w)
+        h = np.round(area / w)
+        x0 = np.random.randint(0, im_w - w + 1)
+        y0 = np.random.randint(0, im_h - h + 1)
+        boxes.append((int(y0), int(y0 + h), int(x0), int(x0 + w)))
+    return boxes
+
+
+def cutmix(image, label, conf, boxes):
+    """generate_unsup_data(mode='cutmix') (augmentation.py:498-541) in one launch."""
+    B, C, Hh, Ww = image.shape
+    image = image.contiguous()
+    bx = torch.tensor(boxes, dtype=torch.int32).to(image.device, non_blocking=True)
+    oi, ol, oc = torch.empty_like(image), torch.empty_like(label), torch.empty_like(conf)
+    K.call("u2pl_cutmix_f32", image, label, conf, bx, B, C, Hh, Ww, oi, ol, oc)
+    return oi, ol, oc
+
+
+class SemiTrainer:
+    def __init__(self, cfg, model, model_teacher, sup_loss_fn, steps_per_epoch, memobank=None):
+        self.cfg = cfg
+        self.model, self.teacher = model, model_teacher
+        self.sup_loss_fn = sup_loss_fn
+        self.steps_per_epoch = steps_per_epoch
+        tr = cfg["trainer"]
+        self.epochs = tr["epochs"]
+        self.sup_only_epoch = tr.get("sup_only_epoch", 1)
+        ok = tr["optimizer"]
+        assert ok["type"] == "SGD", "flat-arena step implements torch.optim.SGD (reference configs use SGD)"
+        self.base_lr = ok["kwargs"]["lr"]
+        self.momentum = ok["kwargs"].get("momentum", 0.0)
+        self.weight_decay = ok["kwargs"].get("weight_decay", 0.0)
+        self.power = tr["lr_scheduler"]["kwargs"].get("power", 0.9) or 0.9
+        times = 10 if cfg["dataset"]["type"].startswith("pascal") else 1  # train_semi.py:100-110
+        groups = [list(model.encoder.parameters()), list(model.decoder.parameters())]
+        tgroups = [list(model_teacher.encoder.parameters()), list(model_teacher.decoder.parameters())]
+        self.lr_mult = [1, times]
+        if hasattr(model, "auxor"):
+            groups.append(list(model.auxor.parameters()))
+            tgroups.append(list(model_teacher.auxor.parameters()))
+            self.lr_mult.append(times)
+        self.arena = K.ParamArena(groups)
+        self.t_arena = K.ParamArena(tgroups, with_grad=False)
+        for p in model_teacher.parameters():
+            p.requires_grad = False
+        C = cfg["net"]["num_classes"]
+        self.num_classes = C
+        dev = next(model.parameters()).device
+        if memobank is None:
+            qs = [30000] * C
+            qs[0] = 50000  # train_semi.py:161-169
+            memobank = H.DeviceMemoryBank(C, qs, 256, dev)
+        self.memobank = memobank
+        self.cur_iter = 0
+        self.use_aux = "aux_loss" in cfg["net"].keys()
+
+    # -- LRScheduler.step (lr_helper.py:78-113): lr for this step is set before the forward
+    def _lrs(self):
+        max_iter = self.epochs * self.steps_per_epoch
+        lr = poly_lr(self.base_lr, self.cur_iter, max_iter, self.power)
+        self.cur_iter += 1
+        return [lr * m for m in self.lr_mult]
+
+    def _reduce_grads_and_step(self, lrs):
+        W = _world()
+        if W > 1:
+            dist.all_reduce(self.arena.grad)  # one flat RCCL all-reduce (DDP mean folded into the SGD launch)
+        self.arena.sgd_step(lrs, self.momentum, self.weight_decay, grad_scale=1.0 / W)
+
+    def train_step(self, image_l, label_l, image_u, epoch, cutmix_boxes=None, dropout=True):
+        cfg = self.cfg
+        model, teacher = self.model, self.teacher
+        B, h, w = label_l.shape
+        lrs = self._lrs()
+        i_iter = self.cur_iter - 1
+        model.train()
+        self.arena.zero_grad()
+        label_l = label_l.long().contiguous()
+        if epoch < self.sup_only_epoch:  # train_semi.py:288-307
+            outs = model(image_l)
+            pred = H.bilinear_up(outs["pred"], (h, w))
+            if self.use_aux:
+                aux = H.bilinear_up(outs["aux"], (h, w))
+                sup_loss = self.sup_loss_fn([pred, aux], label_l)
+            else:
+                sup_loss = self.sup_loss_fn(pred, label_l)
+            teacher.train()
+            with torch.no_grad():
+                teacher(image_l)
+            unsup_loss = H.zero_times_sum(outs["rep"])
+            contra_loss = H.zero_times_sum(outs["rep"])
+        else:
+            if epoch == self.sup_only_epoch:  # Q6: teacher params alias the student's
+                self.t_arena.copy_from(self.arena)
+            # pseudo labels (train_semi.py:317-324)
+            teacher.eval()
+            with torch.no_grad():
+                pred_u_t = teacher(image_u, need_aux=False, need_rep=False)["pred"]
+                conf_u, label_u_aug = H.pseudo_label(H.bilinear_up(pred_u_t, (h, w)))
+            unsup_cfg = cfg["trainer"]["unsupervised"]
+            # strong augmentation (train_semi.py:326-337): host coin flip + host rectangle draws
+            image_u_aug = image_u
+            if np.random.uniform(0, 1) < 0.5 and unsup_cfg.get("apply_aug", False):
+                assert unsup_cfg["apply_aug"] == "cutmix", "only cutmix is wired to a HIP kernel"
+                boxes = cutmix_boxes if cutmix_boxes is not None else generate_cutmix_boxes(B, h, w)
+                image_u_aug, label_u_aug, conf_u = cutmix(image_u, label_u_aug, conf_u, boxes)
+            # student forward (train_semi.py:339-358)
+            image_all = torch.cat((image_l, image_u_aug))
+            outs = model(image_all)
+            pred_all, rep_all = outs["pred"], outs["rep"]
+            pred_l_large = H.bilinear_up(pred_all[:B], (h, w))
+            pred_u_large = H.bilinear_up(pred_all[B:], (h, w))
+            if self.use_aux:
+                aux = H.bilinear_up(outs["aux"][:B], (h, w))
+                sup_loss = self.sup_loss_fn([pred_l_large, aux], label_l.clone())
+            else:
+                sup_loss = self.sup_loss_fn(pred_l_large, label_l.clone())
+            # teacher train-mode forward (train_semi.py:360-374)
+            teacher.train()
+            with torch.no_grad():
+                out_t = teacher(image_all, need_aux=False)
+                pred_all_t, rep_all_t = out_t["pred"], out_t["rep"]
+                prob_all_t = K.new_act(*pred_all_t.shape, pred_all_t.device)
+                pt, ldp = K.as_rows(pred_all_t)
+                Cn = pred_all_t.shape[1]
+                K.call("u2pl_softmax_rows_f32", pt, ldp, prob_all_t, Cn, pt.shape[0] * pt.shape[2] * pt.shape[3], Cn)
+                pred_u_large_t = H.bilinear_up(pred_all_t[B:], (h, w))
+                # one entropy pass + one exact selection for all three percentiles
+                drop_percent = unsup_cfg.get("drop_percent", 100)
+                percent_unreliable = (100 - drop_percent) * (1 - epoch / self.epochs)
+                drop_percent = 100 - percent_unreliable
+                ccfg = cfg["trainer"].get("contrastive", False)
+                specs = [("pct", float(drop_percent))]
+                if ccfg:
+                    alpha_t = ccfg["low_entropy_threshold"] * (1 - epoch / self.epochs)
+                    specs += [("pct", float(alpha_t)), ("pct", float(100 - alpha_t))]
+                ws = H.new_select_ws(image_l.device, B * h * w)
+                ent = H.entropy_map(pred_u_large_t, label_u_aug, ws)
+                thr = H.run_select(ent, ws, specs)
+                target_u = label_u_aug.clone()
+                H.drop_high_entropy_(target_u, ent, thr[0:1])
+            unsup_loss = H.cross_entropy(pred_u_large, target_u, 255, unsup_weight=True,
+                                         scale=float(unsup_cfg.get("loss_weight", 1)))
+            if ccfg:
+                with torch.no_grad():
+                    low_mask, high_mask, lbits = H.reliability_masks(
+                        ent, thr[1:2], thr[2:3], label_l, label_u_aug, pred_all.shape[2:],
+                        negative_high_entropy=ccfg.get("negative_high_entropy", True))
+                _, contra_local = LH.contra_memobank_core(
+                    rep_all, lbits, B, prob_all_t[:B], prob_all_t[B:], low_mask, high_mask, ccfg, self.memobank,
+                    rep_all_t)
+                # Q5: value = cross-rank mean, gradient = local / world
+                contra_loss = contra_local * (float(ccfg.get("loss_weight", 1)) / _world())
+            else:
+                contra_loss = H.zero_times_sum(rep_all)
+        loss = sup_loss + unsup_loss + contra_loss
+        loss.backward()
+        self._reduce_grads_and_step(lrs)
+        # teacher EMA (train_semi.py:531-548)
+        if epoch >= self.sup_only_epoch:
+            d = min(1 - 1 / (i_iter - self.steps_per_epoch * self.sup_only_epoch + 1), cfg["net"]["ema_decay"])
+            if epoch == self.sup_only_epoch:
+                self.t_arena.copy_from(self.arena)  # aliasing: t == s_new before the EMA line
+            self.t_arena.ema_from(self.arena, d)
+        meters = torch.stack((sup_loss.detach(), unsup_loss.detach(), contra_loss.detach()))
+        if _world() > 1:
+            cv = contra_loss.detach().clone()
+            dist.all_reduce(cv)        # contra value = cross-rank mean (train_semi.py:514-519)
+            meters[2] = cv
+            dist.all_reduce(meters)    # logged meters are cross-rank SUMS (train_semi.py:551-561)
+        return meters

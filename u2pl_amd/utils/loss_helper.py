@@ -25,6 +25,9 @@ def compute_unsupervised_loss(predict, target, percent, pred_teacher):
     return H.cross_entropy(predict, target, 255, unsup_weight=True)
 
 
+LAST_STATS = {}  # counts of the last contrastive call (bench roofline accounting)
+
+
 def _rows_view(t):
     """(N,D,h,w) logical NCHW -> (N*h*w, D) contiguous rows (no copy if channels_last)."""
     r = t.permute(0, 2, 3, 1)
@@ -60,9 +63,12 @@ def contra_memobank_core(rep, lbits, num_labeled, prob_l, prob_u, low_mask, high
         for i in range(C):
             new_keys.append(dequeue_and_enqueue_device(memobank, i, rep_t_rows, D, ph1.idx[2, i], int(counts[2][i])))
     valid_classes = [i for i in range(C) if counts[1][i] > 0]
+    LAST_STATS.update(n_keys=int(sum(new_keys)), valid_seg=len(valid_classes), njobs=0,
+                      Q=int(cfg["num_queries"]), K=int(cfg["num_negatives"]))
     if len(valid_classes) <= 1:
         return new_keys, H.zero_times_sum(rep)
     loss = H.infonce_loss(rep_rows, ph1, memobank, valid_classes, counts, cfg, randint)
+    LAST_STATS["njobs"] = getattr(H.infonce_loss, "last_njobs", 0)
     if loss is None:
         return new_keys, H.zero_times_sum(rep)
     return new_keys, loss

@@ -48,6 +48,10 @@ class _Lib:
                 f"{LIB_PATH} is missing: build it with `python -m u2pl_amd.build_ext` "
                 "(hipcc --offload-arch=gfx950).  u2pl_amd has no CPU/PyTorch fallback."
             )
+        # torch bundles its own libamdhip64; load it FIRST so this library binds to the same
+        # HIP runtime instance (streams / device pointers are shared with torch)
+        import torch  # noqa: F401
+
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.decls = parse_header()
         for name, (ret, at, _) in self.decls.items():

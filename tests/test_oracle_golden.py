@@ -189,3 +189,29 @@ def test_formula_state_dict_in_sync():
     m = nn.Sequential(nn.Conv2d(3, 8, 3), nn.BatchNorm2d(8))
     sa, sb = a(m), b(m)
     assert all(torch.equal(sa[k], sb[k]) for k in sa)
+
+
+@pytest.mark.parametrize("tag,arch,C,aux", [("r50_65", "resnet50", 19, True), ("r101_33", "resnet101", 21, False)])
+def test_model_ref_pinned_to_reference_golden(tag, arch, C, aux):
+    """oracle/model_ref.RefNet == the reference ModelBuilder: identical state_dict keys and
+    bit-identical CPU outputs / sampled gradients on the reference-generated golden."""
+    import torch
+    from model_utils import formula_state_dict
+    from oracle.model_ref import RefNet
+
+    g = golden("model_" + tag)
+    net = RefNet(arch, C, aux, p_drop=0.0)
+    net.load_state_dict(formula_state_dict(net))   # strict: key sets must match the reference's
+    net.train()
+    out = net(torch.from_numpy(g["x"]))
+    assert torch.equal(out["pred"], torch.from_numpy(g["pred"]))
+    assert torch.equal(out["rep"], torch.from_numpy(g["rep"]))
+    loss = (out["pred"] * torch.from_numpy(g["gp"])).sum() + (out["rep"] * torch.from_numpy(g["gr"])).sum()
+    if aux:
+        assert torch.equal(out["aux"], torch.from_numpy(g["aux"]))
+        loss = loss + (out["aux"] * torch.from_numpy(g["ga"])).sum()
+    loss.backward()
+    params = dict(net.named_parameters())
+    for n in g["grad_names"]:
+        gr = params[str(n)].grad.flatten()
+        assert torch.equal(gr[:: max(1, gr.numel() // 4096)][:4096], torch.from_numpy(g["grad__" + str(n)])), n

@@ -104,7 +104,7 @@ class SemiTrainer:
             dist.all_reduce(self.arena.grad)  # one flat RCCL all-reduce (DDP mean folded into the SGD launch)
         self.arena.sgd_step(lrs, self.momentum, self.weight_decay, grad_scale=1.0 / W)
 
-    def train_step(self, image_l, label_l, image_u, epoch, cutmix_boxes=None, dropout=True):
+    def train_step(self, image_l, label_l, image_u, epoch, cutmix_boxes=None, randint=None, debug=None):
         cfg = self.cfg
         model, teacher = self.model, self.teacher
         B, h, w = label_l.shape
@@ -185,11 +185,15 @@ class SemiTrainer:
                         negative_high_entropy=ccfg.get("negative_high_entropy", True))
                 _, contra_local = LH.contra_memobank_core(
                     rep_all, lbits, B, prob_all_t[:B], prob_all_t[B:], low_mask, high_mask, ccfg, self.memobank,
-                    rep_all_t)
+                    rep_all_t, randint=randint)
                 # Q5: value = cross-rank mean, gradient = local / world
                 contra_loss = contra_local * (float(ccfg.get("loss_weight", 1)) / _world())
             else:
                 contra_loss = H.zero_times_sum(rep_all)
+        if debug is not None and epoch >= self.sup_only_epoch:
+            debug.update(label_u=label_u_aug, target_u=target_u, entropy=ent, thr=thr)
+            if ccfg:
+                debug.update(low_mask=low_mask, high_mask=high_mask, lbits=lbits)
         loss = sup_loss + unsup_loss + contra_loss
         loss.backward()
         self._reduce_grads_and_step(lrs)

@@ -41,16 +41,23 @@ def test_train_step_matches_cpu_port(arch, S):
     B, C = 2, 19
     cfg = configs.cityscapes_semi(arch=arch, crop=S, batch_size=B, sync_bn=False, epochs=20)
     cfg["criterion"]["kwargs"]["min_kept"] = 4000
+    # near-uniform softmax at init: lower the anchor threshold so the InfoNCE path is exercised
+    cfg["trainer"]["contrastive"]["current_class_threshold"] = 0.055
+    torch.manual_seed(0)
     model, teacher = ModelBuilder(cfg["net"]), ModelBuilder(cfg["net"])
-    sd = formula_state_dict(model)
+    # the reference's own initialisation (kaiming / zero_init_residual; identical RNG draws, see
+    # test_oracle / models): well-conditioned gradients, unlike the closed-form test weights
+    sd = {k: v.detach().clone().contiguous() for k, v in model.state_dict().items()}
     model.load_state_dict(sd), teacher.load_state_dict(sd)
     model, teacher = model.to(DEV), teacher.to(DEV)
     for m in list(model.modules()) + list(teacher.modules()):
         if isinstance(m, nn.Dropout2d):
             m.p = 0.0
     tr = SemiTrainer(cfg, model, teacher, get_criterion(cfg), steps_per_epoch=5)
+    import copy
+    contra = copy.deepcopy(cfg["trainer"]["contrastive"])
     ref = CpuStepRef(arch=arch, num_classes=C, aux=True, epochs=20, steps_per_epoch=5, ohem=(0.7, 4000), p_drop=0.0,
-                     state_dict={k: v.clone() for k, v in sd.items()})
+                     contra=contra, state_dict={k: v.clone() for k, v in sd.items()})
     torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
     report = []
     for step in range(3):
@@ -81,11 +88,20 @@ def test_train_step_matches_cpu_port(arch, S):
             assert abs(a - b) <= tol * max(1.0, abs(b)), r
         assert r["lab_eq"] > 0.999 and r["tgt_eq"] > 0.995 and r["low_eq"] > 0.995 and r["high_eq"] > 0.995, r
     assert report[0]["keys_hip"] == report[0]["keys_ref"] or abs(report[0]["keys_hip"] - report[0]["keys_ref"]) <= 2
-    # parameters after 3 optimizer steps + EMA stay close
+    # parameters after 3 optimizer steps + EMA stay close (relative to the size of the update itself)
     sref = ref.student.state_dict()
-    for k in ["encoder.conv1.0.weight", "decoder.classifier.8.weight", "encoder.layer3.2.bn2.weight", "auxor.aux.4.bias"]:
+    worst = {}
+    for k in ["encoder.conv1.0.weight", "decoder.classifier.8.weight", "encoder.layer3.2.bn2.weight", "auxor.aux.4.bias",
+              "encoder.layer4.2.conv3.weight", "decoder.aspp.conv4.0.weight"]:
         a = dict(model.named_parameters())[k].detach().cpu()
-        assert (a - sref[k]).abs().max().item() <= 5e-3 * sref[k].abs().max().item() + 1e-5, k
+        upd = (sref[k] - sd[k]).abs().max().item()
+        err = (a - sref[k]).abs().max().item()
+        worst[k] = (err, upd)
+        print(k, "err", err, "update", upd)
     tref = ref.teacher.state_dict()
     a = dict(teacher.named_parameters())["decoder.classifier.8.weight"].detach().cpu()
-    assert (a - tref["decoder.classifier.8.weight"]).abs().max().item() <= 5e-3 * tref["decoder.classifier.8.weight"].abs().max().item() + 1e-5
+    terr = (a - tref["decoder.classifier.8.weight"]).abs().max().item()
+    print("teacher classifier.8 err", terr)
+    for k, (err, upd) in worst.items():
+        assert err <= 0.15 * upd + 1e-6, (k, err, upd)  # first-layer grads carry ~3%/step fp32 noise (see model golden: ref32 vs f64)
+    assert terr <= 0.05 * worst["decoder.classifier.8.weight"][1] + 1e-6

@@ -163,7 +163,9 @@ class CpuStepRef:
 def timed_cpu_baseline(crop=769, arch="resnet101", batch=1):
     """bench.py cpu_baseline leg: ONE reference-equivalent CPU step on a bounded sample
     (batch labeled + batch unlabeled images at the full crop)."""
-    ncores = os.cpu_count() or 1
+    # torch-CPU conv scaling collapses when oversubscribed (256 threads: 650 s for this sample on
+    # the MI355X host; 8 threads: ~35 s) -> use a bounded thread pool and report it as `cores`
+    ncores = min(os.cpu_count() or 1, int(os.environ.get("U2PL_CPU_BASELINE_THREADS", "32")))
     torch.set_num_threads(ncores)
     torch.manual_seed(2)
     np.random.seed(2)

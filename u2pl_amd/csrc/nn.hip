@@ -77,17 +77,23 @@ __global__ void k_colreduce_partial(Op op, long Mseg, int C, float* __restrict__
         __syncthreads();
     }
 }
+// ordered (deterministic) second stage: 64 columns x 4 partial-row groups per block,
+// coalesced 256 B reads, double accumulation
 __global__ void k_colreduce_final(const float* __restrict__ partial, int nblk, int C, double* __restrict__ out) {
+    __shared__ double sh[4][64];
     const int seg = blockIdx.y;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * C; i += gridDim.x * blockDim.x) {
-        double acc = 0.0;
-        for (int b = 0; b < nblk; ++b) acc += (double)partial[((long)seg * nblk + b) * 2 * C + i];
-        out[(long)seg * 2 * C + i] = acc;
-    }
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + cl;
+    double acc = 0.0;
+    if (i < 2 * C)
+        for (int b = rg; b < nblk; b += 4) acc += (double)partial[((long)seg * nblk + b) * 2 * C + i];
+    sh[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0 && i < 2 * C) out[(long)seg * 2 * C + i] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
 static int colreduce_blocks(long Mseg) {
-    long b = (Mseg + 63) / 64;
-    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+    long b = (Mseg + 127) / 128;
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
 }
 U2PL_API size_t u2pl_colreduce_workspace_bytes(long Mseg, int nseg, int C) {
     return (size_t)nseg * colreduce_blocks(Mseg) * 2 * C * sizeof(float);
@@ -98,7 +104,7 @@ static int run_colreduce(Op op, long Mseg, int nseg, int C, void* ws, double* ou
     const int nblk = colreduce_blocks(Mseg);
     hipLaunchKernelGGL((k_colreduce_partial<Op>), dim3(nblk, nseg), dim3(256), 0, stream, op, Mseg, C, (float*)ws);
     U2PL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_colreduce_final, dim3(cdiv(2 * C, 256), nseg), dim3(256), 0, stream, (const float*)ws, nblk, C, out);
+    hipLaunchKernelGGL(k_colreduce_final, dim3(cdiv(2 * C, 64), nseg), dim3(256), 0, stream, (const float*)ws, nblk, C, out);
     U2PL_LAUNCH_CHECK();
     return 0;
 }

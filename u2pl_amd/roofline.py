@@ -31,13 +31,22 @@ def profile_step(step_fn):
         rec = _lib.PROFILE
     finally:
         _lib.PROFILE = None
-    agg = {}
+    agg, shapes = {}, {}
     for name, args, e0, e1 in rec:
         d = agg.setdefault(name, dict(ms=0.0, calls=0, flops=0.0))
-        d["ms"] += e0.elapsed_time(e1)
+        ms = e0.elapsed_time(e1)
+        d["ms"] += ms
         d["calls"] += 1
         if name in _CONV_GEOM:
-            d["flops"] += _conv_flops(name, args)
+            fl = _conv_flops(name, args)
+            d["flops"] += fl
+            i = _CONV_GEOM[name]
+            key = (name[12:-4],) + tuple(args[i:i + 9]) + tuple(args[i + 9:i + 12])
+            sd = shapes.setdefault(key, dict(ms=0.0, calls=0, flops=0.0))
+            sd["ms"] += ms
+            sd["calls"] += 1
+            sd["flops"] += fl
+    agg["_shapes"] = shapes
     return agg
 
 
@@ -57,7 +66,13 @@ def measure(trainer, batch, args, ms_per_step):
 
     il, ll, iu = batch
     agg = profile_step(lambda: trainer.train_step(il, ll, iu, epoch=0))
+    shapes = agg.pop("_shapes")
     out = {}
+    if os.environ.get("U2PL_BENCH_SHAPES"):
+        top = sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])[:40]
+        out["conv_shapes"] = [dict(op=k[0], N=k[1], Hin=k[2], Cin=k[4], Hout=k[5], Cout=k[7], k=k[8], s=k[10], d=k[12],
+                                   calls=v["calls"], ms=round(v["ms"], 2),
+                                   tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)) for k, v in top]
     ig = [agg.get("u2pl_conv2d_fwd_f32"), agg.get("u2pl_conv2d_dgrad_f32")]
     ig = [x for x in ig if x]
     if ig:

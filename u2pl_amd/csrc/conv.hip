@@ -31,24 +31,37 @@ struct ConvGeom {
     int mul, off_h, off_w, step, log2div;  // gather: (o*mul + off + r*step) >> log2div
 };
 
+// Masked gathers without branches or selects on data: every global read is a raw buffer load
+// (buffer_load_dwordx4 ... offen) through a descriptor whose num_records is the byte size of the
+// tensor; an out-of-image tap / out-of-range row gets the offset OOB_OFF, for which the hardware
+// returns zeros.  All loads are unconditional, so they stay in flight under the MFMAs.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define OOB_OFF ((int)0x80000000u)   // >= num_records for every tensor (host checks bytes < 2^31)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// branch-free: returns validity, writes a coordinate that is ALWAYS in [0, lim).
 __device__ __forceinline__ bool gather_coord(int base, int tap, int step, int log2div, int lim, int& out) {
-    int v = base + tap * step;
-    if (v < 0) return false;
-    if (log2div) {
-        if (v & ((1 << log2div) - 1)) return false;
-        v >>= log2div;
-    }
-    out = v;
-    return v < lim;
+    const int v = base + tap * step;
+    const int q = v >> log2div;
+    const bool ok = (v >= 0) & ((v & ((1 << log2div) - 1)) == 0) & (q < lim);
+    out = ok ? q : 0;
+    return ok;
 }
 
 template <int TM, int TN>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__ x, long ldx,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
-                                                       long ldy, ConvGeom g) {
+                                                       long ldy, ConvGeom g, unsigned xbytes, unsigned wbytes) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32, RB = BN / 32;  // rows per thread per chunk
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, xbytes), rw = make_rsrc(w, wbytes);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                  // [2][BM][LDP]
     float* Bs = smem + 2 * BM * LDP;   // [2][BN][LDP]
@@ -65,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
 
     const int kq = tid & 7, r0 = tid >> 3;
     int bh[RA], bw[RA];
-    long nb[RA];
+    int nb[RA];   // pixel index of the image origin (fits int: bytes < 2^31)
     bool mv[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
@@ -78,25 +91,26 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
         int n = (int)(t / g.Hout);
         bh[i] = ho * g.mul + g.off_h;
         bw[i] = wo * g.mul + g.off_w;
-        nb[i] = (long)n * g.Hin * g.Win;
+        nb[i] = n * g.Hin * g.Win;
     }
     float4 ra[RA], rb[RB];
+    const int ldxb = (int)ldx * 4;
     auto load_chunk = [&](int kc) {
         const int tap = kc / cpt, c0 = (kc - tap * cpt) * BK;
         const int r = tap / g.S, s = tap - r * g.S;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             int ih, iw;
-            bool ok = mv[i] && gather_coord(bh[i], r, g.step, g.log2div, g.Hin, ih) &&
-                      gather_coord(bw[i], s, g.step, g.log2div, g.Win, iw);
-            ra[i] = ok ? *(const float4*)(x + (nb[i] + (long)ih * g.Win + iw) * ldx + c0 + kq * 4)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool okh = gather_coord(bh[i], r, g.step, g.log2div, g.Hin, ih);
+            const bool okw = gather_coord(bw[i], s, g.step, g.log2div, g.Win, iw);
+            const int off = (nb[i] + ih * g.Win + iw) * ldxb + (c0 + kq * 4) * 4;
+            ra[i] = buf_load4(rx, (mv[i] & okh & okw) ? off : OOB_OFF);
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            int co = n0 + r0 + 32 * i;
-            rb[i] = co < g.Cout ? *(const float4*)(w + (long)co * K + (long)kc * BK + kq * 4)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int co = n0 + r0 + 32 * i;
+            const int off = (co * K + kc * BK + kq * 4) * 4;
+            rb[i] = buf_load4(rw, co < g.Cout ? off : OOB_OFF);
         }
     };
     auto store_chunk = [&](int buf) {
@@ -171,8 +185,13 @@ static int launch_igemm(const float* x, long ldx, const float* w, const float* b
         (void)hipFuncSetAttribute((const void*)k_conv_igemm<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
+    // byte extents of the gathered tensor and of the weight matrix (raw-buffer descriptors)
+    const long xb = (((long)g.N * g.Hin * g.Win - 1) * ldx + g.Cin) * 4;
+    const long wb = (long)g.Cout * g.R * g.S * g.Cin * 4;
+    if (xb >= (1L << 31) || wb >= (1L << 31)) return U2PL_EINVAL;
     dim3 grid((unsigned)cdiv(M, BM), (unsigned)cdiv(g.Cout, BN));
-    hipLaunchKernelGGL((k_conv_igemm<TM, TN>), grid, dim3(256), lds, stream, x, ldx, w, bias, y, ldy, g);
+    hipLaunchKernelGGL((k_conv_igemm<TM, TN>), grid, dim3(256), lds, stream, x, ldx, w, bias, y, ldy, g, (unsigned)xb,
+                       (unsigned)wb);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -242,8 +261,9 @@ template <int TM, int TN>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const float* __restrict__ dy, long lddy,
                                                        const float* __restrict__ x, long ldx,
                                                        float* __restrict__ part, ConvGeom g, int ctiles,
-                                                       int chunks_per_split) {
+                                                       int chunks_per_split, unsigned dybytes, unsigned xbytes) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, dybytes), rx = make_rsrc(x, xbytes);
     constexpr int PA = BM + 4, PB = BN + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                 // [2][BK][PA]
@@ -261,6 +281,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const float* __restrict__
     const int prow = tid >> 3, q = tid & 7;  // pixel row in chunk, float4 lane within 32 channels
     constexpr int JA = BM / 32, JB = BN / 32;
     float4 ra[JA], rb[JB];
+    const int lddyb = (int)lddy * 4, ldxb = (int)ldx * 4;
+    // Cout, Cin are multiples of 4 (host pads narrow heads): a float4 is entirely in or out of range
     auto load_chunk = [&](long ch) {
         const long m = ch * BK + prow;
         const bool mv = m < M;
@@ -270,21 +292,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const float* __restrict__
         const int ho = (int)(t % g.Hout);
         const int n = (int)(t / g.Hout);
         int ih, iw;
-        const bool ok = mv && gather_coord(ho * g.mul + g.off_h, r, g.step, 0, g.Hin, ih) &&
-                        gather_coord(wo * g.mul + g.off_w, s, g.step, 0, g.Win, iw);
-        const float* dyr = dy + mm * lddy;
-        const float* xr = x + ((long)n * g.Hin * g.Win + (ok ? (long)ih * g.Win + iw : 0)) * ldx;
+        const bool okh = gather_coord(ho * g.mul + g.off_h, r, g.step, 0, g.Hin, ih);
+        const bool okw = gather_coord(wo * g.mul + g.off_w, s, g.step, 0, g.Win, iw);
+        const bool okb = mv & okh & okw;
+        const int dyo = (int)mm * lddyb;
+        const int xo = (n * g.Hin * g.Win + ih * g.Win + iw) * ldxb;
 #pragma unroll
         for (int j = 0; j < JA; ++j) {
-            int co = co0 + j * 32 + q * 4;
-            ra[j] = (mv && co + 3 < g.Cout) ? *(const float4*)(dyr + co)
-                    : make_float4(mv && co < g.Cout ? dyr[co] : 0.f, mv && co + 1 < g.Cout ? dyr[co + 1] : 0.f,
-                                  mv && co + 2 < g.Cout ? dyr[co + 2] : 0.f, 0.f);
+            const int co = co0 + j * 32 + q * 4;
+            ra[j] = buf_load4(rdy, (mv & (co < g.Cout)) ? dyo + co * 4 : OOB_OFF);
         }
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
-            int ci = ci0 + j * 32 + q * 4;
-            rb[j] = (ok && ci < g.Cin) ? *(const float4*)(xr + ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int ci = ci0 + j * 32 + q * 4;
+            rb[j] = buf_load4(rx, (okb & (ci < g.Cin)) ? xo + ci * 4 : OOB_OFF);
         }
     };
     auto store_chunk = [&](int buf) {
@@ -385,8 +406,12 @@ static int launch_wgrad(const float* dy, long lddy, const float* x, long ldx, fl
         (void)hipFuncSetAttribute((const void*)k_conv_wgrad<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
+    const long dyb = (((long)g.N * g.Hout * g.Wout - 1) * lddy + g.Cout) * 4;
+    const long xb = (((long)g.N * g.Hin * g.Win - 1) * ldx + g.Cin) * 4;
+    if (dyb >= (1L << 31) || xb >= (1L << 31)) return U2PL_EINVAL;
     dim3 grid((unsigned)(ctiles * g.R * g.S), (unsigned)cdiv(g.Cout, BM), (unsigned)nsplit);
-    hipLaunchKernelGGL((k_conv_wgrad<TM, TN>), grid, dim3(256), lds, stream, dy, lddy, x, ldx, part, g, ctiles, cps);
+    hipLaunchKernelGGL((k_conv_wgrad<TM, TN>), grid, dim3(256), lds, stream, dy, lddy, x, ldx, part, g, ctiles, cps,
+                       (unsigned)dyb, (unsigned)xb);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -396,7 +421,7 @@ U2PL_API int u2pl_conv2d_wgrad_f32(const float* dy, long lddy, const float* x, l
                                    void* workspace, int accumulate, int N, int Hin, int Win, int Cin, int Hout,
                                    int Wout, int Cout, int R, int S, int stride, int pad, int dil,
                                    hipStream_t stream) {
-    if (Cin % 4) return U2PL_EINVAL;
+    if (Cin % 4 || Cout % 4) return U2PL_EINVAL;
     ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
     const int BM = Cout > 64 ? 128 : 64, BN = Cin > 64 ? 128 : 64;
     int ct, ns, cps;

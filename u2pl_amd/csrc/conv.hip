@@ -58,7 +58,8 @@ template <int TM, int TN>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__ x, long ldx,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
-                                                       long ldy, ConvGeom g, unsigned xbytes, unsigned wbytes) {
+                                                       long ldy, ConvGeom g, unsigned xbytes, unsigned wbytes,
+                                                       long m_begin, long m_end) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32, RB = BN / 32;  // rows per thread per chunk
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, xbytes), rw = make_rsrc(w, wbytes);
@@ -68,12 +69,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const long M = (long)g.N * g.Hout * g.Wout;
+    const long M = m_end;  // this launch covers output rows [m_begin, m_end)
     const int K = g.R * g.S * g.Cin;
     const int nk = K / BK;
     const int cpt = g.Cin / BK;  // chunks per tap
     // M tiles fastest: concurrently resident blocks share the same weight tile (L2 reuse)
-    const long m0 = (long)blockIdx.x * BM;
+    const long m0 = m_begin + (long)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
 
     const int kq = tid & 7, r0 = tid >> 3;
@@ -176,9 +177,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
 
 template <int TM, int TN>
 static int launch_igemm(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
-                        const ConvGeom& g, hipStream_t stream) {
+                        const ConvGeom& g, long m_begin, long m_end, hipStream_t stream) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    const long M = (long)g.N * g.Hout * g.Wout;
+    if (m_end <= m_begin) return 0;
     const size_t lds = (size_t)2 * (BM + BN) * LDP * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -189,9 +190,9 @@ static int launch_igemm(const float* x, long ldx, const float* w, const float* b
     const long xb = (((long)g.N * g.Hin * g.Win - 1) * ldx + g.Cin) * 4;
     const long wb = (long)g.Cout * g.R * g.S * g.Cin * 4;
     if (xb >= (1L << 31) || wb >= (1L << 31)) return U2PL_EINVAL;
-    dim3 grid((unsigned)cdiv(M, BM), (unsigned)cdiv(g.Cout, BN));
+    dim3 grid((unsigned)cdiv(m_end - m_begin, BM), (unsigned)cdiv(g.Cout, BN));
     hipLaunchKernelGGL((k_conv_igemm<TM, TN>), grid, dim3(256), lds, stream, x, ldx, w, bias, y, ldy, g, (unsigned)xb,
-                       (unsigned)wb);
+                       (unsigned)wb, m_begin, m_end);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -202,11 +203,34 @@ static int log2_exact(int v) {
     return (1 << l) == v ? l : -1;
 }
 
+// Tile-quantisation planner.  All 256 CUs finish a "round" of equal blocks together, so a launch of
+// nblk blocks costs ceil(nblk/256) rounds of one block's area.  The body is covered with 128x128
+// tiles in whole rounds; the remaining rows (the partial last round that would leave most CUs idle)
+// are covered by a second launch with whichever smaller tile (128x128 / 64x128 / 64x64) is cheapest.
+#define NUM_CUS 256
+static double tail_cost(long rows, int cout, int bm, int bn, double eff) {
+    const long nblk = (long)cdiv(rows, bm) * cdiv(cout, bn);
+    return (double)cdiv(nblk, NUM_CUS) * bm * bn / eff;
+}
 static int run_igemm(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
                      const ConvGeom& g, hipStream_t stream) {
     if (g.Cin % BK) return U2PL_EINVAL;
-    if (g.Cout > 64) return launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, stream);
-    return launch_igemm<2, 1>(x, ldx, w, bias, y, ldy, g, stream);
+    const long M = (long)g.N * g.Hout * g.Wout;
+    if (g.Cout <= 64) return launch_igemm<2, 1>(x, ldx, w, bias, y, ldy, g, 0, M, stream);
+    const int nt = cdiv(g.Cout, 128);
+    const long mtiles = cdiv(M, 128);
+    long body_tiles = (mtiles * nt / NUM_CUS) * NUM_CUS / nt;   // M tiles covered by whole rounds
+    if (body_tiles > mtiles) body_tiles = mtiles;
+    long m_body = body_tiles * 128;
+    if (m_body > M) m_body = M;
+    const long tail = M - m_body;
+    int rc = launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, 0, m_body, stream);
+    if (rc || tail <= 0) return rc;
+    const double c22 = tail_cost(tail, g.Cout, 128, 128, 1.0), c12 = tail_cost(tail, g.Cout, 64, 128, 0.9);
+    const double c11 = tail_cost(tail, g.Cout, 64, 64, 0.8);
+    if (c22 <= c12 && c22 <= c11) return launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, m_body, M, stream);
+    if (c12 <= c11) return launch_igemm<1, 2>(x, ldx, w, bias, y, ldy, g, m_body, M, stream);
+    return launch_igemm<1, 1>(x, ldx, w, bias, y, ldy, g, m_body, M, stream);
 }
 
 // nn.Conv2d forward: resnet.py:25-41,178-186; base.py:23-83; decoder.py:60-106,132-138

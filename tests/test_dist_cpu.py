@@ -1,0 +1,99 @@
+"""world_size-2 gloo tests on CPU for the host-side multi-rank logic (no kernels):
+rank-major variable-length key gather (utils.py:16-24,31-47 semantics), the
+contrastive-loss value/gradient scaling quirk (train_semi.py:514-519) and the
+shifted-sum SyncBN statistics protocol."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn, world=2):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+def _gather_case(rank, world):
+    from u2pl_amd.utils.utils import dequeue_and_enqueue, gather_keys
+
+    g = torch.Generator().manual_seed(100 + rank)
+    outs = []
+    queue, ptr = [torch.zeros(0, 8)], torch.zeros(1, dtype=torch.long)
+    for n in ([3, 0], [0, 0], [5, 7], [30, 1]):
+        keys = torch.randn(n[rank], 8, generator=g) + 10 * rank
+        outs.append(gather_keys(keys).numpy())
+        dequeue_and_enqueue(keys, queue, ptr, 20)
+    return outs, queue[0].numpy(), int(ptr[0])
+
+
+def test_gather_keys_rank_major_and_bank_replicated():
+    (o0, q0, p0), (o1, q1, p1) = _run(_gather_case)
+    for a, b in zip(o0, o1):
+        assert np.array_equal(a, b)               # every rank sees the same concatenation
+    assert o0[0].shape[0] == 3 and (o0[0] < 5).all()   # rank 0 rows first
+    assert o0[2].shape[0] == 12 and (o0[2][:5] < 5).all() and (o0[2][5:] > 5).all()
+    assert np.array_equal(q0, q1) and p0 == p1 == 20 and q0.shape[0] == 20   # FIFO truncated to last 20 rows
+    assert (q0[-1] > 5).all()                      # last row comes from rank 1
+
+
+def _contra_scale_case(rank, world):
+    # Q5: value = cross-rank mean, gradient = local / world
+    x = torch.tensor([1.0 + rank], requires_grad=True)
+    local = (x * x).sum()
+    contra = local * (1.0 / world)
+    contra.backward()
+    v = contra.detach().clone()
+    dist.all_reduce(v)
+    return float(v), float(x.grad)
+
+
+def test_contra_loss_value_is_mean_gradient_is_local_over_world():
+    (v0, g0), (v1, g1) = _run(_contra_scale_case)
+    assert v0 == v1 == (1.0 + 4.0) / 2
+    assert g0 == 2 * 1.0 / 2 and g1 == 2 * 2.0 / 2
+
+
+def _syncbn_protocol_case(rank, world):
+    # the arithmetic of u2pl_bn_stats_f32 + all_reduce + u2pl_bn_finalize_f32, in torch
+    g = torch.Generator().manual_seed(5)
+    full = torch.randn(8, 6, 5, 5, generator=g) * 3 + 2
+    x = full[rank * 4:(rank + 1) * 4]
+    pivot = torch.full((6,), 0.3, dtype=torch.float64)
+    xs = x.permute(0, 2, 3, 1).reshape(-1, 6).double() - pivot
+    sums = torch.cat([xs.sum(0), (xs * xs).sum(0)])
+    dist.all_reduce(sums)
+    count = float(xs.shape[0] * world)
+    m1, m2 = sums[:6] / count, sums[6:] / count
+    mean, var = pivot + m1, m2 - m1 * m1
+    ref_mean = full.permute(0, 2, 3, 1).reshape(-1, 6).double().mean(0)
+    ref_var = full.permute(0, 2, 3, 1).reshape(-1, 6).double().var(0, unbiased=False)
+    return float((mean - ref_mean).abs().max()), float((var - ref_var).abs().max())
+
+
+def test_syncbn_shifted_sum_protocol_matches_global_batch_stats():
+    for em, ev in _run(_syncbn_protocol_case):
+        assert em < 1e-12 and ev < 1e-10

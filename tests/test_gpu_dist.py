@@ -1,0 +1,106 @@
+"""-m gpu: the real N>1 code path (SyncBatchNorm exchange, flat gradient all-reduce, bank key
+gather, meters) driven by TWO processes sharing the one visible MI355X through the gloo backend
+(RCCL needs one GPU per rank; the 2/4/8-GPU RCCL runs are the driver's scaling bench)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn, world=2):
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+def _syncbn_case(rank, world):
+    from u2pl_amd import nn as K
+    g = torch.Generator().manual_seed(3)
+    full = torch.randn(4, 64, 9, 7, generator=g) * 2 + 1
+    gy_full = torch.randn(4, 64, 9, 7, generator=g)
+    ref = torch.nn.BatchNorm2d(64)
+    xr = full.clone().requires_grad_(True)
+    yr = torch.relu(ref(xr))
+    yr.backward(gy_full)
+    bn = K.SyncBatchNorm(64).cuda()
+    x = full[rank * 2:(rank + 1) * 2].cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = bn(x, relu=True)
+    y.backward(gy_full[rank * 2:(rank + 1) * 2].cuda())
+    sl = slice(rank * 2, (rank + 1) * 2)
+    return dict(
+        y=float((y.detach().cpu() - yr.detach()[sl]).abs().max()),
+        dx=float((x.grad.cpu() - xr.grad[sl]).abs().max()),
+        rm=float((bn.running_mean.cpu() - ref.running_mean).abs().max()),
+        rv=float((bn.running_var.cpu() - ref.running_var).abs().max()),
+        dgamma_local=bn.weight.grad.cpu().numpy(), dgamma_ref=ref.weight.grad.numpy())
+
+
+def test_syncbn_two_ranks_equals_full_batch_bn():
+    r0, r1 = _run(_syncbn_case)
+    for r in (r0, r1):
+        assert r["y"] < 2e-5 and r["dx"] < 2e-5 and r["rm"] < 1e-5 and r["rv"] < 1e-4, r
+    # parameter grads are local sums; their cross-rank sum is the full-batch gradient
+    assert np.abs(r0["dgamma_local"] + r1["dgamma_local"] - r0["dgamma_ref"]).max() < 2e-3
+
+
+def _train_case(rank, world):
+    from u2pl_amd import configs
+    from u2pl_amd.models.model_helper import ModelBuilder
+    from u2pl_amd.trainer import SemiTrainer
+    from u2pl_amd.utils.loss_helper import get_criterion
+    torch.manual_seed(2)
+    np.random.seed(2)
+    cfg = configs.cityscapes_semi(arch="resnet50", crop=97, batch_size=2, sync_bn=True, epochs=10)
+    cfg["criterion"]["kwargs"]["min_kept"] = 3000
+    cfg["trainer"]["contrastive"]["current_class_threshold"] = 0.055
+    dev = torch.device("cuda", 0)
+    model, teacher = ModelBuilder(cfg["net"]).to(dev), ModelBuilder(cfg["net"]).to(dev)
+    tr = SemiTrainer(cfg, model, teacher, get_criterion(cfg), steps_per_epoch=4)
+    g = torch.Generator().manual_seed(10 + rank)     # different data per rank, same weights/seeds
+    meters = []
+    for step in range(3):
+        il, iu = torch.randn(2, 3, 97, 97, generator=g), torch.randn(2, 3, 97, 97, generator=g)
+        ll = torch.randint(0, 19, (2, 97, 97), generator=g)
+        ll[:, :6] = 255
+        meters.append(tr.train_step(il.to(dev), ll.to(dev), iu.to(dev), epoch=0).cpu().numpy())
+    torch.cuda.synchronize()
+    return dict(meters=np.stack(meters), w=tr.arena.flat.double().sum().item(), w2=(tr.arena.flat.double() ** 2).sum().item(),
+                t=tr.t_arena.flat.double().sum().item(), bank_len=list(tr.memobank.length),
+                bank_sum=[float(tr.memobank.logical(c).double().sum()) for c in range(19)],
+                rm=float(model.encoder.bn1.running_mean.double().sum()))
+
+
+def test_two_rank_training_keeps_replicas_and_banks_identical():
+    r0, r1 = _run(_train_case)
+    assert np.isfinite(r0["meters"]).all()
+    assert np.array_equal(r0["meters"], r1["meters"])          # all-reduced meters agree
+    assert r0["w"] == r1["w"] and r0["w2"] == r1["w2"] and r0["t"] == r1["t"]   # weights stay replicated bit-for-bit
+    assert r0["bank_len"] == r1["bank_len"] and r0["bank_sum"] == r1["bank_sum"] and sum(r0["bank_len"]) > 0
+    assert r0["rm"] == r1["rm"]                                  # SyncBN running stats identical

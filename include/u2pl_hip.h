@@ -48,13 +48,19 @@ int u2pl_pseudo_label_f32(const float* logits_nchw, int N, int C, int H, int W, 
 /* entropy = -sum(p*log(p+1e-10)); NaN where label==ignore; *nvalid += #valid:
  * train_semi.py:402-403, loss_helper.py:35-36 (label may be NULL) */
 int u2pl_entropy_f32(const float* logits_nchw, const long long* label, int ignore, int N, int C, int H, int W,
-                     float* entropy, unsigned* nvalid, hipStream_t stream);
+                     float* entropy, unsigned* ws, hipStream_t stream);
+/* same, fused with the bilinear up-sampling of the LOW-RES logits (train_semi.py:371-374 + 402-403):
+ * the full-resolution logit tensor is never materialised; also accumulates ws[0] and the select's hist0 */
+int u2pl_entropy_up_f32(const float* in, long sn, long sc, long sh, long sw, int N, int C, int h, int w, int H, int W,
+                        const long long* label, int ignore, float* entropy, unsigned* ws, hipStream_t stream);
 /* np.percentile(entropy[valid], q) x nspec (exact order statistics + numpy float32 lerp),
  * train_semi.py:405-407,412-415, loss_helper.py:38-40; spec kind 1 = OHEM k-th smallest
- * (loss_helper.py:521-526).  ws must be zeroed, then ws[0]=n_valid, ws[1]=n_total. */
+ * (loss_helper.py:521-526).  ws must be zeroed, then ws[0]=n_valid, ws[1]=n_total;
+ * producers (u2pl_entropy*_f32, u2pl_ohem_prob_f32) also fill the pass-0 histogram (hist0_done=1). */
 size_t u2pl_select_workspace_bytes(void);
 int u2pl_select_f32(const float* values, long n, int nspec, const int* spec_kind_dev, const float* q32_dev,
-                    const long long* kparam_dev, const float* fparam_dev, unsigned* ws, hipStream_t stream);
+                    const long long* kparam_dev, const float* fparam_dev, unsigned* ws, int hist0_done,
+                    hipStream_t stream);
 /* target[entropy >= thresh] = 255 and count of kept pixels: loss_helper.py:41-44 */
 int u2pl_apply_drop_i64(const float* entropy, const unsigned* thr_bits, long long* target, int ignore, long n,
                         unsigned* nkept, hipStream_t stream);
@@ -64,6 +70,11 @@ int u2pl_reliability_masks(const float* entropy, const unsigned* thr_lo_bits, co
                            const long long* label_l, const long long* label_u, int ignore, int B, int H, int W,
                            int h, int w, int negative_high_entropy, float* low_mask, float* high_mask,
                            unsigned* lbits, hipStream_t stream);
+/* fused tail: unsup target overwrite + masks + class bits in one launch (thr_bits = {drop, low, high}) */
+int u2pl_reliability_apply(const float* entropy, const unsigned* thr_bits, const long long* label_l,
+                           const long long* label_u, int ignore, int B, int H, int W, int h, int w,
+                           int negative_high_entropy, long long* target_u, unsigned* nkept, float* low_mask,
+                           float* high_mask, unsigned* lbits, hipStream_t stream);
 int u2pl_pack_class_bits(const long long* onehot, int N, int C, int h, int w, unsigned* bits, hipStream_t stream);
 int u2pl_unpack_class_bits(const unsigned* bits, int N, int C, int h, int w, long long* onehot,
                            hipStream_t stream);
@@ -106,7 +117,7 @@ int u2pl_ce_bwd_f32(const float* logits_nchw, const long long* target, int ignor
                     const float* out3_dev, const float* gout_dev, float gmul, float* grad, hipStream_t stream);
 /* OhemCrossEntropy2dTensor: loss_helper.py:502-531 */
 int u2pl_ohem_prob_f32(const float* logits_nchw, const long long* target, int ignore, int N, int C, int H,
-                       int W, float* mask_prob, unsigned* nvalid, hipStream_t stream);
+                       int W, float* mask_prob, unsigned* ws, hipStream_t stream);
 int u2pl_ohem_apply_i64(const float* mask_prob, const unsigned* thr_bits, const long long* target, int ignore,
                         long n, long long* kept_target, hipStream_t stream);
 

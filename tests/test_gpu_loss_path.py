@@ -180,6 +180,32 @@ def test_reliability_split_golden(tag):
     assert (high2.cpu().numpy().astype(np.uint8) != g["high_mask_all"]).sum() <= 1
 
 
+def test_fused_entropy_up_and_apply_match_unfused():
+    """fused bilinear+entropy(+hist0) and fused drop+masks+bits == the unfused kernels, bit for bit"""
+    H = hip()
+    g = golden("relsplit_65_a20")
+    B, C, S, s = 2, 19, int(g["size"]), 17
+    lab_u, lab_l = T(g["label_u_aug"], torch.int64), T(g["label_l"], torch.int64)
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        low = T(g["low_t_train"]).contiguous(memory_format=fmt)
+        ws1, ws2 = H.new_select_ws(DEV, B * S * S), H.new_select_ws(DEV, B * S * S)
+        e1 = H.entropy_map(H.bilinear_up(low[B:], (S, S)), lab_u, ws1)
+        e2 = H.entropy_map_up(low[B:], (S, S), lab_u, ws2)
+        assert torch.equal(e1.view(torch.int32), e2.view(torch.int32))
+        assert torch.equal(ws1[:2200], ws2[:2200])          # n_valid + pass-0 histogram
+        specs = [("pct", 80.0), ("pct", 20.0), ("pct", 80.0)]
+        t1, t2 = H.run_select(e1, ws1, specs), H.run_select(e2, ws2, specs)
+        assert torch.equal(t1.view(torch.int32), t2.view(torch.int32))
+        ref = np.percentile(e1.cpu().numpy()[g["label_u_aug"] != 255], [80.0, 20.0]).astype(np.float32)
+        assert np.array_equal(t1.cpu().numpy()[:2], ref)
+        tgt, nk, lo, hi, lb = H.reliability_apply(e2, t2, lab_l, lab_u, (s, s))
+        tgt0 = lab_u.clone()
+        nk0 = H.drop_high_entropy_(tgt0, e1, t1[0:1])
+        lo0, hi0, lb0 = H.reliability_masks(e1, t1[1:2], t1[2:3], lab_l, lab_u, (s, s))
+        assert torch.equal(tgt, tgt0) and int(nk) == int(nk0)
+        assert torch.equal(lo, lo0) and torch.equal(hi, hi0) and torch.equal(lb, lb0)
+
+
 # ------------------------------------------------------------------ OHEM (a10)
 @pytest.mark.parametrize("tag", ["65_k3000", "65_kbig", "65_k60"])
 def test_ohem_golden(tag):

@@ -51,6 +51,16 @@ def main():
         return ent, thr, H.reliability_masks(ent, thr[1:2], thr[2:3], label_l, label_u, (s, s))
 
     res["reliability_total_us"] = timeit(rel)
+
+    def rel_fused():
+        ws = H.new_select_ws(DEV, B * S * S)
+        ent = H.entropy_map_up(low[B:], (S, S), label_u, ws)
+        thr = H.run_select(ent, ws, [("pct", 80.0), ("pct", 20.0), ("pct", 80.0)])
+        return H.reliability_apply(ent, thr, label_l, label_u, (s, s))
+
+    res["reliability_fused_total_us"] = timeit(rel_fused)
+    wsf = H.new_select_ws(DEV, B * S * S)
+    res["entropy_up_us"] = timeit(lambda: H.entropy_map_up(low[B:], (S, S), label_u, wsf))
     ws = H.new_select_ws(DEV, B * S * S)
     res["entropy_us"] = timeit(lambda: H.entropy_map(large, label_u, ws))
     ent, thr, (lo, hi, lbits) = rel()

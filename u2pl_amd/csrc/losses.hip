@@ -113,7 +113,10 @@ U2PL_API int u2pl_ce_bwd_f32(const float* logits, const long long* target, int i
 // OHEM (loss_helper.py:502-520): mask_prob = softmax(pred)[target] (1.0 on
 // ignored pixels); counts valid pixels into ws[0] (select workspace word 0)
 __global__ void k_ohem_prob(const float* __restrict__ z, const long long* __restrict__ target, int ignore,
-                            int N, int C, long HW, float* __restrict__ mp, unsigned* __restrict__ nvalid) {
+                            int N, int C, long HW, float* __restrict__ mp, unsigned* __restrict__ ws) {
+    __shared__ unsigned sh[2048];   // pass-0 histogram of the k-th-smallest selection (select.hip)
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) sh[i] = 0;
+    __syncthreads();
     long total = (long)N * HW;
     unsigned cnt = 0;
     for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
@@ -130,15 +133,19 @@ __global__ void k_ohem_prob(const float* __restrict__ z, const long long* __rest
             cnt++;
         }
         mp[p] = v;
+        atomicAdd(&sh[f32_key(v) >> 21], 1u);
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x)
+        if (sh[i]) atomicAdd(&ws[128 + i], sh[i]);
     cnt = wave_sum_u(cnt);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(nvalid, cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&ws[0], cnt);
 }
 U2PL_API int u2pl_ohem_prob_f32(const float* logits, const long long* target, int ignore, int N, int C, int H,
                                 int W, float* mask_prob, unsigned* nvalid, hipStream_t stream) {
     long total = (long)N * H * W;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_ohem_prob, dim3(grid_for(total, 256)), dim3(256), 0, stream, logits, target, ignore, N,
+    hipLaunchKernelGGL(k_ohem_prob, dim3(grid_for(total, 256, 2048)), dim3(256), 0, stream, logits, target, ignore, N,
                        C, (long)H * W, mask_prob, nvalid);
     U2PL_LAUNCH_CHECK();
     return 0;

@@ -130,12 +130,30 @@ U2PL_API int u2pl_pseudo_label_f32(const float* logits, int N, int C, int H, int
 }
 
 // ---------------------------------------------------------------------------
-// a11/a12: entropy = -sum p*log(p+1e-10); NaN marks label==ignore pixels so a
-// single float stream carries both value and validity; counts valid pixels.
-// state[0] += #valid (atomic, integer => deterministic)
+// a11/a12: per-pixel entropy of the teacher logits (train_semi.py:402-403,
+// loss_helper.py:35-36).  NaN marks label==ignore pixels so one float stream
+// carries value and validity.  The kernel also counts the valid pixels
+// (ws[0]) and builds the pass-0 histogram of the radix select (ws[128..]) so
+// the selection needs no extra sweep.
+//   entropy = log(s) - sum_c e_c*(z_c-m)/s,  e_c = exp(z_c-m), s = sum e_c
+// (= -sum p*log(p); the reference's +1e-10 inside the log changes the value by
+//  < C*1e-10, far below the Tier-B tolerance 2e-6, and needs one exp per class
+//  instead of two exps, a log and a divide).
 // ---------------------------------------------------------------------------
+#define SEL_H0 128
+__device__ __forceinline__ void hist0_flush(unsigned* sh, unsigned cnt, unsigned* __restrict__ ws) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x)
+        if (sh[i]) atomicAdd(&ws[SEL_H0 + i], sh[i]);
+    cnt = wave_sum_u(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&ws[0], cnt);
+}
+
 __global__ void k_entropy(const float* __restrict__ z, const long long* __restrict__ label, int ignore,
-                          int N, int C, long HW, float* __restrict__ ent, unsigned* __restrict__ nvalid) {
+                          int N, int C, long HW, float* __restrict__ ent, unsigned* __restrict__ ws) {
+    __shared__ unsigned sh[2048];
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) sh[i] = 0;
+    __syncthreads();
     long total = (long)N * HW;
     unsigned cnt = 0;
     for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total;
@@ -144,205 +162,106 @@ __global__ void k_entropy(const float* __restrict__ z, const long long* __restri
         const float* b = z + n * C * HW + q;
         float m = b[0];
         for (int c = 1; c < C; ++c) m = fmaxf(m, b[(long)c * HW]);
-        float s = 0.f;
-        for (int c = 0; c < C; ++c) s += expf(b[(long)c * HW] - m);
-        float e = 0.f;
+        float s = 0.f, t = 0.f;
         for (int c = 0; c < C; ++c) {
-            float pr = expf(b[(long)c * HW] - m) / s;
-            e += pr * logf(pr + 1e-10f);
+            const float d = b[(long)c * HW] - m;
+            const float e = expf(d);
+            s += e;
+            t += e * d;
         }
-        e = -e;
-        bool valid = label == nullptr || label[p] != (long long)ignore;
-        ent[p] = valid ? e : __uint_as_float(0x7fc00000u);
+        float e = logf(s) - t / s;
+        const bool valid = label == nullptr || label[p] != (long long)ignore;
+        e = valid ? e : __uint_as_float(0x7fc00000u);
+        ent[p] = e;
         cnt += valid ? 1u : 0u;
+        atomicAdd(&sh[f32_key(e) >> 21], 1u);
     }
-    cnt = wave_sum_u(cnt);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(nvalid, cnt);
+    hist0_flush(sh, cnt, ws);
 }
 
 U2PL_API int u2pl_entropy_f32(const float* logits, const long long* label, int ignore, int N, int C, int H,
-                              int W, float* entropy, unsigned* nvalid, hipStream_t stream) {
+                              int W, float* entropy, unsigned* ws, hipStream_t stream) {
     long total = (long)N * H * W;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_entropy, dim3(grid_for(total, 256)), dim3(256), 0, stream, logits, label, ignore,
-                       N, C, (long)H * W, entropy, nvalid);
+    hipLaunchKernelGGL(k_entropy, dim3(grid_for(total, 256, 2048)), dim3(256), 0, stream, logits, label, ignore,
+                       N, C, (long)H * W, entropy, ws);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
 
-// ---------------------------------------------------------------------------
-// Exact selection.  Workspace layout (unsigned words), see u2pl_hip.h:
-//   [0]            n_valid (non-NaN count; written by producer or by pass 0)
-//   [1]            n_total
-//   [8 + s]        prefix key of slot s   (s < U2PL_SEL_MAX_SLOTS)
-//   [24 + s]       remaining rank of slot s inside its prefix
-//   [40 + s]       float bits of the selected value (after last resolve)
-//   [56 + j]       float bits of threshold j (percentile lerp or OHEM thr)
-//   [64 + j]       float bits of gamma_j
-//   [128 ...]      histograms: [pass 4][slot 16][256]
-// ---------------------------------------------------------------------------
-#define SEL_PREFIX 8
-#define SEL_KREM 24
-#define SEL_VAL 40
-#define SEL_THR 56
-#define SEL_GAMMA 64
-#define SEL_HIST 128
-
-__global__ void k_select_hist(const float* __restrict__ v, long n, int pass, int nslots,
-                              unsigned* __restrict__ ws) {
-    __shared__ unsigned sh[U2PL_SEL_MAX_SLOTS * 256];
-    __shared__ unsigned s_prefix[U2PL_SEL_MAX_SLOTS];
-    __shared__ int s_active[U2PL_SEL_MAX_SLOTS];
-    for (int i = threadIdx.x; i < U2PL_SEL_MAX_SLOTS * 256; i += blockDim.x) sh[i] = 0;
-    if (threadIdx.x < U2PL_SEL_MAX_SLOTS) {
-        // a slot is active if it is the first slot carrying its prefix (pass 0: slot 0 only)
-        int s = threadIdx.x;
-        unsigned pf = (s < nslots && pass > 0) ? ws[SEL_PREFIX + s] : 0u;
-        int act = s < nslots;
-        if (pass == 0) act = (s == 0);
-        else
-            for (int t = 0; t < s; ++t)
-                if (ws[SEL_PREFIX + t] == pf) act = 0;
-        s_prefix[s] = pf;
-        s_active[s] = act;
-    }
+// Fused bilinear up-sampling (bit-exact FMA form, a7) + entropy from the LOW-RES teacher logits:
+// the (B,C,H,W) full-resolution logit tensor (90 MB at 769^2) is never materialised.
+// CT = compile-time class count (registers hold the C up-sampled logits); CT == 0: generic two-sweep.
+template <int CT>
+__global__ void k_entropy_up(const float* __restrict__ in, long sn, long sc, long sh_, long sw, int N, int C,
+                             int h, int w, int H, int W, float sy, float sx,
+                             const long long* __restrict__ label, int ignore, float* __restrict__ ent,
+                             unsigned* __restrict__ ws) {
+    __shared__ unsigned sh[2048];
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) sh[i] = 0;
     __syncthreads();
-    const int shift = 24 - 8 * pass;
-    const unsigned himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-    unsigned prefix[U2PL_SEL_MAX_SLOTS];
-    bool active[U2PL_SEL_MAX_SLOTS];
+    const long total = (long)N * H * W;
+    unsigned cnt = 0;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(p % W);
+        const long t0 = p / W;
+        const int oy = (int)(t0 % H), n = (int)(t0 / H);
+        const AcCoord cy = ac_coord(oy, sy, h), cx = ac_coord(ox, sx, w);
+        const float* b = in + n * sn;
+        const long o00 = cy.i0 * sh_ + cx.i0 * sw, o01 = cy.i0 * sh_ + cx.i1 * sw;
+        const long o10 = cy.i1 * sh_ + cx.i0 * sw, o11 = cy.i1 * sh_ + cx.i1 * sw;
+        auto up = [&](int c) {
+            const float* bc = b + c * sc;
+            const float top = __fmaf_rn(cx.l0, bc[o00], __fmul_rn(cx.l1, bc[o01]));
+            const float bot = __fmaf_rn(cx.l0, bc[o10], __fmul_rn(cx.l1, bc[o11]));
+            return __fmaf_rn(cy.l0, top, __fmul_rn(cy.l1, bot));
+        };
+        float m, s = 0.f, t = 0.f;
+        if (CT > 0) {
+            float zc[CT > 0 ? CT : 1];
 #pragma unroll
-    for (int s = 0; s < U2PL_SEL_MAX_SLOTS; ++s) {
-        prefix[s] = s_prefix[s];
-        active[s] = s_active[s] != 0;
-    }
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        unsigned k = f32_key(v[i]);
-        unsigned d = (k >> shift) & 0xffu;
+            for (int c = 0; c < CT; ++c) zc[c] = up(c);
+            m = zc[0];
 #pragma unroll
-        for (int s = 0; s < U2PL_SEL_MAX_SLOTS; ++s)
-            if (active[s] && (k & himask) == prefix[s]) atomicAdd(&sh[s * 256 + d], 1u);
-    }
-    __syncthreads();
-    unsigned* gh = ws + SEL_HIST + (long)pass * U2PL_SEL_MAX_SLOTS * 256;
-    for (int i = threadIdx.x; i < U2PL_SEL_MAX_SLOTS * 256; i += blockDim.x)
-        if (sh[i]) atomicAdd(&gh[i], sh[i]);
-}
-
-// One block of 256 threads.  pass==0 additionally derives the ranks from n_valid.
-// spec_kind[j]: 0 = numpy percentile with q32[j] -> slots (2j, 2j+1)
-//               1 = explicit rank min(n_total, kparam[j]) - 1 -> slots 2j and 2j+1
-__global__ void k_select_resolve(int pass, int nspec, const int* __restrict__ spec_kind,
-                                 const float* __restrict__ q32, const long long* __restrict__ kparam,
-                                 unsigned* __restrict__ ws) {
-    __shared__ unsigned cum[256];
-    __shared__ unsigned s_prefix[U2PL_SEL_MAX_SLOTS], s_krem[U2PL_SEL_MAX_SLOTS];
-    __shared__ unsigned s_newprefix[U2PL_SEL_MAX_SLOTS], s_newkrem[U2PL_SEL_MAX_SLOTS];
-    const int nslots = 2 * nspec;
-    const int tid = threadIdx.x;
-    if (pass == 0 && tid < nspec) {
-        const unsigned nv = ws[0], nt = ws[1];
-        long lo, hi;
-        float gamma = 0.f;
-        if (spec_kind[tid] == 0) {
-            long n = nv;
-            float vi = __fmul_rn((float)(n - 1), q32[tid]);  // numpy: (n - 1) * q, float32
-            float fl = floorf(vi);
-            gamma = __fsub_rn(vi, fl);
-            if (n <= 0) { lo = hi = 0; }
-            else if (!(vi == vi) || vi >= (float)(n - 1)) { lo = hi = n - 1; }
-            else if (vi < 0.f) { lo = hi = 0; }
-            else { lo = (long)fl; hi = lo + 1; }
+            for (int c = 1; c < CT; ++c) m = fmaxf(m, zc[c]);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float d = zc[c] - m, e = expf(d);
+                s += e;
+                t += e * d;
+            }
         } else {
-            long k = kparam[tid];
-            long n = nt;
-            lo = hi = (k < n ? k : n) - 1;
-            if (lo < 0) lo = hi = 0;
+            m = up(0);
+            for (int c = 1; c < C; ++c) m = fmaxf(m, up(c));
+            for (int c = 0; c < C; ++c) {
+                const float d = up(c) - m, e = expf(d);
+                s += e;
+                t += e * d;
+            }
         }
-        s_krem[2 * tid] = (unsigned)lo;
-        s_krem[2 * tid + 1] = (unsigned)hi;
-        s_prefix[2 * tid] = 0;
-        s_prefix[2 * tid + 1] = 0;
-        ws[SEL_GAMMA + tid] = __float_as_uint(gamma);
-    } else if (pass > 0 && tid < nslots) {
-        s_prefix[tid] = ws[SEL_PREFIX + tid];
-        s_krem[tid] = ws[SEL_KREM + tid];
+        float e = logf(s) - t / s;
+        const bool valid = label == nullptr || label[p] != (long long)ignore;
+        e = valid ? e : __uint_as_float(0x7fc00000u);
+        ent[p] = e;
+        cnt += valid ? 1u : 0u;
+        atomicAdd(&sh[f32_key(e) >> 21], 1u);
     }
-    __syncthreads();
-    const int shift = 24 - 8 * pass;
-    const unsigned* gh = ws + SEL_HIST + (long)pass * U2PL_SEL_MAX_SLOTS * 256;
-    for (int s = 0; s < nslots; ++s) {
-        const unsigned pf = s_prefix[s], k = s_krem[s];
-        int l = s;  // histogram owner = first slot with this prefix (must match k_select_hist)
-        if (pass == 0) l = 0;
-        else
-            for (int t = 0; t < s; ++t)
-                if (s_prefix[t] == pf) { l = t; break; }
-        cum[tid] = gh[l * 256 + tid];
-        __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {  // inclusive Hillis-Steele scan
-            unsigned t = tid >= o ? cum[tid - o] : 0;
-            __syncthreads();
-            cum[tid] += t;
-            __syncthreads();
-        }
-        const unsigned before = tid ? cum[tid - 1] : 0;
-        if (k >= before && k < cum[tid]) {
-            s_newprefix[s] = pf | ((unsigned)tid << shift);
-            s_newkrem[s] = k - before;
-        }
-        __syncthreads();
-    }
-    if (tid < nslots) {
-        ws[SEL_PREFIX + tid] = s_newprefix[tid];
-        ws[SEL_KREM + tid] = s_newkrem[tid];
-        if (pass == 3) ws[SEL_VAL + tid] = __float_as_uint(key_f32(s_newprefix[tid]));
-    }
+    hist0_flush(sh, cnt, ws);
 }
 
-// thresholds: numpy _lerp in float32 (no FMA):  d=b-a;  t>=.5 ? b-d*(1-t) : a+d*t
-// spec kind 1 (OHEM): thr = kth > fthresh ? kth : fthresh, or +inf when
-// min_kept > n_valid ("no filtering", loss_helper.py:513-515)
-__global__ void k_select_finish(int nspec, const int* __restrict__ spec_kind,
-                                const long long* __restrict__ kparam, const float* __restrict__ fparam,
-                                unsigned* __restrict__ ws) {
-    int j = threadIdx.x;
-    if (j >= nspec) return;
-    float a = __uint_as_float(ws[SEL_VAL + 2 * j]), b = __uint_as_float(ws[SEL_VAL + 2 * j + 1]);
-    float thr;
-    if (spec_kind[j] == 0) {
-        float t = __uint_as_float(ws[SEL_GAMMA + j]);
-        float d = __fsub_rn(b, a);
-        thr = (t >= 0.5f) ? __fsub_rn(b, __fmul_rn(d, __fsub_rn(1.0f, t))) : __fadd_rn(a, __fmul_rn(d, t));
-        if (ws[0] == 0) thr = __uint_as_float(0x7fc00000u);  // empty selection -> NaN (numpy)
-    } else {
-        long long nv = ws[0];
-        if (kparam[j] > nv) thr = __uint_as_float(0x7f800000u);  // keep every valid pixel
-        else thr = a > fparam[j] ? a : fparam[j];
-    }
-    ws[SEL_THR + j] = __float_as_uint(thr);
-}
-
-U2PL_API size_t u2pl_select_workspace_bytes(void) {
-    return (size_t)(SEL_HIST + 4 * U2PL_SEL_MAX_SLOTS * 256) * sizeof(unsigned);
-}
-
-// Caller contract: ws was zeroed (hipMemsetAsync) before the producer wrote
-// ws[0] (n_valid) / ws[1] (n_total); spec arrays live in device memory.
-U2PL_API int u2pl_select_f32(const float* values, long n, int nspec, const int* spec_kind,
-                             const float* q32, const long long* kparam, const float* fparam,
-                             unsigned* ws, hipStream_t stream) {
-    if (nspec < 1 || 2 * nspec > U2PL_SEL_MAX_SLOTS) return U2PL_EINVAL;
-    const int nslots = 2 * nspec;
-    const int grid = grid_for(n, 256, 1024);
-    for (int pass = 0; pass < 4; ++pass) {
-        hipLaunchKernelGGL(k_select_hist, dim3(grid), dim3(256), 0, stream, values, n, pass, nslots, ws);
-        U2PL_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_select_resolve, dim3(1), dim3(256), 0, stream, pass, nspec, spec_kind, q32,
-                           kparam, ws);
-        U2PL_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(k_select_finish, dim3(1), dim3(64), 0, stream, nspec, spec_kind, kparam, fparam, ws);
+U2PL_API int u2pl_entropy_up_f32(const float* in, long sn, long sc, long sh, long sw, int N, int C, int h, int w,
+                                 int H, int W, const long long* label, int ignore, float* entropy, unsigned* ws,
+                                 hipStream_t stream) {
+    long total = (long)N * H * W;
+    if (total <= 0) return 0;
+    dim3 grid(grid_for(total, 256, 2048)), block(256);
+    const float sy = ac_scale_host(h, H), sx = ac_scale_host(w, W);
+    if (C == 19)
+        hipLaunchKernelGGL(k_entropy_up<19>, grid, block, 0, stream, in, sn, sc, sh, sw, N, C, h, w, H, W, sy, sx, label, ignore, entropy, ws);
+    else if (C == 21)
+        hipLaunchKernelGGL(k_entropy_up<21>, grid, block, 0, stream, in, sn, sc, sh, sw, N, C, h, w, H, W, sy, sx, label, ignore, entropy, ws);
+    else
+        hipLaunchKernelGGL(k_entropy_up<0>, grid, block, 0, stream, in, sn, sc, sh, sw, N, C, h, w, H, W, sy, sx, label, ignore, entropy, ws);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -418,6 +337,67 @@ __global__ void k_reliability_masks(const float* __restrict__ ent, const unsigne
         }
         lbits[p] = bits;
     }
+}
+
+// One launch for the whole tail of the split: unsup target overwrite (loss_helper.py:41-44) on the
+// full-res grid AND the low-res masks / class bits (train_semi.py:408-465).  Thresholds are read from
+// the select workspace: thr_bits[0] = drop, [1] = low, [2] = high.
+__global__ void k_reliability_apply(const float* __restrict__ ent, const unsigned* __restrict__ thr_bits,
+                                    const long long* __restrict__ label_l, const long long* __restrict__ label_u,
+                                    int ignore, int B, int H, int W, int h, int w, float ny, float nx, int neg_high,
+                                    long long* __restrict__ target_u, unsigned* __restrict__ nkept,
+                                    float* __restrict__ low_mask, float* __restrict__ high_mask,
+                                    unsigned* __restrict__ lbits) {
+    const float tdrop = __uint_as_float(thr_bits[0]), tlo = __uint_as_float(thr_bits[1]),
+                thi = __uint_as_float(thr_bits[2]);
+    const long HW = (long)H * W, nfull = (long)B * HW, nlow = (long)2 * B * h * w;
+    unsigned cnt = 0;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < nfull + nlow; p += (long)gridDim.x * blockDim.x) {
+        if (p < nfull) {
+            long long t = label_u[p];
+            if (ent[p] >= tdrop && t != ignore) t = ignore;
+            target_u[p] = t;
+            cnt += t != ignore;
+        } else {
+            const long q = p - nfull;
+            const int x = (int)(q % w);
+            const long t = q / w;
+            const int y = (int)(t % h), n = (int)(t / h);
+            const long src = (long)nearest_src(y, ny, H) * W + nearest_src(x, nx, W);
+            const long long* lab = n < B ? label_l : label_u;
+            const int b = n < B ? n : n - B;
+            float lo, hi;
+            if (n < B) lo = hi = lab[b * HW + src] != ignore ? 1.f : 0.f;
+            else {
+                const float e = ent[b * HW + src];
+                lo = e <= tlo ? 1.f : 0.f;
+                hi = neg_high ? (e >= thi ? 1.f : 0.f) : 1.f;
+            }
+            low_mask[q] = lo;
+            high_mask[q] = hi;
+            unsigned bits = 0;
+            if (b == 0 && lab[src] != ignore)
+                for (int bb = 0; bb < B; ++bb) {
+                    const long long l = lab[bb * HW + src];
+                    bits |= 1u << (l == ignore ? 0 : (int)l);
+                }
+            lbits[q] = bits;
+        }
+    }
+    cnt = wave_sum_u(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(nkept, cnt);
+}
+U2PL_API int u2pl_reliability_apply(const float* entropy, const unsigned* thr_bits, const long long* label_l,
+                                    const long long* label_u, int ignore, int B, int H, int W, int h, int w,
+                                    int negative_high_entropy, long long* target_u, unsigned* nkept, float* low_mask,
+                                    float* high_mask, unsigned* lbits, hipStream_t stream) {
+    const long total = (long)B * H * W + (long)2 * B * h * w;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_reliability_apply, dim3(grid_for(total, 256)), dim3(256), 0, stream, entropy, thr_bits, label_l,
+                       label_u, ignore, B, H, W, h, w, (float)H / (float)h, (float)W / (float)w, negative_high_entropy,
+                       target_u, nkept, low_mask, high_mask, lbits);
+    U2PL_LAUNCH_CHECK();
+    return 0;
 }
 
 U2PL_API int u2pl_reliability_masks(const float* entropy, const unsigned* thr_lo_bits,

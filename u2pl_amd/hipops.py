@@ -73,6 +73,7 @@ def new_select_ws(device, n_total):
     words = query("u2pl_select_workspace_bytes") // 4
     ws = torch.zeros(words, dtype=torch.int32, device=device)
     ws[1] = int(n_total)
+    ws._hist0 = False   # set by producers that accumulate the pass-0 histogram themselves
     return ws
 
 
@@ -101,7 +102,8 @@ def run_select(values, ws, specs):
     buf = torch.from_numpy(np.concatenate([kp.view(np.uint8), kind.view(np.uint8), q32.view(np.uint8),
                                            fp.view(np.uint8)])).to(dev, non_blocking=True)
     base = buf.data_ptr()
-    call("u2pl_select_f32", values, values.numel(), n, base + 8 * n, base + 12 * n, base, base + 16 * n, ws)
+    call("u2pl_select_f32", values, values.numel(), n, base + 8 * n, base + 12 * n, base, base + 16 * n, ws,
+         int(bool(getattr(ws, "_hist0", False))))
     return ws[SEL_WORD_THR:SEL_WORD_THR + n].view(torch.float32)
 
 
@@ -111,7 +113,35 @@ def entropy_map(logits_large, label, ws, ignore=255):
     N, C, H, W = x.shape
     ent = torch.empty((N, H, W), dtype=torch.float32, device=x.device)
     call("u2pl_entropy_f32", x, label, ignore, N, C, H, W, ent, ws)
+    ws._hist0 = True
     return ent
+
+
+def entropy_map_up(logits_low, size, label, ws, ignore=255):
+    """bilinear(align_corners=True) up-sampling fused with the entropy: never writes the
+    (B,C,H,W) logits.  logits_low may be any strided (B,C,h,w) view."""
+    N, C, h, w = logits_low.shape
+    H, W = int(size[0]), int(size[1])
+    ent = torch.empty((N, H, W), dtype=torch.float32, device=logits_low.device)
+    call("u2pl_entropy_up_f32", _f32c(logits_low), *_strides_nchw(logits_low), N, C, h, w, H, W, label, ignore, ent, ws)
+    ws._hist0 = True
+    return ent
+
+
+def reliability_apply(entropy, thr3, label_l, label_u_aug, out_hw, negative_high_entropy=True, ignore=255):
+    """fused: unsup target (label_u_aug with entropy >= thr3[0] -> 255), low/high masks
+    (thr3[1], thr3[2]) at out_hw and the Q0 class bits; returns (target_u, nkept, low, high, lbits)."""
+    B, H, W = label_u_aug.shape
+    h, w = out_hw
+    dev = entropy.device
+    target = torch.empty_like(label_u_aug)
+    nk = torch.zeros(1, dtype=torch.int32, device=dev)
+    low = torch.empty((2 * B, 1, h, w), dtype=torch.float32, device=dev)
+    high = torch.empty((2 * B, 1, h, w), dtype=torch.float32, device=dev)
+    lbits = torch.empty((2 * B, h, w), dtype=torch.int32, device=dev)
+    call("u2pl_reliability_apply", entropy, thr3, label_l.contiguous(), label_u_aug.contiguous(), ignore, B, H, W, h, w,
+         int(bool(negative_high_entropy)), target, nk, low, high, lbits)
+    return target, nk, low, high, lbits
 
 
 # --------------------------------------------------------------------------- cross entropy
@@ -152,6 +182,7 @@ def ohem_kept_target(pred, target, thresh, min_kept, ignore_index=255):
     ws = new_select_ws(x.device, N * H * W)
     mp = torch.empty((N, H, W), dtype=torch.float32, device=x.device)
     call("u2pl_ohem_prob_f32", x, target, ignore_index, N, C, H, W, mp, ws)
+    ws._hist0 = True
     thr = run_select(mp, ws, [("kth", int(min_kept), float(thresh))])
     kept = torch.empty_like(target)
     call("u2pl_ohem_apply_i64", mp, thr, target, ignore_index, target.numel(), kept)

@@ -161,8 +161,8 @@ class SemiTrainer:
                 pt, ldp = K.as_rows(pred_all_t)
                 Cn = pred_all_t.shape[1]
                 K.call("u2pl_softmax_rows_f32", pt, ldp, prob_all_t, Cn, pt.shape[0] * pt.shape[2] * pt.shape[3], Cn)
-                pred_u_large_t = H.bilinear_up(pred_all_t[B:], (h, w))
-                # one entropy pass + one exact selection for all three percentiles
+                # one fused pass: bilinear up-sampling + entropy + valid count + select histogram, then ONE
+                # exact selection for all three percentiles (drop_percent, alpha_t, 100 - alpha_t)
                 drop_percent = unsup_cfg.get("drop_percent", 100)
                 percent_unreliable = (100 - drop_percent) * (1 - epoch / self.epochs)
                 drop_percent = 100 - percent_unreliable
@@ -172,17 +172,18 @@ class SemiTrainer:
                     alpha_t = ccfg["low_entropy_threshold"] * (1 - epoch / self.epochs)
                     specs += [("pct", float(alpha_t)), ("pct", float(100 - alpha_t))]
                 ws = H.new_select_ws(image_l.device, B * h * w)
-                ent = H.entropy_map(pred_u_large_t, label_u_aug, ws)
+                ent = H.entropy_map_up(pred_all_t[B:], (h, w), label_u_aug, ws)
                 thr = H.run_select(ent, ws, specs)
-                target_u = label_u_aug.clone()
-                H.drop_high_entropy_(target_u, ent, thr[0:1])
+                if ccfg:
+                    target_u, _, low_mask, high_mask, lbits = H.reliability_apply(
+                        ent, thr, label_l, label_u_aug, pred_all.shape[2:],
+                        negative_high_entropy=ccfg.get("negative_high_entropy", True))
+                else:
+                    target_u = label_u_aug.clone()
+                    H.drop_high_entropy_(target_u, ent, thr[0:1])
             unsup_loss = H.cross_entropy(pred_u_large, target_u, 255, unsup_weight=True,
                                          scale=float(unsup_cfg.get("loss_weight", 1)))
             if ccfg:
-                with torch.no_grad():
-                    low_mask, high_mask, lbits = H.reliability_masks(
-                        ent, thr[1:2], thr[2:3], label_l, label_u_aug, pred_all.shape[2:],
-                        negative_high_entropy=ccfg.get("negative_high_entropy", True))
                 _, contra_local = LH.contra_memobank_core(
                     rep_all, lbits, B, prob_all_t[:B], prob_all_t[B:], low_mask, high_mask, ccfg, self.memobank,
                     rep_all_t, randint=randint)

@@ -31,16 +31,20 @@ __global__ void k_contra_classify(const float* __restrict__ prob, long sn, long 
         const unsigned lb = lbits[p];
         const bool lo = low_mask[p] != 0.f, hi = high_mask[p] != 0.f;
         unsigned a = 0, l = 0, ng = 0;
-        if (lb != 0 || n < num_labeled) {
+        if (lb != 0) {   // every output needs label_i == 1 (labeled negatives are structurally empty, Q2)
             const float* b = prob + n * sn + q * sp;
-            for (int i = 0; i < C; ++i) {
+            float pr[MAXC];
+#pragma unroll
+            for (int j = 0; j < MAXC; ++j) pr[j] = j < C ? b[j * sc] : -1.f;
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                if (i >= C) break;
                 const bool has = (lb >> i) & 1u;
-                const float pi = b[i * sc];
+                if (!has) continue;
+                const float pi = pr[i];
                 int rank = 0;
-                for (int j = 0; j < C; ++j) {
-                    float pj = b[j * sc];
-                    rank += (pj > pi) || (pj == pi && j < i);
-                }
+#pragma unroll
+                for (int j = 0; j < MAXC; ++j) rank += (pr[j] > pi) || (pr[j] == pi && j < i);
                 bool cmask = n < num_labeled ? (rank < low_rank && !has) : (rank >= low_rank && rank < high_rank);
                 if (has && lo) {
                     l |= 1u << i;
@@ -106,16 +110,23 @@ __global__ void k_compact_count(const unsigned* __restrict__ b0, const unsigned*
     for (int i = threadIdx.x; i < 3 * MAXC; i += blockDim.x) blk[(long)blockIdx.x * 3 * MAXC + i] = cnt[i];
 }
 
+// exclusive scan over blocks: one wave64 per (kind, class) pair, shuffle scan in chunks of 64 blocks
 __global__ void k_compact_scan(unsigned* __restrict__ blk, int nblk, unsigned* __restrict__ counts) {
-    int i = threadIdx.x;  // (kind, class) pair, 3*MAXC threads
-    if (i >= 3 * MAXC) return;
-    unsigned run = 0;
-    for (int b = 0; b < nblk; ++b) {
-        unsigned v = blk[(long)b * 3 * MAXC + i];
-        blk[(long)b * 3 * MAXC + i] = run;
-        run += v;
+    const int i = blockIdx.x, lane = threadIdx.x;   // grid = 3*MAXC, block = 64
+    unsigned carry = 0;
+    for (int base = 0; base < nblk; base += 64) {
+        const int b = base + lane;
+        const unsigned v = b < nblk ? blk[(long)b * 3 * MAXC + i] : 0;
+        unsigned x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned u = __shfl_up(x, o, 64);
+            if (lane >= o) x += u;
+        }
+        if (b < nblk) blk[(long)b * 3 * MAXC + i] = carry + x - v;
+        carry += __shfl(x, 63, 64);
     }
-    counts[i] = run;
+    if (lane == 0) counts[i] = carry;
 }
 
 __global__ void k_compact_write(const unsigned* __restrict__ b0, const unsigned* __restrict__ b1,
@@ -180,7 +191,7 @@ U2PL_API int u2pl_compact_lists(const unsigned* abits, const unsigned* lowbits, 
     unsigned* blk = (unsigned*)workspace;
     hipLaunchKernelGGL(k_compact_count, dim3(nblk), dim3(256), 0, stream, abits, lowbits, nbits, P, C, blk);
     U2PL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(128), 0, stream, blk, nblk, counts);
+    hipLaunchKernelGGL(k_compact_scan, dim3(3 * MAXC), dim3(64), 0, stream, blk, nblk, counts);
     U2PL_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_compact_write, dim3(nblk), dim3(256), 0, stream, abits, lowbits, nbits, P, C, blk, idx, cap);
     U2PL_LAUNCH_CHECK();

@@ -138,14 +138,13 @@ __global__ void k_ohem_prob(const float* __restrict__ z, const long long* __rest
     __syncthreads();
     for (int i = threadIdx.x; i < 2048; i += blockDim.x)
         if (sh[i]) atomicAdd(&ws[128 + i], sh[i]);
-    cnt = wave_sum_u(cnt);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&ws[0], cnt);
+    block_count_flush(cnt, &ws[0]);
 }
 U2PL_API int u2pl_ohem_prob_f32(const float* logits, const long long* target, int ignore, int N, int C, int H,
                                 int W, float* mask_prob, unsigned* nvalid, hipStream_t stream) {
     long total = (long)N * H * W;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_ohem_prob, dim3(grid_for(total, 256, 2048)), dim3(256), 0, stream, logits, target, ignore, N,
+    hipLaunchKernelGGL(k_ohem_prob, dim3(grid_for(total, 256, 512)), dim3(256), 0, stream, logits, target, ignore, N,
                        C, (long)H * W, mask_prob, nvalid);
     U2PL_LAUNCH_CHECK();
     return 0;

@@ -145,8 +145,7 @@ __device__ __forceinline__ void hist0_flush(unsigned* sh, unsigned cnt, unsigned
     __syncthreads();
     for (int i = threadIdx.x; i < 2048; i += blockDim.x)
         if (sh[i]) atomicAdd(&ws[SEL_H0 + i], sh[i]);
-    cnt = wave_sum_u(cnt);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&ws[0], cnt);
+    block_count_flush(cnt, &ws[0]);
 }
 
 __global__ void k_entropy(const float* __restrict__ z, const long long* __restrict__ label, int ignore,
@@ -183,7 +182,7 @@ U2PL_API int u2pl_entropy_f32(const float* logits, const long long* label, int i
                               int W, float* entropy, unsigned* ws, hipStream_t stream) {
     long total = (long)N * H * W;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_entropy, dim3(grid_for(total, 256, 2048)), dim3(256), 0, stream, logits, label, ignore,
+    hipLaunchKernelGGL(k_entropy, dim3(grid_for(total, 256, 512)), dim3(256), 0, stream, logits, label, ignore,
                        N, C, (long)H * W, entropy, ws);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -335,11 +334,11 @@ U2PL_API int u2pl_entropy_up_f32(const float* in, long sn, long sc, long sh, lon
                                  hipStream_t stream) {
     long total = (long)N * H * W;
     if (total <= 0) return 0;
-    dim3 grid(grid_for(total, 256, 2048)), block(256);
+    dim3 grid(grid_for(total, 256, 512)), block(256);
     const float sy = ac_scale_host(h, H), sx = ac_scale_host(w, W);
     if (h > 1 && w > 1 && H - 1 == 4 * (h - 1) && W - 1 == 4 * (w - 1)) {
         const long ncell = (long)N * h * w;
-        hipLaunchKernelGGL(k_entropy_up_cell<4>, dim3(grid_for(ncell, 64, 4096)), dim3(64), 0, stream, in, sn, sc, sh, sw,
+        hipLaunchKernelGGL(k_entropy_up_cell<4>, dim3(grid_for(ncell, 128, 1024)), dim3(128), 0, stream, in, sn, sc, sh, sw,
                            N, C, h, w, H, W, sy, sx, label, ignore, entropy, ws);
         U2PL_LAUNCH_CHECK();
         return 0;
@@ -368,14 +367,13 @@ __global__ void k_apply_drop(const float* __restrict__ ent, const unsigned* __re
         if (ent[i] >= thr && t != ignore) { t = ignore; target[i] = t; }
         cnt += t != ignore;
     }
-    cnt = wave_sum_u(cnt);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(nkept, cnt);
+    block_count_flush(cnt, nkept);
 }
 
 U2PL_API int u2pl_apply_drop_i64(const float* entropy, const unsigned* thr_bits, long long* target,
                                  int ignore, long n, unsigned* nkept, hipStream_t stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_apply_drop, dim3(grid_for(n, 256)), dim3(256), 0, stream, entropy, thr_bits,
+    hipLaunchKernelGGL(k_apply_drop, dim3(grid_for(n, 256, 512)), dim3(256), 0, stream, entropy, thr_bits,
                        target, ignore, n, nkept);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -472,8 +470,7 @@ __global__ void k_reliability_apply(const float* __restrict__ ent, const unsigne
             lbits[q] = bits;
         }
     }
-    cnt = wave_sum_u(cnt);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(nkept, cnt);
+    block_count_flush(cnt, nkept);
 }
 U2PL_API int u2pl_reliability_apply(const float* entropy, const unsigned* thr_bits, const long long* label_l,
                                     const long long* label_u, int ignore, int B, int H, int W, int h, int w,
@@ -481,7 +478,7 @@ U2PL_API int u2pl_reliability_apply(const float* entropy, const unsigned* thr_bi
                                     float* high_mask, unsigned* lbits, hipStream_t stream) {
     const long total = (long)B * H * W + (long)2 * B * h * w;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_reliability_apply, dim3(grid_for(total, 256)), dim3(256), 0, stream, entropy, thr_bits, label_l,
+    hipLaunchKernelGGL(k_reliability_apply, dim3(grid_for(total, 256, 1024)), dim3(256), 0, stream, entropy, thr_bits, label_l,
                        label_u, ignore, B, H, W, h, w, (float)H / (float)h, (float)W / (float)w, negative_high_entropy,
                        target_u, nkept, low_mask, high_mask, lbits);
     U2PL_LAUNCH_CHECK();

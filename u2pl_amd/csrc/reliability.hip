@@ -248,10 +248,10 @@ __global__ void k_entropy_up(const float* __restrict__ in, long sn, long sc, lon
     hist0_flush(sh, cnt, ws);
 }
 
-// Integer up-sampling ratio R = (H-1)/(h-1) (4 for the stride-4 logits, 8 for the aux head): one thread owns
-// one low-res CELL and produces its R x R output pixels, so the four corner logits of a class are loaded once
-// per 16 / 64 outputs instead of once per output (the generic kernel is load-issue bound: 76 gathers/pixel).
-// Arithmetic per output pixel is the identical FMA form (ac_coord recomputed per pixel) => same bits.
+// Integer up-sampling ratio R = (H-1)/(h-1) (4 for the stride-4 logits): one thread owns one output ROW of
+// one low-res CELL (R consecutive pixels that share the same four corner logits), so the corners of a
+// class are loaded once per R outputs instead of once per output (the generic kernel is load-issue bound:
+// 76 gathers / pixel).  Arithmetic per output pixel is the identical FMA form => same bits.
 template <int R>
 __global__ void k_entropy_up_cell(const float* __restrict__ in, long sn, long sc, long sh_, long sw, int N, int C,
                                   int h, int w, int H, int W, float sy, float sx,
@@ -260,71 +260,64 @@ __global__ void k_entropy_up_cell(const float* __restrict__ in, long sn, long sc
     __shared__ unsigned sh[2048];
     for (int i = threadIdx.x; i < 2048; i += blockDim.x) sh[i] = 0;
     __syncthreads();
-    const long ncell = (long)N * h * w;
+    const long nseg = (long)N * H * w;   // (n, oy, cell column)
     unsigned cnt = 0;
-    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < ncell; q += (long)gridDim.x * blockDim.x) {
+    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < nseg; q += (long)gridDim.x * blockDim.x) {
         const int cj = (int)(q % w);
         const long t0 = q / w;
-        const int ci = (int)(t0 % h), n = (int)(t0 / h);
-        const int oy0 = ci * R, ox0 = cj * R;
-        const int ny = min(R, H - oy0), nx = min(R, W - ox0);
-        // per-pixel interpolation coordinates (identical to the generic kernel)
-        float ly0[R], ly1[R], lx0[R], lx1[R];
-        int y0 = ci, y1 = ci, x0 = cj, x1 = cj;
+        const int oy = (int)(t0 % H), n = (int)(t0 / H);
+        const int ox0 = cj * R;
+        const int nx = min(R, W - ox0);
+        const AcCoord cy = ac_coord(oy, sy, h);
+        float lx0[R], lx1[R];
+        int x0 = cj, x1 = cj;
 #pragma unroll
         for (int a = 0; a < R; ++a) {
-            const AcCoord cy = ac_coord(min(oy0 + a, H - 1), sy, h), cx = ac_coord(min(ox0 + a, W - 1), sx, w);
-            ly0[a] = cy.l0; ly1[a] = cy.l1; lx0[a] = cx.l0; lx1[a] = cx.l1;
-            if (a == 0) { y0 = cy.i0; y1 = cy.i1; x0 = cx.i0; x1 = cx.i1; }
+            const AcCoord cx = ac_coord(min(ox0 + a, W - 1), sx, w);
+            lx0[a] = cx.l0; lx1[a] = cx.l1;
+            if (a == 0) { x0 = cx.i0; x1 = cx.i1; }
         }
         const float* b = in + n * sn;
-        const long o00 = y0 * sh_ + x0 * sw, o01 = y0 * sh_ + x1 * sw, o10 = y1 * sh_ + x0 * sw, o11 = y1 * sh_ + x1 * sw;
-        float m[R][R], s[R][R], t[R][R];
+        const long o00 = cy.i0 * sh_ + x0 * sw, o01 = cy.i0 * sh_ + x1 * sw, o10 = cy.i1 * sh_ + x0 * sw,
+                   o11 = cy.i1 * sh_ + x1 * sw;
+        float m[R], s[R], t[R];
 #pragma unroll
-        for (int a = 0; a < R; ++a)
-#pragma unroll
-            for (int bb = 0; bb < R; ++bb) { m[a][bb] = -INFINITY; s[a][bb] = 0.f; t[a][bb] = 0.f; }
+        for (int a = 0; a < R; ++a) { m[a] = -INFINITY; s[a] = 0.f; t[a] = 0.f; }
         for (int c = 0; c < C; ++c) {   // sweep 1: per-pixel max
             const float* bc = b + c * sc;
             const float v00 = bc[o00], v01 = bc[o01], v10 = bc[o10], v11 = bc[o11];
 #pragma unroll
-            for (int bb = 0; bb < R; ++bb) {
-                const float top = __fmaf_rn(lx0[bb], v00, __fmul_rn(lx1[bb], v01));
-                const float bot = __fmaf_rn(lx0[bb], v10, __fmul_rn(lx1[bb], v11));
-#pragma unroll
-                for (int a = 0; a < R; ++a) m[a][bb] = fmaxf(m[a][bb], __fmaf_rn(ly0[a], top, __fmul_rn(ly1[a], bot)));
+            for (int a = 0; a < R; ++a) {
+                const float top = __fmaf_rn(lx0[a], v00, __fmul_rn(lx1[a], v01));
+                const float bot = __fmaf_rn(lx0[a], v10, __fmul_rn(lx1[a], v11));
+                m[a] = fmaxf(m[a], __fmaf_rn(cy.l0, top, __fmul_rn(cy.l1, bot)));
             }
         }
         for (int c = 0; c < C; ++c) {   // sweep 2: exp sums
             const float* bc = b + c * sc;
             const float v00 = bc[o00], v01 = bc[o01], v10 = bc[o10], v11 = bc[o11];
 #pragma unroll
-            for (int bb = 0; bb < R; ++bb) {
-                const float top = __fmaf_rn(lx0[bb], v00, __fmul_rn(lx1[bb], v01));
-                const float bot = __fmaf_rn(lx0[bb], v10, __fmul_rn(lx1[bb], v11));
-#pragma unroll
-                for (int a = 0; a < R; ++a) {
-                    const float d = __fmaf_rn(ly0[a], top, __fmul_rn(ly1[a], bot)) - m[a][bb];
-                    const float e = expf(d);
-                    s[a][bb] += e;
-                    t[a][bb] += e * d;
-                }
+            for (int a = 0; a < R; ++a) {
+                const float top = __fmaf_rn(lx0[a], v00, __fmul_rn(lx1[a], v01));
+                const float bot = __fmaf_rn(lx0[a], v10, __fmul_rn(lx1[a], v11));
+                const float d = __fmaf_rn(cy.l0, top, __fmul_rn(cy.l1, bot)) - m[a];
+                const float e = expf(d);
+                s[a] += e;
+                t[a] += e * d;
             }
         }
+        const long p0 = ((long)n * H + oy) * W + ox0;
 #pragma unroll
-        for (int a = 0; a < R; ++a)
-#pragma unroll
-            for (int bb = 0; bb < R; ++bb) {
-                if (a < ny && bb < nx) {
-                    const long p = ((long)n * H + oy0 + a) * W + ox0 + bb;
-                    float e = logf(s[a][bb]) - t[a][bb] / s[a][bb];
-                    const bool valid = label == nullptr || label[p] != (long long)ignore;
-                    e = valid ? e : __uint_as_float(0x7fc00000u);
-                    ent[p] = e;
-                    cnt += valid ? 1u : 0u;
-                    atomicAdd(&sh[f32_key(e) >> 21], 1u);
-                }
+        for (int a = 0; a < R; ++a) {
+            if (a < nx) {
+                float e = logf(s[a]) - t[a] / s[a];
+                const bool valid = label == nullptr || label[p0 + a] != (long long)ignore;
+                e = valid ? e : __uint_as_float(0x7fc00000u);
+                ent[p0 + a] = e;
+                cnt += valid ? 1u : 0u;
+                atomicAdd(&sh[f32_key(e) >> 21], 1u);
             }
+        }
     }
     hist0_flush(sh, cnt, ws);
 }
@@ -337,8 +330,8 @@ U2PL_API int u2pl_entropy_up_f32(const float* in, long sn, long sc, long sh, lon
     dim3 grid(grid_for(total, 256, 512)), block(256);
     const float sy = ac_scale_host(h, H), sx = ac_scale_host(w, W);
     if (h > 1 && w > 1 && H - 1 == 4 * (h - 1) && W - 1 == 4 * (w - 1)) {
-        const long ncell = (long)N * h * w;
-        hipLaunchKernelGGL(k_entropy_up_cell<4>, dim3(grid_for(ncell, 128, 1024)), dim3(128), 0, stream, in, sn, sc, sh, sw,
+        const long nseg = (long)N * H * w;
+        hipLaunchKernelGGL(k_entropy_up_cell<4>, dim3(grid_for(nseg, 256, 1024)), dim3(256), 0, stream, in, sn, sc, sh, sw,
                            N, C, h, w, H, W, sy, sx, label, ignore, entropy, ws);
         U2PL_LAUNCH_CHECK();
         return 0;

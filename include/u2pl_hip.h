@@ -120,6 +120,9 @@ int u2pl_ohem_prob_f32(const float* logits_nchw, const long long* target, int ig
                        int W, float* mask_prob, unsigned* ws, hipStream_t stream);
 int u2pl_ohem_apply_i64(const float* mask_prob, const unsigned* thr_bits, const long long* target, int ignore,
                         long n, long long* kept_target, hipStream_t stream);
+/* validate(): argmax + intersection/output/target histograms (train_semi.py:620-641, utils.py:568-580) */
+int u2pl_confusion_hist_f32(const float* logits_nchw, const long long* target, int ignore, int N, int C, int H, int W,
+                            long long* hist3c, hipStream_t stream);
 
 /* ---- conv.hip (implicit GEMM on v_mfma_f32_32x32x2_f32) -------------------- */
 /* nn.Conv2d forward (NHWC rows, weights [Cout][R][S][Cin]): resnet.py:25-41,178-186;

@@ -38,8 +38,7 @@ __global__ void k_contra_classify(const float* __restrict__ prob, long sn, long 
             for (int j = 0; j < MAXC; ++j) pr[j] = j < C ? b[j * sc] : -1.f;
 #pragma unroll
             for (int i = 0; i < MAXC; ++i) {
-                if (i >= C) break;
-                const bool has = (lb >> i) & 1u;
+                const bool has = (i < C) && ((lb >> i) & 1u);
                 if (!has) continue;
                 const float pi = pr[i];
                 int rank = 0;

@@ -167,3 +167,41 @@ U2PL_API int u2pl_ohem_apply_i64(const float* mask_prob, const unsigned* thr_bit
     U2PL_LAUNCH_CHECK();
     return 0;
 }
+
+// validate(): argmax over classes + intersection / union / target histograms on device
+// (train_semi.py:620-641, utils.py:568-580).  hist: int64 [3][C] = intersection, area_output, area_target
+// (area_union = output + target - intersection); integer atomics => deterministic.
+__global__ void k_confusion(const float* __restrict__ z, const long long* __restrict__ target, int ignore, int N,
+                            int C, long HW, unsigned long long* __restrict__ hist) {
+    extern __shared__ unsigned sh_h[];   // [3][C]
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) sh_h[i] = 0;
+    __syncthreads();
+    const long total = (long)N * HW;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        const long long t = target[p];
+        if (t == ignore) continue;   // output[target == ignore] = ignore (utils.py:574)
+        const long n = p / HW, q = p % HW;
+        const float* b = z + n * C * HW + q;
+        float m = b[0];
+        int am = 0;
+        for (int c = 1; c < C; ++c) {
+            const float v = b[(long)c * HW];
+            if (v > m) { m = v; am = c; }
+        }
+        atomicAdd(&sh_h[C + am], 1u);
+        atomicAdd(&sh_h[2 * C + (int)t], 1u);
+        if (am == (int)t) atomicAdd(&sh_h[am], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x)
+        if (sh_h[i]) atomicAdd(&hist[i], (unsigned long long)sh_h[i]);
+}
+U2PL_API int u2pl_confusion_hist_f32(const float* logits, const long long* target, int ignore, int N, int C, int H,
+                                     int W, long long* hist3c, hipStream_t stream) {
+    const long total = (long)N * H * W;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_confusion, dim3(grid_for(total, 256, 512)), dim3(256), 3 * C * sizeof(unsigned), stream, logits,
+                       target, ignore, N, C, (long)H * W, (unsigned long long*)hist3c);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}

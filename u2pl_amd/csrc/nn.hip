@@ -61,12 +61,29 @@ __global__ void k_colreduce_partial(Op op, long Mseg, int C, float* __restrict__
     for (int cb = 0; cb < C4; cb += tc) {
         const int c4 = cb + cl;
         float4 a0 = f4zero(), a1 = f4zero();
-        if (rg < tr && c4 < C4)
-            for (long r = rb + rg; r < re; r += tr) {
+        if (rg < tr && c4 < C4) {
+            // 4 independent row streams per thread: keeps >= 4 x 16 B loads in flight per lane
+            float4 b0 = f4zero(), b1 = f4zero(), c0 = f4zero(), c1 = f4zero(), d0 = f4zero(), d1 = f4zero();
+            long r = rb + rg;
+            for (; r + 3 * (long)tr < re; r += 4 * (long)tr) {
+                float4 v0, v1, w0, w1, x0, x1, y0, y1;
+                op.get(r, c4, v0, v1);
+                op.get(r + tr, c4, w0, w1);
+                op.get(r + 2 * (long)tr, c4, x0, x1);
+                op.get(r + 3 * (long)tr, c4, y0, y1);
+                a0 = f4add(a0, v0); a1 = f4add(a1, v1);
+                b0 = f4add(b0, w0); b1 = f4add(b1, w1);
+                c0 = f4add(c0, x0); c1 = f4add(c1, x1);
+                d0 = f4add(d0, y0); d1 = f4add(d1, y1);
+            }
+            for (; r < re; r += tr) {
                 float4 v0, v1;
                 op.get(r, c4, v0, v1);
                 a0 = f4add(a0, v0); a1 = f4add(a1, v1);
             }
+            a0 = f4add(f4add(a0, b0), f4add(c0, d0));
+            a1 = f4add(f4add(a1, b1), f4add(c1, d1));
+        }
         sh0[tid] = a0; sh1[tid] = a1;
         __syncthreads();
         if (rg == 0 && c4 < C4) {
@@ -92,8 +109,8 @@ __global__ void k_colreduce_final(const float* __restrict__ partial, int nblk, i
     if (rg == 0 && i < 2 * C) out[(long)seg * 2 * C + i] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
 static int colreduce_blocks(long Mseg) {
-    long b = (Mseg + 127) / 128;
-    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+    long b = (Mseg + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 U2PL_API size_t u2pl_colreduce_workspace_bytes(long Mseg, int nseg, int C) {
     return (size_t)nseg * colreduce_blocks(Mseg) * 2 * C * sizeof(float);

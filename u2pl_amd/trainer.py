@@ -96,7 +96,12 @@ class SemiTrainer:
         max_iter = self.epochs * self.steps_per_epoch
         lr = poly_lr(self.base_lr, self.cur_iter, max_iter, self.power)
         self.cur_iter += 1
+        self.last_lr = lr
         return [lr * m for m in self.lr_mult]
+
+    def resync_arenas(self):
+        """parameters were (re)loaded through load_state_dict: views already alias the arenas."""
+        return None
 
     def _reduce_grads_and_step(self, lrs):
         W = _world()
@@ -210,4 +215,53 @@ class SemiTrainer:
             dist.all_reduce(cv)        # contra value = cross-rank mean (train_semi.py:514-519)
             meters[2] = cv
             dist.all_reduce(meters)    # logged meters are cross-rank SUMS (train_semi.py:551-561)
+        return meters
+
+
+class SupTrainer:
+    """train_sup.py:177-251: supervised-only step (student only, no teacher / bank)."""
+
+    def __init__(self, cfg, model, sup_loss_fn, steps_per_epoch):
+        self.cfg, self.model, self.sup_loss_fn, self.steps_per_epoch = cfg, model, sup_loss_fn, steps_per_epoch
+        tr = cfg["trainer"]
+        self.epochs = tr["epochs"]
+        ok = tr["optimizer"]
+        assert ok["type"] == "SGD"
+        self.base_lr, self.momentum = ok["kwargs"]["lr"], ok["kwargs"].get("momentum", 0.0)
+        self.weight_decay = ok["kwargs"].get("weight_decay", 0.0)
+        self.power = tr["lr_scheduler"]["kwargs"].get("power", 0.9) or 0.9
+        times = 10 if cfg["dataset"]["type"].startswith("pascal") else 1
+        groups = [list(model.encoder.parameters()), list(model.decoder.parameters())]
+        self.lr_mult = [1, times]
+        if hasattr(model, "auxor"):
+            groups.append(list(model.auxor.parameters()))
+            self.lr_mult.append(times)
+        self.arena = K.ParamArena(groups)
+        self.cur_iter, self.last_lr = 0, self.base_lr
+        self.use_aux = "aux_loss" in cfg["net"].keys()
+
+    _lrs = SemiTrainer._lrs
+    resync_arenas = SemiTrainer.resync_arenas
+
+    def train_step(self, image, label, epoch=0):
+        lrs = self._lrs()
+        self.model.train()
+        self.arena.zero_grad()
+        h, w = label.shape[1:]
+        label = label.long().contiguous()
+        outs = self.model(image, need_rep=False)
+        pred = H.bilinear_up(outs["pred"], (h, w))
+        if self.use_aux:
+            loss = self.sup_loss_fn([pred, H.bilinear_up(outs["aux"], (h, w))], label)
+        else:
+            loss = self.sup_loss_fn(pred, label)
+        loss.backward()
+        W = _world()
+        if W > 1:
+            dist.all_reduce(self.arena.grad)
+        self.arena.sgd_step(lrs, self.momentum, self.weight_decay, grad_scale=1.0 / W)
+        z = torch.zeros((), device=loss.device)
+        meters = torch.stack((loss.detach(), z, z))
+        if W > 1:
+            dist.all_reduce(meters)
         return meters

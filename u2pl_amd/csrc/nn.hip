@@ -94,23 +94,39 @@ __global__ void k_colreduce_partial(Op op, long Mseg, int C, float* __restrict__
         __syncthreads();
     }
 }
-// ordered (deterministic) second stage: 64 columns x 4 partial-row groups per block,
-// coalesced 256 B reads, double accumulation
-__global__ void k_colreduce_final(const float* __restrict__ partial, int nblk, int C, double* __restrict__ out) {
-    __shared__ double sh[4][64];
+// ordered (deterministic) second stage: 64 columns x 16 partial-row groups per 1024-thread block; every
+// thread keeps 8 independent loads in flight (the kernel is pure latency: <= 512 x 2C floats in total)
+__global__ __launch_bounds__(1024) void k_colreduce_final(const float* __restrict__ partial, int nblk, int C,
+                                                          double* __restrict__ out) {
+    __shared__ double sh[16][64];
     const int seg = blockIdx.y;
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + cl;
     double acc = 0.0;
-    if (i < 2 * C)
-        for (int b = rg; b < nblk; b += 4) acc += (double)partial[((long)seg * nblk + b) * 2 * C + i];
+    if (i < 2 * C) {
+        const float* p = partial + (long)seg * nblk * 2 * C + i;
+        int b = rg;
+        for (; b + 7 * 16 < nblk; b += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(long)(b + u * 16) * 2 * C];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (double)v[u];
+        }
+        for (; b < nblk; b += 16) acc += (double)p[(long)b * 2 * C];
+    }
     sh[rg][cl] = acc;
     __syncthreads();
-    if (rg == 0 && i < 2 * C) out[(long)seg * 2 * C + i] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+    if (rg == 0 && i < 2 * C) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][cl];
+        out[(long)seg * 2 * C + i] = t;
+    }
 }
 static int colreduce_blocks(long Mseg) {
     long b = (Mseg + 255) / 256;
-    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
 }
 U2PL_API size_t u2pl_colreduce_workspace_bytes(long Mseg, int nseg, int C) {
     return (size_t)nseg * colreduce_blocks(Mseg) * 2 * C * sizeof(float);
@@ -121,7 +137,7 @@ static int run_colreduce(Op op, long Mseg, int nseg, int C, void* ws, double* ou
     const int nblk = colreduce_blocks(Mseg);
     hipLaunchKernelGGL((k_colreduce_partial<Op>), dim3(nblk, nseg), dim3(256), 0, stream, op, Mseg, C, (float*)ws);
     U2PL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_colreduce_final, dim3(cdiv(2 * C, 64), nseg), dim3(256), 0, stream, (const float*)ws, nblk, C, out);
+    hipLaunchKernelGGL(k_colreduce_final, dim3(cdiv(2 * C, 64), nseg), dim3(1024), 0, stream, (const float*)ws, nblk, C, out);
     U2PL_LAUNCH_CHECK();
     return 0;
 }

@@ -48,50 +48,51 @@ struct BnBwdOp {  // g = dy*[y>0]*drop ; v0 = g, v1 = g * xhat     (BN backward 
     }
 };
 
+// grid = (row blocks, segments, column slabs of 64 float4): enough blocks in flight to cover HBM latency
+// even when the tensor has few rows (layer3/4: 37636 rows x 1024-2048 channels)
 template <class Op>
 __global__ void k_colreduce_partial(Op op, long Mseg, int C, float* __restrict__ partial) {
     __shared__ float4 sh0[256], sh1[256];
     const int C4 = C >> 2;
-    const int tc = C4 < 256 ? C4 : 256, tr = 256 / tc;
+    const int slab0 = blockIdx.z * 64;
+    const int wcols = min(64, C4 - slab0);          // float4 columns handled by this block
+    const int tc = wcols, tr = 256 / tc;
     const int tid = threadIdx.x, cl = tid % tc, rg = tid / tc;
     const int nblk = gridDim.x, seg = blockIdx.y;
     const long per = (Mseg + nblk - 1) / nblk;
     const long rb = seg * Mseg + blockIdx.x * per, re = min(seg * Mseg + Mseg, rb + per);
     float* out = partial + ((long)seg * nblk + blockIdx.x) * 2 * C;
-    for (int cb = 0; cb < C4; cb += tc) {
-        const int c4 = cb + cl;
-        float4 a0 = f4zero(), a1 = f4zero();
-        if (rg < tr && c4 < C4) {
-            // 4 independent row streams per thread: keeps >= 4 x 16 B loads in flight per lane
-            float4 b0 = f4zero(), b1 = f4zero(), c0 = f4zero(), c1 = f4zero(), d0 = f4zero(), d1 = f4zero();
-            long r = rb + rg;
-            for (; r + 3 * (long)tr < re; r += 4 * (long)tr) {
-                float4 v0, v1, w0, w1, x0, x1, y0, y1;
-                op.get(r, c4, v0, v1);
-                op.get(r + tr, c4, w0, w1);
-                op.get(r + 2 * (long)tr, c4, x0, x1);
-                op.get(r + 3 * (long)tr, c4, y0, y1);
-                a0 = f4add(a0, v0); a1 = f4add(a1, v1);
-                b0 = f4add(b0, w0); b1 = f4add(b1, w1);
-                c0 = f4add(c0, x0); c1 = f4add(c1, x1);
-                d0 = f4add(d0, y0); d1 = f4add(d1, y1);
-            }
-            for (; r < re; r += tr) {
-                float4 v0, v1;
-                op.get(r, c4, v0, v1);
-                a0 = f4add(a0, v0); a1 = f4add(a1, v1);
-            }
-            a0 = f4add(f4add(a0, b0), f4add(c0, d0));
-            a1 = f4add(f4add(a1, b1), f4add(c1, d1));
+    const int c4 = slab0 + cl;
+    float4 a0 = f4zero(), a1 = f4zero();
+    if (rg < tr) {
+        // 4 independent row streams per thread: keeps >= 4 x 16 B loads in flight per lane
+        float4 b0 = f4zero(), b1 = f4zero(), c0 = f4zero(), c1 = f4zero(), d0 = f4zero(), d1 = f4zero();
+        long r = rb + rg;
+        for (; r + 3 * (long)tr < re; r += 4 * (long)tr) {
+            float4 v0, v1, w0, w1, x0, x1, y0, y1;
+            op.get(r, c4, v0, v1);
+            op.get(r + tr, c4, w0, w1);
+            op.get(r + 2 * (long)tr, c4, x0, x1);
+            op.get(r + 3 * (long)tr, c4, y0, y1);
+            a0 = f4add(a0, v0); a1 = f4add(a1, v1);
+            b0 = f4add(b0, w0); b1 = f4add(b1, w1);
+            c0 = f4add(c0, x0); c1 = f4add(c1, x1);
+            d0 = f4add(d0, y0); d1 = f4add(d1, y1);
         }
-        sh0[tid] = a0; sh1[tid] = a1;
-        __syncthreads();
-        if (rg == 0 && c4 < C4) {
-            for (int k = 1; k < tr; ++k) { a0 = f4add(a0, sh0[k * tc + cl]); a1 = f4add(a1, sh1[k * tc + cl]); }
-            *(float4*)(out + c4 * 4) = a0;
-            *(float4*)(out + C + c4 * 4) = a1;
+        for (; r < re; r += tr) {
+            float4 v0, v1;
+            op.get(r, c4, v0, v1);
+            a0 = f4add(a0, v0); a1 = f4add(a1, v1);
         }
-        __syncthreads();
+        a0 = f4add(f4add(a0, b0), f4add(c0, d0));
+        a1 = f4add(f4add(a1, b1), f4add(c1, d1));
+    }
+    sh0[tid] = a0; sh1[tid] = a1;
+    __syncthreads();
+    if (rg == 0) {
+        for (int k = 1; k < tr; ++k) { a0 = f4add(a0, sh0[k * tc + cl]); a1 = f4add(a1, sh1[k * tc + cl]); }
+        *(float4*)(out + c4 * 4) = a0;
+        *(float4*)(out + C + c4 * 4) = a1;
     }
 }
 // ordered (deterministic) second stage: 64 columns x 16 partial-row groups per 1024-thread block; every
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(1024) void k_colreduce_final(const float* __restric
     }
 }
 static int colreduce_blocks(long Mseg) {
-    long b = (Mseg + 255) / 256;
+    long b = (Mseg + 63) / 64;
     return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
 }
 U2PL_API size_t u2pl_colreduce_workspace_bytes(long Mseg, int nseg, int C) {
@@ -135,7 +136,7 @@ template <class Op>
 static int run_colreduce(Op op, long Mseg, int nseg, int C, void* ws, double* out, hipStream_t stream) {
     if (C % 4 || Mseg <= 0) return U2PL_EINVAL;
     const int nblk = colreduce_blocks(Mseg);
-    hipLaunchKernelGGL((k_colreduce_partial<Op>), dim3(nblk, nseg), dim3(256), 0, stream, op, Mseg, C, (float*)ws);
+    hipLaunchKernelGGL((k_colreduce_partial<Op>), dim3(nblk, nseg, cdiv(C / 4, 64)), dim3(256), 0, stream, op, Mseg, C, (float*)ws);
     U2PL_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_colreduce_final, dim3(cdiv(2 * C, 64), nseg), dim3(1024), 0, stream, (const float*)ws, nblk, C, out);
     U2PL_LAUNCH_CHECK();

@@ -15,6 +15,8 @@ sampling (Q3), contrastive gradient scaled by an extra 1/world (Q5), teacher
 aliasing in the first semi epoch (Q6), per-rank thresholds (Q7), LR set before
 the forward (Q9), zero (not None) grads for unused heads (Q13).
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -99,6 +101,11 @@ class SemiTrainer:
         self.last_lr = lr
         return [lr * m for m in self.lr_mult]
 
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream() if os.environ.get("U2PL_NO_SIDE_STREAM") is None else torch.cuda.current_stream()
+        return self._side
+
     def resync_arenas(self):
         """parameters were (re)loaded through load_state_dict: views already alias the arenas."""
         return None
@@ -146,8 +153,22 @@ class SemiTrainer:
                 assert unsup_cfg["apply_aug"] == "cutmix", "only cutmix is wired to a HIP kernel"
                 boxes = cutmix_boxes if cutmix_boxes is not None else generate_cutmix_boxes(B, h, w)
                 image_u_aug, label_u_aug, conf_u = cutmix(image_u, label_u_aug, conf_u, boxes)
-            # student forward (train_semi.py:339-358)
             image_all = torch.cat((image_l, image_u_aug))
+            # teacher train-mode forward (train_semi.py:360-374) on a SIDE HIP stream: it is independent of
+            # the student forward, so its memory-bound BN passes and kernel tails overlap the student's
+            # MFMA-bound convs (both streams feed the same GPU; order of results is unaffected)
+            main = torch.cuda.current_stream()
+            side = self._side_stream()
+            side.wait_stream(main)
+            teacher.train()
+            with torch.cuda.stream(side), torch.no_grad():
+                out_t = teacher(image_all, need_aux=False)
+                pred_all_t, rep_all_t = out_t["pred"], out_t["rep"]
+                prob_all_t = K.new_act(*pred_all_t.shape, pred_all_t.device)
+                pt, ldp = K.as_rows(pred_all_t)
+                Cn = pred_all_t.shape[1]
+                K.call("u2pl_softmax_rows_f32", pt, ldp, prob_all_t, Cn, pt.shape[0] * pt.shape[2] * pt.shape[3], Cn)
+            # student forward (train_semi.py:339-358)
             outs = model(image_all)
             pred_all, rep_all = outs["pred"], outs["rep"]
             pred_l_large = H.bilinear_up(pred_all[:B], (h, w))
@@ -157,15 +178,12 @@ class SemiTrainer:
                 sup_loss = self.sup_loss_fn([pred_l_large, aux], label_l.clone())
             else:
                 sup_loss = self.sup_loss_fn(pred_l_large, label_l.clone())
-            # teacher train-mode forward (train_semi.py:360-374)
-            teacher.train()
+            main.wait_stream(side)
+            if side is not main:
+                for t_ in (pred_all_t, rep_all_t, prob_all_t):
+                    t_.record_stream(main)   # allocated on the side stream, consumed on the main stream
+                image_all.record_stream(side)  # allocated on the main stream, read on the side stream
             with torch.no_grad():
-                out_t = teacher(image_all, need_aux=False)
-                pred_all_t, rep_all_t = out_t["pred"], out_t["rep"]
-                prob_all_t = K.new_act(*pred_all_t.shape, pred_all_t.device)
-                pt, ldp = K.as_rows(pred_all_t)
-                Cn = pred_all_t.shape[1]
-                K.call("u2pl_softmax_rows_f32", pt, ldp, prob_all_t, Cn, pt.shape[0] * pt.shape[2] * pt.shape[3], Cn)
                 # one fused pass: bilinear up-sampling + entropy + valid count + select histogram, then ONE
                 # exact selection for all three percentiles (drop_percent, alpha_t, 100 - alpha_t)
                 drop_percent = unsup_cfg.get("drop_percent", 100)

@@ -1,0 +1,46 @@
+"""Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md
+prescribes) of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline` into profiles/r01_traffic.json.
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of a wide coalesced stream -> x2."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def load(d, counter):
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    per = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        per[k][0] += float(r["Counter_Value"])
+        per[k][1] += 1
+    return per
+
+
+def main(fetch_dir, write_dir, out, steps_profiled):
+    fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+    rows = {}
+    for k in sorted(set(fe) | set(wr)):
+        f, nf = fe.get(k, [0.0, 0])
+        w, nw = wr.get(k, [0.0, 0])
+        n = max(nf, nw, 1)
+        rows[k] = dict(launches=n, fetch_KiB_raw=f, write_KiB=w, bytes_per_launch=(2 * f + w) * 1024 / n)
+    ig = [v for k, v in rows.items() if k.startswith("k_conv_igemm")]
+    ig_l = sum(v["launches"] for v in ig)
+    ig_b = sum(v["bytes_per_launch"] * v["launches"] for v in ig) / max(ig_l, 1)
+    hbm_names = ("k_entropy", "k_sel_", "k_reliability", "k_apply_drop", "k_contra", "k_compact", "k_proto", "k_bank",
+                 "k_infonce", "k_scatter_add")
+    hb = sum(v["bytes_per_launch"] * v["launches"] for k, v in rows.items() if k.startswith(hbm_names)) / steps_profiled
+    res = dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py; bytes = (2*FETCH_SIZE + "
+                    "WRITE_SIZE) KiB (gfx950 FETCH_SIZE x2 correction, WRITE_SIZE uncalibrated); Infinity-Cache hits are counted",
+               k_conv_igemm_bytes_per_launch=round(ig_b), k_conv_igemm_launches=ig_l,
+               hbm_group_bytes_per_step=round(hb), kernels={k: v for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["bytes_per_launch"] * kv[1]["launches"])[:25]})
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps({k: res[k] for k in ("k_conv_igemm_bytes_per_launch", "k_conv_igemm_launches", "hbm_group_bytes_per_step")}))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]))

@@ -65,7 +65,13 @@ def measure(trainer, batch, args, ms_per_step):
     from .utils import loss_helper as LH
 
     il, ll, iu = batch
-    agg = profile_step(lambda: trainer.train_step(il, ll, iu, epoch=0))
+    # per-kernel HIP-event timing needs serial execution: run the profiled step without the side stream
+    saved = getattr(trainer, "_side", None)
+    trainer._side = torch.cuda.current_stream()
+    try:
+        agg = profile_step(lambda: trainer.train_step(il, ll, iu, epoch=0))
+    finally:
+        trainer._side = saved
     shapes = agg.pop("_shapes")
     out = {}
     if os.environ.get("U2PL_BENCH_SHAPES"):
@@ -107,6 +113,16 @@ def measure(trainer, batch, args, ms_per_step):
                                "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
                                "algorithmic_MB": round((rel_b + con_b) / 1e6, 1), "reliability_us": round(t_rel * 1e3, 1),
                                "contrastive_us": round(t_con * 1e3, 1), "stats": dict(LH.LAST_STATS)}
+    # HBM traffic per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
+    # same command (profiles/r01_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), if present
+    tj = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_traffic.json")
+    if os.path.exists(tj) and "roofline" in out:
+        import json
+        tr = json.load(open(tj))
+        out["roofline"]["traffic"] = tr.get("k_conv_igemm_bytes_per_launch")
+        out["roofline"]["traffic_note"] = tr.get("note")
+        if "roofline_hbm" in out and tr.get("hbm_group_bytes_per_step") is not None:
+            out["roofline_hbm"]["traffic"] = tr["hbm_group_bytes_per_step"]
     top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]
     out["kernel_ms_per_step"] = {k: round(v["ms"], 2) for k, v in top}
     out["kernel_ms_total_profiled"] = round(sum(v["ms"] for v in agg.values()), 2)

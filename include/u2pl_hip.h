@@ -92,13 +92,17 @@ int u2pl_compact_lists(const unsigned* abits, const unsigned* lowbits, const uns
 /* torch.mean(rep_teacher[low_valid], dim=0): loss_helper.py:119-123 */
 size_t u2pl_proto_workspace_bytes(long P, int C, int D);
 int u2pl_class_prototypes(const float* rows, long ld, int D, const int* idx, long cap, const unsigned* counts,
-                          int C, long P, void* workspace, float* proto, hipStream_t stream);
+                          int C, long P, void* workspace, float* proto, const unsigned* lowbits,
+                          hipStream_t stream);
 /* keys = rep_teacher[negative_mask]: loss_helper.py:142 */
 int u2pl_gather_rows_f32(const float* rows, long ld, int D, const int* list, long n, float* out,
                          hipStream_t stream);
 /* dequeue_and_enqueue FIFO (utils.py:27-47) on a device ring; tail=(head+len)%cap */
 int u2pl_bank_append_f32(float* bank, long cap, long tail, int D, const float* rows, long ld, const int* list,
                          long n_new, hipStream_t stream);
+/* same for every class in ONE launch; desc_dev = int64 [nclass][6] {bank, cap, tail, rows, list|0, n_new} */
+int u2pl_bank_append_multi_f32(const long long* desc_dev, int nclass, int D, long ld, long max_new,
+                               hipStream_t stream);
 /* cosine_similarity / temp + cross_entropy(target 0): loss_helper.py:173-230 */
 size_t u2pl_infonce_job_bytes(void);
 int u2pl_infonce_f32(const void* jobs_dev, int njobs, const float* rep, long ld, int D, int Q, int K,

@@ -203,45 +203,74 @@ U2PL_API int u2pl_compact_lists(const unsigned* abits, const unsigned* lowbits, 
 // Deterministic two-stage sum: chunks of PR_ROWS rows -> partial[C][nchunk][D]
 // (float), then an ordered double-precision finish.
 // ---------------------------------------------------------------------------
-#define PR_ROWS 128
-__global__ void k_proto_partial(const float* __restrict__ rows, long ld, int D, const int* __restrict__ idx,
-                                long cap, const unsigned* __restrict__ counts, int nchunk,
-                                float* __restrict__ partial) {
-    const int c = blockIdx.y, ch = blockIdx.x;
-    const unsigned n = counts[1 * MAXC + c];
-    const long r0 = (long)ch * PR_ROWS;
-    if (r0 >= n) return;
-    const int* list = idx + ((long)1 * MAXC + c) * cap;
-    const long r1 = min((long)n, r0 + PR_ROWS);
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        float acc = 0.f;
-        for (long r = r0; r < r1; ++r) acc += rows[(long)list[r] * ld + d];
-        partial[((long)c * nchunk + ch) * D + d] = acc;
+// Streaming formulation: every pixel row of rep_teacher that belongs to at least one class is read ONCE
+// (1 KiB coalesced by D/4 lanes) and added into a per-block [C][D] LDS accumulator; thread d owns column
+// d of every class, visits the block's pixels in order => deterministic.  Only images {0, B} carry class
+// bits (Q0), so ~2*h*w rows are streamed instead of sum_c |low_valid_c| gathered rows.
+#define PR_PIX 256
+__global__ void k_proto_stream(const float* __restrict__ rows, long ld, int D, const unsigned* __restrict__ lowbits,
+                               long P, int C, float* __restrict__ partial) {
+    extern __shared__ float acc[];   // [C][D]
+    __shared__ unsigned bits[PR_PIX];
+    __shared__ int any;
+    const long p0 = (long)blockIdx.x * PR_PIX;
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < PR_PIX; i += blockDim.x) {
+        const unsigned b = (p0 + i < P) ? lowbits[p0 + i] : 0u;
+        bits[i] = b;
+        if (b) any = 1;
     }
+    for (int i = threadIdx.x; i < C * D; i += blockDim.x) acc[i] = 0.f;
+    __syncthreads();
+    float* out = partial + (long)blockIdx.x * C * D;
+    if (any) {
+        for (int d = threadIdx.x; d < D; d += blockDim.x)
+            for (int i = 0; i < PR_PIX; ++i) {
+                unsigned b = bits[i];
+                if (!b) continue;
+                const float v = rows[(p0 + i) * ld + d];
+                while (b) {
+                    const int c = __ffs(b) - 1;
+                    b &= b - 1;
+                    acc[c * D + d] += v;
+                }
+            }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < C * D; i += blockDim.x) out[i] = acc[i];
 }
 __global__ void k_proto_finish(const float* __restrict__ partial, int D, const unsigned* __restrict__ counts,
-                               int nchunk, float* __restrict__ proto) {
+                               int nblk, int C, float* __restrict__ proto) {
     const int c = blockIdx.x;
     const unsigned n = counts[1 * MAXC + c];
-    const int used = (int)((n + PR_ROWS - 1) / PR_ROWS);
     for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        double acc = 0.0;
-        for (int ch = 0; ch < used; ++ch) acc += (double)partial[((long)c * nchunk + ch) * D + d];
-        proto[(long)c * D + d] = n ? (float)(acc / (double)n) : __uint_as_float(0x7fc00000u);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int b = 0;
+        for (; b + 3 < nblk; b += 4) {
+            a0 += (double)partial[((long)b * C + c) * D + d];
+            a1 += (double)partial[((long)(b + 1) * C + c) * D + d];
+            a2 += (double)partial[((long)(b + 2) * C + c) * D + d];
+            a3 += (double)partial[((long)(b + 3) * C + c) * D + d];
+        }
+        for (; b < nblk; ++b) a0 += (double)partial[((long)b * C + c) * D + d];
+        proto[(long)c * D + d] = n ? (float)(((a0 + a1) + (a2 + a3)) / (double)n) : __uint_as_float(0x7fc00000u);
     }
 }
 
 U2PL_API size_t u2pl_proto_workspace_bytes(long P, int C, int D) {
-    return (size_t)C * cdiv(P, PR_ROWS) * D * sizeof(float);
+    return (size_t)cdiv(P, PR_PIX) * C * D * sizeof(float);
 }
+// idx/cap are unused by the streaming formulation (kept in the ABI for list-based callers)
 U2PL_API int u2pl_class_prototypes(const float* rows, long ld, int D, const int* idx, long cap,
                                    const unsigned* counts, int C, long P, void* workspace, float* proto,
-                                   hipStream_t stream) {
-    int nchunk = cdiv(P, PR_ROWS);
-    hipLaunchKernelGGL(k_proto_partial, dim3(nchunk, C), dim3(256), 0, stream, rows, ld, D, idx, cap, counts,
-                       nchunk, (float*)workspace);
+                                   const unsigned* lowbits, hipStream_t stream) {
+    (void)idx; (void)cap;
+    const int nblk = cdiv(P, PR_PIX);
+    hipLaunchKernelGGL(k_proto_stream, dim3(nblk), dim3(256), (size_t)C * D * sizeof(float), stream, rows, ld, D, lowbits, P,
+                       C, (float*)workspace);
     U2PL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_proto_finish, dim3(C), dim3(256), 0, stream, (const float*)workspace, D, counts, nchunk, proto);
+    hipLaunchKernelGGL(k_proto_finish, dim3(C), dim3(256), 0, stream, (const float*)workspace, D, counts, nblk, C, proto);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -287,6 +316,35 @@ __global__ void k_bank_append(float* __restrict__ bank, long cap, long tail, int
         ((float4*)bank)[slot * D4 + d] = *(const float4*)(rows + src * ld + 4 * d);
     }
 }
+// all classes in one launch: desc = int64 [C][6] = {bank ptr, cap, tail, rows ptr, list ptr (or 0), n_new}
+__global__ void k_bank_append_multi(const long long* __restrict__ desc, int D, long ld) {
+    const long long* d = desc + 6 * blockIdx.y;
+    float* bank = (float*)d[0];
+    const long cap = d[1], tail = d[2];
+    const float* rows = (const float*)d[3];
+    const int* list = (const int*)d[4];
+    const long n_new = d[5];
+    const long skip = n_new > cap ? n_new - cap : 0;
+    const int D4 = D >> 2;
+    const long total = (n_new - skip) * D4;
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long j = skip + t / D4;
+        const int dd = (int)(t % D4);
+        const long src = list ? (long)list[j] : j;
+        const long slot = (tail + j) % cap;
+        ((float4*)bank)[slot * D4 + dd] = *(const float4*)(rows + src * ld + 4 * dd);
+    }
+}
+U2PL_API int u2pl_bank_append_multi_f32(const long long* desc_dev, int nclass, int D, long ld, long max_new,
+                                        hipStream_t stream) {
+    if (D % 4) return U2PL_EINVAL;
+    if (nclass <= 0 || max_new <= 0) return 0;
+    dim3 grid(grid_for(max_new * (D / 4), 256, 64), nclass);
+    hipLaunchKernelGGL(k_bank_append_multi, grid, dim3(256), 0, stream, desc_dev, D, ld);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
 U2PL_API int u2pl_bank_append_f32(float* bank, long cap, long tail, int D, const float* rows, long ld,
                                   const int* list, long n_new, hipStream_t stream) {
     if (D % 4 || cap <= 0) return U2PL_EINVAL;
@@ -334,36 +392,63 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
     na = fmaxf(sqrtf(wave_sum(na)), 1e-8f);
 #pragma unroll
     for (int i = 0; i < VPL; ++i) ah[i] = a[i] / na;
-    // online softmax over the 1+K logits, accumulating sum_j softmax_j * fhat_j
+    // online softmax over the 1+K logits, accumulating sum_j softmax_j * fhat_j.  Features are processed
+    // four at a time: four independent 1 KiB row loads in flight per wave and four interleaved shuffle
+    // reductions (the kernel is a latency-bound gather otherwise).
     float m = -INFINITY, s = 0.f, l0 = 0.f, cw = 0.f;  // cw = sum_j w_j * cos_j (un-normalised)
     float f0h[VPL];
-    for (int j = 0; j <= K; ++j) {
-        const float* fr;
-        if (j == 0) fr = J.proto + lane * VPL;
-        else {
-            long r = (J.bank_head + J.idx_n[(long)q * K + (j - 1)]) % J.bank_cap;
-            fr = J.bank + r * D + lane * VPL;
+    auto row_ptr = [&](int j) -> const float* {
+        if (j == 0) return J.proto + lane * VPL;
+        const long r = (J.bank_head + J.idx_n[(long)q * K + (j - 1)]) % J.bank_cap;
+        return J.bank + r * D + lane * VPL;
+    };
+    for (int j0 = 0; j0 <= K; j0 += 4) {
+        float f[4][VPL], nf[4], dot[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* fr = row_ptr(min(j0 + u, K));
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) f[u][i] = fr[i];
         }
-        float f[VPL], nf = 0.f, dot = 0.f;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) { f[i] = fr[i]; nf += f[i] * f[i]; }
-        nf = fmaxf(sqrtf(wave_sum(nf)), 1e-8f);
+        for (int u = 0; u < 4; ++u) {
+            nf[u] = 0.f;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) { f[i] = f[i] / nf; dot += ah[i] * f[i]; }
-        const float cosv = wave_sum(dot);
-        const float l = cosv * inv_temp;
-        if (j == 0) {
-            l0 = l;
-#pragma unroll
-            for (int i = 0; i < VPL; ++i) f0h[i] = f[i];
+            for (int i = 0; i < VPL; ++i) nf[u] += f[u][i] * f[u][i];
         }
-        const float mn = fmaxf(m, l);
-        const float sc = expf(m - mn), w = expf(l - mn);
-        s = s * sc + w;
-        cw = cw * sc + w * cosv;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) acc[i] = acc[i] * sc + w * f[i];
-        m = mn;
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) nf[u] += __shfl_xor(nf[u], o, 64);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            nf[u] = fmaxf(sqrtf(nf[u]), 1e-8f);
+            dot[u] = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) { f[u][i] = f[u][i] / nf[u]; dot[u] += ah[i] * f[u][i]; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dot[u] += __shfl_xor(dot[u], o, 64);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j0 + u > K) continue;
+            const float cosv = dot[u];
+            const float l = cosv * inv_temp;
+            if (j0 + u == 0) {
+                l0 = l;
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) f0h[i] = f[u][i];
+            }
+            const float mn = fmaxf(m, l);
+            const float sc = expf(m - mn), w = expf(l - mn);
+            s = s * sc + w;
+            cw = cw * sc + w * cosv;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) acc[i] = acc[i] * sc + w * f[u][i];
+            m = mn;
+        }
     }
     const float lse = m + logf(s);
     if (lane == 0) {
@@ -398,28 +483,25 @@ U2PL_API int u2pl_infonce_f32(const void* jobs_dev, int njobs, const float* rep,
 }
 U2PL_API size_t u2pl_infonce_job_bytes(void) { return sizeof(NceJob); }
 
-// loss = (sum_jobs mean_q loss_q) / valid_seg   (loss_helper.py:228-233), ordered sum
-__global__ void k_infonce_reduce(const float* __restrict__ loss_q, int njobs, int Q, float inv_valid_seg,
-                                 float* __restrict__ loss) {
-    __shared__ double sh[256];
-    double tot = 0.0;
-    for (int j = 0; j < njobs; ++j) {
-        double acc = 0.0;
-        for (int q = threadIdx.x; q < Q; q += 256) acc += (double)loss_q[(long)j * Q + q];
-        sh[threadIdx.x] = acc;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-            __syncthreads();
-        }
-        tot += sh[0] / (double)Q;
+// loss = (sum_jobs mean_q loss_q) / valid_seg = sum_all loss_q / (Q * valid_seg)   (loss_helper.py:228-233)
+// one 1024-thread block, fixed summation order (deterministic), double accumulation
+__global__ __launch_bounds__(1024) void k_infonce_reduce(const float* __restrict__ loss_q, int njobs, int Q,
+                                                         float inv_valid_seg, float* __restrict__ loss) {
+    __shared__ double sh[1024];
+    const long n = (long)njobs * Q;
+    double acc = 0.0;
+    for (long i = threadIdx.x; i < n; i += 1024) acc += (double)loss_q[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *loss = (float)(tot * (double)inv_valid_seg);
+    if (threadIdx.x == 0) *loss = (float)(sh[0] / (double)Q * (double)inv_valid_seg);
 }
 U2PL_API int u2pl_infonce_reduce_f32(const float* loss_q, int njobs, int Q, float inv_valid_seg, float* loss,
                                      hipStream_t stream) {
-    hipLaunchKernelGGL(k_infonce_reduce, dim3(1), dim3(256), 0, stream, loss_q, njobs, Q, inv_valid_seg, loss);
+    hipLaunchKernelGGL(k_infonce_reduce, dim3(1), dim3(1024), 0, stream, loss_q, njobs, Q, inv_valid_seg, loss);
     U2PL_LAUNCH_CHECK();
     return 0;
 }

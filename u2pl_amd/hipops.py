@@ -254,6 +254,27 @@ class DeviceMemoryBank:
         self.head[c] = (new_tail - self.length[c]) % cap
         self._book(c, n_new)
 
+    def append_multi(self, entries, ld):
+        """entries: [(class, rows tensor/ptr, n_new, int32 index list or None)] -> ONE launch."""
+        desc = np.zeros((len(entries), 6), dtype=np.int64)
+        mx = 0
+        for k, (c, rows, n_new, idx_list) in enumerate(entries):
+            cap = self.cap[c]
+            tail = (self.head[c] + self.length[c]) % cap
+            desc[k] = (self.buf[c].data_ptr(), cap, tail, _lib._ptr(rows) or 0,
+                       idx_list.data_ptr() if idx_list is not None else 0, n_new)
+            mx = max(mx, min(n_new, cap))
+        if mx > 0:
+            dd = torch.from_numpy(desc).to(self.buf[0].device, non_blocking=True)
+            call("u2pl_bank_append_multi_f32", dd, len(entries), self.D, ld, mx)
+        for c, rows, n_new, idx_list in entries:
+            if n_new > 0:
+                cap = self.cap[c]
+                tail = (self.head[c] + self.length[c]) % cap
+                self.length[c] = min(self.length[c] + n_new, cap)
+                self.head[c] = ((tail + n_new) % cap - self.length[c]) % cap
+            self._book(c, n_new)
+
     def _book(self, c, bs):
         if self.length[c] >= self.cap[c]:
             self.ptr[c] = self.cap[c]
@@ -304,7 +325,7 @@ def contra_phase1(rep_teacher_rows, ld, D, prob, prob_strides, lbits, low_mask, 
     call("u2pl_compact_lists", abits, lowbits, nbits, P, C, work, out.idx, P, out.counts)
     pw = torch.empty(query("u2pl_proto_workspace_bytes", P, C, D), dtype=torch.uint8, device=dev)
     out.proto = torch.empty((C, D), dtype=torch.float32, device=dev)
-    call("u2pl_class_prototypes", rep_teacher_rows, ld, D, out.idx, P, out.counts, C, P, pw, out.proto)
+    call("u2pl_class_prototypes", rep_teacher_rows, ld, D, out.idx, P, out.counts, C, P, pw, out.proto, lowbits)
     out.counts_host = None
     return out
 

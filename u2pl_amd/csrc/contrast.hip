@@ -208,53 +208,84 @@ U2PL_API int u2pl_compact_lists(const unsigned* abits, const unsigned* lowbits, 
 // d of every class, visits the block's pixels in order => deterministic.  Only images {0, B} carry class
 // bits (Q0), so ~2*h*w rows are streamed instead of sum_c |low_valid_c| gathered rows.
 #define PR_PIX 256
+// 4 waves per block; wave w streams pixels w, w+4, ... of the block's range (8 row loads in flight per
+// wave), lane l owns channels [4l, 4l+4) (D == 256) or strides over D; per-class accumulators live in
+// registers (class loop fully unrolled and predicated), combined across the 4 waves through LDS in a
+// fixed order => deterministic.
+template <int CT>
 __global__ void k_proto_stream(const float* __restrict__ rows, long ld, int D, const unsigned* __restrict__ lowbits,
-                               long P, int C, float* __restrict__ partial) {
-    extern __shared__ float acc[];   // [C][D]
-    __shared__ unsigned bits[PR_PIX];
-    __shared__ int any;
+                               long P, float* __restrict__ partial) {
+    extern __shared__ float red[];   // [4][CT][D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long p0 = (long)blockIdx.x * PR_PIX;
-    if (threadIdx.x == 0) any = 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < PR_PIX; i += blockDim.x) {
-        const unsigned b = (p0 + i < P) ? lowbits[p0 + i] : 0u;
-        bits[i] = b;
-        if (b) any = 1;
-    }
-    for (int i = threadIdx.x; i < C * D; i += blockDim.x) acc[i] = 0.f;
-    __syncthreads();
-    float* out = partial + (long)blockIdx.x * C * D;
-    if (any) {
-        for (int d = threadIdx.x; d < D; d += blockDim.x)
-            for (int i = 0; i < PR_PIX; ++i) {
-                unsigned b = bits[i];
-                if (!b) continue;
-                const float v = rows[(p0 + i) * ld + d];
-                while (b) {
-                    const int c = __ffs(b) - 1;
-                    b &= b - 1;
-                    acc[c * D + d] += v;
+    float* out = partial + (long)blockIdx.x * CT * D;
+    for (int d0 = 0; d0 < D; d0 += 256) {       // D <= 256: one trip
+        const int d = d0 + lane * 4;
+        float4 acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d < D) {
+            for (int i0 = wave; i0 < PR_PIX; i0 += 4 * 8) {
+                unsigned bits[8];
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const long p = p0 + i0 + 4 * u;
+                    bits[u] = (i0 + 4 * u < PR_PIX && p < P) ? lowbits[p] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = bits[u] ? *(const float4*)(rows + (p0 + i0 + 4 * u) * ld + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (!bits[u]) continue;   // wave-uniform (bits are per pixel)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+                        if ((bits[u] >> c) & 1u) {
+                            acc[c].x += v[u].x; acc[c].y += v[u].y; acc[c].z += v[u].z; acc[c].w += v[u].w;
+                        }
                 }
             }
+#pragma unroll
+            for (int c = 0; c < CT; ++c) *(float4*)(red + ((long)wave * CT + c) * D + d) = acc[c];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < CT * D / 4; i += blockDim.x) {
+            const float4 a = ((float4*)red)[i], b2 = ((float4*)red)[CT * D / 4 + i];
+            const float4 c2 = ((float4*)red)[2 * CT * D / 4 + i], e = ((float4*)red)[3 * CT * D / 4 + i];
+            float4 r;
+            r.x = (a.x + b2.x) + (c2.x + e.x); r.y = (a.y + b2.y) + (c2.y + e.y);
+            r.z = (a.z + b2.z) + (c2.z + e.z); r.w = (a.w + b2.w) + (c2.w + e.w);
+            ((float4*)out)[i] = r;
+        }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < C * D; i += blockDim.x) out[i] = acc[i];
 }
+// grid (C, D/64): 64 channels x 4 partial groups per block, 8 loads in flight per thread
 __global__ void k_proto_finish(const float* __restrict__ partial, int D, const unsigned* __restrict__ counts,
                                int nblk, int C, float* __restrict__ proto) {
-    const int c = blockIdx.x;
+    __shared__ double sh[4][64];
+    const int c = blockIdx.x, cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int d = blockIdx.y * 64 + cl;
     const unsigned n = counts[1 * MAXC + c];
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int b = 0;
-        for (; b + 3 < nblk; b += 4) {
-            a0 += (double)partial[((long)b * C + c) * D + d];
-            a1 += (double)partial[((long)(b + 1) * C + c) * D + d];
-            a2 += (double)partial[((long)(b + 2) * C + c) * D + d];
-            a3 += (double)partial[((long)(b + 3) * C + c) * D + d];
+    double acc = 0.0;
+    if (d < D) {
+        const float* p = partial + (long)c * D + d;
+        int b = rg;
+        for (; b + 7 * 4 < nblk; b += 8 * 4) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(long)(b + 4 * u) * C * D];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (double)v[u];
         }
-        for (; b < nblk; ++b) a0 += (double)partial[((long)b * C + c) * D + d];
-        proto[(long)c * D + d] = n ? (float)(((a0 + a1) + (a2 + a3)) / (double)n) : __uint_as_float(0x7fc00000u);
+        for (; b < nblk; b += 4) acc += (double)p[(long)b * C * D];
+    }
+    sh[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0 && d < D) {
+        const double t = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+        proto[(long)c * D + d] = n ? (float)(t / (double)n) : __uint_as_float(0x7fc00000u);
     }
 }
 
@@ -267,10 +298,21 @@ U2PL_API int u2pl_class_prototypes(const float* rows, long ld, int D, const int*
                                    const unsigned* lowbits, hipStream_t stream) {
     (void)idx; (void)cap;
     const int nblk = cdiv(P, PR_PIX);
-    hipLaunchKernelGGL(k_proto_stream, dim3(nblk), dim3(256), (size_t)C * D * sizeof(float), stream, rows, ld, D, lowbits, P,
-                       C, (float*)workspace);
+    if (D % 4 || D > 256) return U2PL_EINVAL;
+    const size_t lds = (size_t)4 * C * D * sizeof(float);
+#define PROTO_CASE(CT)                                                                                           \
+    case CT: {                                                                                                   \
+        static bool set_##CT = false;                                                                            \
+        if (!set_##CT) { (void)hipFuncSetAttribute((const void*)k_proto_stream<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * CT * 256 * 4)); set_##CT = true; } \
+        hipLaunchKernelGGL(k_proto_stream<CT>, dim3(nblk), dim3(256), lds, stream, rows, ld, D, lowbits, P, (float*)workspace); \
+    } break;
+    switch (C) {
+        PROTO_CASE(19) PROTO_CASE(21) PROTO_CASE(32)
+        default: return U2PL_EINVAL;
+    }
+#undef PROTO_CASE
     U2PL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_proto_finish, dim3(C), dim3(256), 0, stream, (const float*)workspace, D, counts, nblk, C, proto);
+    hipLaunchKernelGGL(k_proto_finish, dim3(C, cdiv(D, 64)), dim3(256), 0, stream, (const float*)workspace, D, counts, nblk, C, proto);
     U2PL_LAUNCH_CHECK();
     return 0;
 }

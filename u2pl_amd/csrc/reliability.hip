@@ -248,75 +248,79 @@ __global__ void k_entropy_up(const float* __restrict__ in, long sn, long sc, lon
     hist0_flush(sh, cnt, ws);
 }
 
-// Integer up-sampling ratio R = (H-1)/(h-1) (4 for the stride-4 logits): one thread owns one output ROW of
-// one low-res CELL (R consecutive pixels that share the same four corner logits), so the corners of a
-// class are loaded once per R outputs instead of once per output (the generic kernel is load-issue bound:
-// 76 gathers / pixel).  Arithmetic per output pixel is the identical FMA form => same bits.
-template <int R>
-__global__ void k_entropy_up_cell(const float* __restrict__ in, long sn, long sc, long sh_, long sw, int N, int C,
+// Integer up-sampling ratio R = (H-1)/(h-1) (4 for the stride-4 logits): one thread owns one low-res CELL
+// and produces its R x R output pixels.  The 4 x CT corner logits are fetched ONCE with CT*4 independent
+// loads issued back to back (class loop fully unrolled, values stay in registers for both sweeps), instead
+// of 4 gathers per class per output pixel (the generic kernel is load-issue bound: 76 gathers / pixel).
+// Arithmetic per output pixel is the identical FMA form (ac_coord per pixel) => same bits.
+template <int R, int CT>
+__global__ __launch_bounds__(64, 1) void k_entropy_up_cell(const float* __restrict__ in, long sn, long sc, long sh_, long sw, int N,
                                   int h, int w, int H, int W, float sy, float sx,
                                   const long long* __restrict__ label, int ignore, float* __restrict__ ent,
                                   unsigned* __restrict__ ws) {
     __shared__ unsigned sh[2048];
     for (int i = threadIdx.x; i < 2048; i += blockDim.x) sh[i] = 0;
     __syncthreads();
-    const long nseg = (long)N * H * w;   // (n, oy, cell column)
+    const long ncell = (long)N * h * w;
     unsigned cnt = 0;
-    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < nseg; q += (long)gridDim.x * blockDim.x) {
+    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < ncell; q += (long)gridDim.x * blockDim.x) {
         const int cj = (int)(q % w);
         const long t0 = q / w;
-        const int oy = (int)(t0 % H), n = (int)(t0 / H);
-        const int ox0 = cj * R;
-        const int nx = min(R, W - ox0);
-        const AcCoord cy = ac_coord(oy, sy, h);
-        float lx0[R], lx1[R];
-        int x0 = cj, x1 = cj;
+        const int ci = (int)(t0 % h), n = (int)(t0 / h);
+        const int oy0 = ci * R, ox0 = cj * R;
+        const int ny = min(R, H - oy0), nx = min(R, W - ox0);
+        float ly0[R], ly1[R], lx0[R], lx1[R];
+        int y0 = ci, y1 = ci, x0 = cj, x1 = cj;
 #pragma unroll
         for (int a = 0; a < R; ++a) {
-            const AcCoord cx = ac_coord(min(ox0 + a, W - 1), sx, w);
-            lx0[a] = cx.l0; lx1[a] = cx.l1;
-            if (a == 0) { x0 = cx.i0; x1 = cx.i1; }
+            const AcCoord cy = ac_coord(min(oy0 + a, H - 1), sy, h), cx = ac_coord(min(ox0 + a, W - 1), sx, w);
+            ly0[a] = cy.l0; ly1[a] = cy.l1; lx0[a] = cx.l0; lx1[a] = cx.l1;
+            if (a == 0) { y0 = cy.i0; y1 = cy.i1; x0 = cx.i0; x1 = cx.i1; }
         }
         const float* b = in + n * sn;
-        const long o00 = cy.i0 * sh_ + x0 * sw, o01 = cy.i0 * sh_ + x1 * sw, o10 = cy.i1 * sh_ + x0 * sw,
-                   o11 = cy.i1 * sh_ + x1 * sw;
-        float m[R], s[R], t[R];
+        const long o00 = y0 * sh_ + x0 * sw, o01 = y0 * sh_ + x1 * sw, o10 = y1 * sh_ + x0 * sw, o11 = y1 * sh_ + x1 * sw;
+        float v00[CT], v01[CT], v10[CT], v11[CT];
 #pragma unroll
-        for (int a = 0; a < R; ++a) { m[a] = -INFINITY; s[a] = 0.f; t[a] = 0.f; }
-        for (int c = 0; c < C; ++c) {   // sweep 1: per-pixel max
+        for (int c = 0; c < CT; ++c) {
             const float* bc = b + c * sc;
-            const float v00 = bc[o00], v01 = bc[o01], v10 = bc[o10], v11 = bc[o11];
-#pragma unroll
-            for (int a = 0; a < R; ++a) {
-                const float top = __fmaf_rn(lx0[a], v00, __fmul_rn(lx1[a], v01));
-                const float bot = __fmaf_rn(lx0[a], v10, __fmul_rn(lx1[a], v11));
-                m[a] = fmaxf(m[a], __fmaf_rn(cy.l0, top, __fmul_rn(cy.l1, bot)));
-            }
+            v00[c] = bc[o00]; v01[c] = bc[o01]; v10[c] = bc[o10]; v11[c] = bc[o11];
         }
-        for (int c = 0; c < C; ++c) {   // sweep 2: exp sums
-            const float* bc = b + c * sc;
-            const float v00 = bc[o00], v01 = bc[o01], v10 = bc[o10], v11 = bc[o11];
-#pragma unroll
-            for (int a = 0; a < R; ++a) {
-                const float top = __fmaf_rn(lx0[a], v00, __fmul_rn(lx1[a], v01));
-                const float bot = __fmaf_rn(lx0[a], v10, __fmul_rn(lx1[a], v11));
-                const float d = __fmaf_rn(cy.l0, top, __fmul_rn(cy.l1, bot)) - m[a];
-                const float e = expf(d);
-                s[a] += e;
-                t[a] += e * d;
-            }
-        }
-        const long p0 = ((long)n * H + oy) * W + ox0;
 #pragma unroll
         for (int a = 0; a < R; ++a) {
-            if (a < nx) {
-                float e = logf(s[a]) - t[a] / s[a];
-                const bool valid = label == nullptr || label[p0 + a] != (long long)ignore;
-                e = valid ? e : __uint_as_float(0x7fc00000u);
-                ent[p0 + a] = e;
-                cnt += valid ? 1u : 0u;
-                atomicAdd(&sh[f32_key(e) >> 21], 1u);
-            }
+            if (a >= ny) continue;
+            float m[R], s[R], t[R];
+#pragma unroll
+            for (int bb = 0; bb < R; ++bb) { m[bb] = -INFINITY; s[bb] = 0.f; t[bb] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int bb = 0; bb < R; ++bb) {
+                    const float top = __fmaf_rn(lx0[bb], v00[c], __fmul_rn(lx1[bb], v01[c]));
+                    const float bot = __fmaf_rn(lx0[bb], v10[c], __fmul_rn(lx1[bb], v11[c]));
+                    m[bb] = fmaxf(m[bb], __fmaf_rn(ly0[a], top, __fmul_rn(ly1[a], bot)));
+                }
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int bb = 0; bb < R; ++bb) {
+                    const float top = __fmaf_rn(lx0[bb], v00[c], __fmul_rn(lx1[bb], v01[c]));
+                    const float bot = __fmaf_rn(lx0[bb], v10[c], __fmul_rn(lx1[bb], v11[c]));
+                    const float d = __fmaf_rn(ly0[a], top, __fmul_rn(ly1[a], bot)) - m[bb];
+                    const float e = expf(d);
+                    s[bb] += e;
+                    t[bb] += e * d;
+                }
+            const long p0 = ((long)n * H + oy0 + a) * W + ox0;
+#pragma unroll
+            for (int bb = 0; bb < R; ++bb)
+                if (bb < nx) {
+                    float e = logf(s[bb]) - t[bb] / s[bb];
+                    const bool valid = label == nullptr || label[p0 + bb] != (long long)ignore;
+                    e = valid ? e : __uint_as_float(0x7fc00000u);
+                    ent[p0 + bb] = e;
+                    cnt += valid ? 1u : 0u;
+                    atomicAdd(&sh[f32_key(e) >> 21], 1u);
+                }
         }
     }
     hist0_flush(sh, cnt, ws);
@@ -329,10 +333,15 @@ U2PL_API int u2pl_entropy_up_f32(const float* in, long sn, long sc, long sh, lon
     if (total <= 0) return 0;
     dim3 grid(grid_for(total, 256, 512)), block(256);
     const float sy = ac_scale_host(h, H), sx = ac_scale_host(w, W);
-    if (h > 1 && w > 1 && H - 1 == 4 * (h - 1) && W - 1 == 4 * (w - 1)) {
-        const long nseg = (long)N * H * w;
-        hipLaunchKernelGGL(k_entropy_up_cell<4>, dim3(grid_for(nseg, 256, 1024)), dim3(256), 0, stream, in, sn, sc, sh, sw,
-                           N, C, h, w, H, W, sy, sx, label, ignore, entropy, ws);
+    if (h > 1 && w > 1 && H - 1 == 4 * (h - 1) && W - 1 == 4 * (w - 1) && (C == 19 || C == 21)) {
+        const long ncell = (long)N * h * w;
+        dim3 cgrid(grid_for(ncell, 64, 4096)), cblock(64);
+        if (C == 19)
+            hipLaunchKernelGGL((k_entropy_up_cell<4, 19>), cgrid, cblock, 0, stream, in, sn, sc, sh, sw, N, h, w, H, W, sy, sx,
+                               label, ignore, entropy, ws);
+        else
+            hipLaunchKernelGGL((k_entropy_up_cell<4, 21>), cgrid, cblock, 0, stream, in, sn, sc, sh, sw, N, h, w, H, W, sy, sx,
+                               label, ignore, entropy, ws);
         U2PL_LAUNCH_CHECK();
         return 0;
     }

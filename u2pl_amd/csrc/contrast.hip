@@ -225,26 +225,36 @@ __global__ void k_proto_stream(const float* __restrict__ rows, long ld, int D, c
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (d < D) {
-            for (int i0 = wave; i0 < PR_PIX; i0 += 4 * 8) {
-                unsigned bits[8];
-                float4 v[8];
+            // this wave's 64 pixels are wave + 4*i; lane i holds the class bits of pixel i of that set
+            const long pmine = p0 + wave + 4 * lane;
+            const unsigned mybits = pmine < P ? lowbits[pmine] : 0u;
+            unsigned long long todo = __ballot(mybits != 0);
+            while (todo) {          // wave-uniform loop: up to 8 contributing pixels per trip
+                int sel[8];
+                int nsel = 0;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const long p = p0 + i0 + 4 * u;
-                    bits[u] = (i0 + 4 * u < PR_PIX && p < P) ? lowbits[p] : 0u;
+                    sel[u] = 0;
+                    if (todo) {
+                        sel[u] = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1;
+                        nsel = u + 1;
+                    }
+                }
+                float4 v[8];
+                unsigned bits[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {   // unconditional loads (sel[u] = 0 is a valid pixel of the set)
+                    v[u] = *(const float4*)(rows + (p0 + wave + 4 * (long)sel[u]) * ld + d);
+                    bits[u] = u < nsel ? __shfl(mybits, sel[u], 64) : 0u;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    v[u] = bits[u] ? *(const float4*)(rows + (p0 + i0 + 4 * u) * ld + d) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (!bits[u]) continue;   // wave-uniform (bits are per pixel)
 #pragma unroll
                     for (int c = 0; c < CT; ++c)
                         if ((bits[u] >> c) & 1u) {
                             acc[c].x += v[u].x; acc[c].y += v[u].y; acc[c].z += v[u].z; acc[c].w += v[u].w;
                         }
-                }
             }
 #pragma unroll
             for (int c = 0; c < CT; ++c) *(float4*)(red + ((long)wave * CT + c) * D + d) = acc[c];
@@ -439,9 +449,14 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
     // reductions (the kernel is a latency-bound gather otherwise).
     float m = -INFINITY, s = 0.f, l0 = 0.f, cw = 0.f;  // cw = sum_j w_j * cos_j (un-normalised)
     float f0h[VPL];
+    // the K sampled bank rows of this anchor: one coalesced index load, then lane broadcasts (no dependent
+    // index -> row latency chain inside the loop)
+    const bool pre = K <= 64;
+    long myrow = 0;
+    if (pre && lane < K) myrow = (J.bank_head + J.idx_n[(long)q * K + lane]) % J.bank_cap;
     auto row_ptr = [&](int j) -> const float* {
         if (j == 0) return J.proto + lane * VPL;
-        const long r = (J.bank_head + J.idx_n[(long)q * K + (j - 1)]) % J.bank_cap;
+        const long r = pre ? __shfl(myrow, j - 1, 64) : (J.bank_head + J.idx_n[(long)q * K + (j - 1)]) % J.bank_cap;
         return J.bank + r * D + lane * VPL;
     };
     for (int j0 = 0; j0 <= K; j0 += 4) {

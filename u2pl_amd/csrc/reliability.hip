@@ -7,6 +7,7 @@
 // All kernels are HBM-bound; reads/writes are lane-contiguous along W.
 #include "common.h"
 #include "u2pl_hip.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------
 // a7: out[n][c][oy][ox] (NCHW contiguous) from a strided low-res tensor.
@@ -253,7 +254,7 @@ __global__ void k_entropy_up(const float* __restrict__ in, long sn, long sc, lon
 // loads issued back to back (class loop fully unrolled, values stay in registers for both sweeps), instead
 // of 4 gathers per class per output pixel (the generic kernel is load-issue bound: 76 gathers / pixel).
 // Arithmetic per output pixel is the identical FMA form (ac_coord per pixel) => same bits.
-template <int R, int CT>
+template <int R, int CT, int RY>
 __global__ __launch_bounds__(64, 1) void k_entropy_up_cell(const float* __restrict__ in, long sn, long sc, long sh_, long sw, int N,
                                   int h, int w, int H, int W, float sy, float sx,
                                   const long long* __restrict__ label, int ignore, float* __restrict__ ent,
@@ -261,14 +262,18 @@ __global__ __launch_bounds__(64, 1) void k_entropy_up_cell(const float* __restri
     __shared__ unsigned sh[2048];
     for (int i = threadIdx.x; i < 2048; i += blockDim.x) sh[i] = 0;
     __syncthreads();
-    const long ncell = (long)N * h * w;
+    constexpr int NSUB = R / RY;                       // threads per cell (each owns RY output rows)
+    const long nwork = (long)N * h * w * NSUB;
     unsigned cnt = 0;
-    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < ncell; q += (long)gridDim.x * blockDim.x) {
-        const int cj = (int)(q % w);
-        const long t0 = q / w;
+    for (long qq = blockIdx.x * (long)blockDim.x + threadIdx.x; qq < nwork; qq += (long)gridDim.x * blockDim.x) {
+        const int cj = (int)(qq % w);
+        long t0 = qq / w;
+        const int sub = (int)(t0 % NSUB);
+        t0 /= NSUB;
         const int ci = (int)(t0 % h), n = (int)(t0 / h);
-        const int oy0 = ci * R, ox0 = cj * R;
-        const int ny = min(R, H - oy0), nx = min(R, W - ox0);
+        const int oy0 = ci * R + sub * RY, ox0 = cj * R;
+        if (oy0 >= H) continue;
+        const int ny = min(RY, H - oy0), nx = min(R, W - ox0);
         float ly0[R], ly1[R], lx0[R], lx1[R];
         int y0 = ci, y1 = ci, x0 = cj, x1 = cj;
 #pragma unroll
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(64, 1) void k_entropy_up_cell(const float* __restri
             v00[c] = bc[o00]; v01[c] = bc[o01]; v10[c] = bc[o10]; v11[c] = bc[o11];
         }
 #pragma unroll
-        for (int a = 0; a < R; ++a) {
+        for (int a = 0; a < RY; ++a) {
             if (a >= ny) continue;
             float m[R], s[R], t[R];
 #pragma unroll
@@ -334,14 +339,16 @@ U2PL_API int u2pl_entropy_up_f32(const float* in, long sn, long sc, long sh, lon
     dim3 grid(grid_for(total, 256, 512)), block(256);
     const float sy = ac_scale_host(h, H), sx = ac_scale_host(w, W);
     if (h > 1 && w > 1 && H - 1 == 4 * (h - 1) && W - 1 == 4 * (w - 1) && (C == 19 || C == 21)) {
-        const long ncell = (long)N * h * w;
-        dim3 cgrid(grid_for(ncell, 64, 4096)), cblock(64);
-        if (C == 19)
-            hipLaunchKernelGGL((k_entropy_up_cell<4, 19>), cgrid, cblock, 0, stream, in, sn, sc, sh, sw, N, h, w, H, W, sy, sx,
-                               label, ignore, entropy, ws);
-        else
-            hipLaunchKernelGGL((k_entropy_up_cell<4, 21>), cgrid, cblock, 0, stream, in, sn, sc, sh, sw, N, h, w, H, W, sy, sx,
-                               label, ignore, entropy, ws);
+        static int ry = 0;   // rows of a cell per thread: 1 (default), 2 or 4 (U2PL_ENTROPY_RY, tuning knob)
+        if (!ry) { const char* e = getenv("U2PL_ENTROPY_RY"); ry = e ? atoi(e) : 1; if (ry != 1 && ry != 2 && ry != 4) ry = 1; }
+        const long nwork = (long)N * h * w * (4 / ry);
+        dim3 cgrid(grid_for(nwork, 64, 8192)), cblock(64);
+#define ENT_CASE(CC, RR)                                                                                       \
+    hipLaunchKernelGGL((k_entropy_up_cell<4, CC, RR>), cgrid, cblock, 0, stream, in, sn, sc, sh, sw, N, h, w, H, W, sy, \
+                       sx, label, ignore, entropy, ws)
+        if (C == 19) { if (ry == 1) ENT_CASE(19, 1); else if (ry == 2) ENT_CASE(19, 2); else ENT_CASE(19, 4); }
+        else { if (ry == 1) ENT_CASE(21, 1); else if (ry == 2) ENT_CASE(21, 2); else ENT_CASE(21, 4); }
+#undef ENT_CASE
         U2PL_LAUNCH_CHECK();
         return 0;
     }

@@ -224,7 +224,8 @@ __global__ void k_proto_stream(const float* __restrict__ rows, long ld, int D, c
         float4 acc[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (d < D) {
+        const bool act = d < D;       // lanes beyond D only take part in the ballots / broadcasts
+        {
             // this wave's 64 pixels are wave + 4*i; lane i holds the class bits of pixel i of that set
             const long pmine = p0 + wave + 4 * lane;
             const unsigned mybits = pmine < P ? lowbits[pmine] : 0u;
@@ -245,7 +246,7 @@ __global__ void k_proto_stream(const float* __restrict__ rows, long ld, int D, c
                 unsigned bits[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {   // unconditional loads (sel[u] = 0 is a valid pixel of the set)
-                    v[u] = *(const float4*)(rows + (p0 + wave + 4 * (long)sel[u]) * ld + d);
+                    v[u] = act ? *(const float4*)(rows + (p0 + wave + 4 * (long)sel[u]) * ld + d) : make_float4(0.f, 0.f, 0.f, 0.f);
                     bits[u] = u < nsel ? __shfl(mybits, sel[u], 64) : 0u;
                 }
 #pragma unroll
@@ -256,8 +257,10 @@ __global__ void k_proto_stream(const float* __restrict__ rows, long ld, int D, c
                             acc[c].x += v[u].x; acc[c].y += v[u].y; acc[c].z += v[u].z; acc[c].w += v[u].w;
                         }
             }
+            if (act) {
 #pragma unroll
-            for (int c = 0; c < CT; ++c) *(float4*)(red + ((long)wave * CT + c) * D + d) = acc[c];
+                for (int c = 0; c < CT; ++c) *(float4*)(red + ((long)wave * CT + c) * D + d) = acc[c];
+            }
         }
         __syncthreads();
         for (int i = threadIdx.x; i < CT * D / 4; i += blockDim.x) {

@@ -331,6 +331,90 @@ __global__ __launch_bounds__(64, 1) void k_entropy_up_cell(const float* __restri
     hist0_flush(sh, cnt, ws);
 }
 
+// LDS-shared variant: a 256-thread block owns 64 consecutive cells; the 4 x CT corner logits of each cell are
+// fetched once by the block (thread t loads corner t/64 of cell t%64: CT loads per thread), parked in LDS
+// as [corner][class][cell] (conflict-free), then thread (cell, row a) produces the 4 pixels of output row a.
+// 4x the waves of the one-thread-per-cell kernel at the same global-load count.
+template <int CT>
+__global__ __launch_bounds__(256) void k_entropy_up_cell_lds(const float* __restrict__ in, long sn, long sc, long sh_,
+                                                             long sw, int N, int h, int w, int H, int W, float sy,
+                                                             float sx, const long long* __restrict__ label, int ignore,
+                                                             float* __restrict__ ent, unsigned* __restrict__ ws) {
+    constexpr int R = 4;
+    __shared__ unsigned sh[2048];
+    __shared__ float cv[4][CT][64];
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) sh[i] = 0;
+    const long ncell = (long)N * h * w;
+    const int cell = threadIdx.x & 63, part = threadIdx.x >> 6;
+    unsigned cnt = 0;
+    for (long base = (long)blockIdx.x * 64; base < ncell; base += (long)gridDim.x * 64) {
+        const long q = base + cell;
+        const bool live = q < ncell;
+        const long qq = live ? q : ncell - 1;
+        const int cj = (int)(qq % w);
+        const long t0 = qq / w;
+        const int ci = (int)(t0 % h), n = (int)(t0 / h);
+        const AcCoord cy0 = ac_coord(min(ci * R, H - 1), sy, h), cx0 = ac_coord(min(cj * R, W - 1), sx, w);
+        {   // corner `part` of this cell -> LDS
+            const int yy = (part & 2) ? cy0.i1 : cy0.i0, xx = (part & 1) ? cx0.i1 : cx0.i0;
+            const float* b = in + n * sn + yy * sh_ + xx * sw;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) cv[part][c][cell] = b[c * sc];
+        }
+        __syncthreads();
+        const int oy = ci * R + part, ox0 = cj * R;
+        if (live && oy < H) {
+            const AcCoord cy = ac_coord(oy, sy, h);
+            float lx0[R], lx1[R];
+#pragma unroll
+            for (int a = 0; a < R; ++a) {
+                const AcCoord cx = ac_coord(min(ox0 + a, W - 1), sx, w);
+                lx0[a] = cx.l0; lx1[a] = cx.l1;
+            }
+            float m[R], s[R], t[R], z[R];
+#pragma unroll
+            for (int bb = 0; bb < R; ++bb) { m[bb] = -INFINITY; s[bb] = 0.f; t[bb] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float v00 = cv[0][c][cell], v01 = cv[1][c][cell], v10 = cv[2][c][cell], v11 = cv[3][c][cell];
+#pragma unroll
+                for (int bb = 0; bb < R; ++bb) {
+                    const float top = __fmaf_rn(lx0[bb], v00, __fmul_rn(lx1[bb], v01));
+                    const float bot = __fmaf_rn(lx0[bb], v10, __fmul_rn(lx1[bb], v11));
+                    m[bb] = fmaxf(m[bb], __fmaf_rn(cy.l0, top, __fmul_rn(cy.l1, bot)));
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float v00 = cv[0][c][cell], v01 = cv[1][c][cell], v10 = cv[2][c][cell], v11 = cv[3][c][cell];
+#pragma unroll
+                for (int bb = 0; bb < R; ++bb) {
+                    const float top = __fmaf_rn(lx0[bb], v00, __fmul_rn(lx1[bb], v01));
+                    const float bot = __fmaf_rn(lx0[bb], v10, __fmul_rn(lx1[bb], v11));
+                    z[bb] = __fmaf_rn(cy.l0, top, __fmul_rn(cy.l1, bot)) - m[bb];
+                    const float e = expf(z[bb]);
+                    s[bb] += e;
+                    t[bb] += e * z[bb];
+                }
+            }
+            const int nx = min(R, W - ox0);
+            const long p0 = ((long)n * H + oy) * W + ox0;
+#pragma unroll
+            for (int bb = 0; bb < R; ++bb)
+                if (bb < nx) {
+                    float e = logf(s[bb]) - t[bb] / s[bb];
+                    const bool valid = label == nullptr || label[p0 + bb] != (long long)ignore;
+                    e = valid ? e : __uint_as_float(0x7fc00000u);
+                    ent[p0 + bb] = e;
+                    cnt += valid ? 1u : 0u;
+                    atomicAdd(&sh[f32_key(e) >> 21], 1u);
+                }
+        }
+        __syncthreads();
+    }
+    hist0_flush(sh, cnt, ws);
+}
+
 U2PL_API int u2pl_entropy_up_f32(const float* in, long sn, long sc, long sh, long sw, int N, int C, int h, int w,
                                  int H, int W, const long long* label, int ignore, float* entropy, unsigned* ws,
                                  hipStream_t stream) {
@@ -339,8 +423,18 @@ U2PL_API int u2pl_entropy_up_f32(const float* in, long sn, long sc, long sh, lon
     dim3 grid(grid_for(total, 256, 512)), block(256);
     const float sy = ac_scale_host(h, H), sx = ac_scale_host(w, W);
     if (h > 1 && w > 1 && H - 1 == 4 * (h - 1) && W - 1 == 4 * (w - 1) && (C == 19 || C == 21)) {
-        static int ry = 0;   // rows of a cell per thread: 1 (default), 2 or 4 (U2PL_ENTROPY_RY, tuning knob)
-        if (!ry) { const char* e = getenv("U2PL_ENTROPY_RY"); ry = e ? atoi(e) : 1; if (ry != 1 && ry != 2 && ry != 4) ry = 1; }
+        static int ry = 0;   // 0/unset: LDS-shared kernel (default); 1|2|4: rows of a cell per thread (register kernel)
+        if (!ry) { const char* e = getenv("U2PL_ENTROPY_RY"); ry = e ? atoi(e) : 8; if (ry != 1 && ry != 2 && ry != 4) ry = 8; }
+        if (ry == 8) {
+            const long ncell8 = (long)N * h * w;
+            dim3 lg(grid_for(ncell8, 64, 2048)), lb(256);
+            if (C == 19)
+                hipLaunchKernelGGL(k_entropy_up_cell_lds<19>, lg, lb, 0, stream, in, sn, sc, sh, sw, N, h, w, H, W, sy, sx, label, ignore, entropy, ws);
+            else
+                hipLaunchKernelGGL(k_entropy_up_cell_lds<21>, lg, lb, 0, stream, in, sn, sc, sh, sw, N, h, w, H, W, sy, sx, label, ignore, entropy, ws);
+            U2PL_LAUNCH_CHECK();
+            return 0;
+        }
         const long nwork = (long)N * h * w * (4 / ry);
         dim3 cgrid(grid_for(nwork, 64, 8192)), cblock(64);
 #define ENT_CASE(CC, RR)                                                                                       \

@@ -213,7 +213,7 @@ U2PL_API int u2pl_compact_lists(const unsigned* abits, const unsigned* lowbits, 
 // registers (class loop fully unrolled and predicated), combined across the 4 waves through LDS in a
 // fixed order => deterministic.
 template <int CT>
-__global__ void k_proto_stream(const float* __restrict__ rows, long ld, int D, const unsigned* __restrict__ lowbits,
+__global__ __launch_bounds__(256, 2) void k_proto_stream(const float* __restrict__ rows, long ld, int D, const unsigned* __restrict__ lowbits,
                                long P, float* __restrict__ partial) {
     extern __shared__ float red[];   // [4][CT][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

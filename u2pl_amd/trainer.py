@@ -141,25 +141,31 @@ class SemiTrainer:
         else:
             if epoch == self.sup_only_epoch:  # Q6: teacher params alias the student's
                 self.t_arena.copy_from(self.arena)
-            # pseudo labels (train_semi.py:317-324)
+            unsup_cfg = cfg["trainer"]["unsupervised"]
+            main = torch.cuda.current_stream()
+            side = self._side_stream()
+            side.wait_stream(main)
+            # Both teacher passes run on a SIDE HIP stream, concurrently with the student forward (they do not
+            # depend on it): their memory-bound BN passes and kernel tails fill the bubbles of the student's
+            # MFMA-bound convs.  Results and RNG draw order are unchanged.
+            # (1) pseudo labels (train_semi.py:317-324), eval mode
             teacher.eval()
-            with torch.no_grad():
+            with torch.cuda.stream(side), torch.no_grad():
                 pred_u_t = teacher(image_u, need_aux=False, need_rep=False)["pred"]
                 conf_u, label_u_aug = H.pseudo_label(H.bilinear_up(pred_u_t, (h, w)))
-            unsup_cfg = cfg["trainer"]["unsupervised"]
-            # strong augmentation (train_semi.py:326-337): host coin flip + host rectangle draws
+            # strong augmentation (train_semi.py:326-337): host coin flip + host rectangle draws.  The IMAGE mix
+            # needs only the boxes, so it is issued on the main stream right away; labels are mixed on the side.
             image_u_aug = image_u
             if np.random.uniform(0, 1) < 0.5 and unsup_cfg.get("apply_aug", False):
                 assert unsup_cfg["apply_aug"] == "cutmix", "only cutmix is wired to a HIP kernel"
                 boxes = cutmix_boxes if cutmix_boxes is not None else generate_cutmix_boxes(B, h, w)
-                image_u_aug, label_u_aug, conf_u = cutmix(image_u, label_u_aug, conf_u, boxes)
-            image_all = torch.cat((image_l, image_u_aug))
-            # teacher train-mode forward (train_semi.py:360-374) on a SIDE HIP stream: it is independent of
-            # the student forward, so its memory-bound BN passes and kernel tails overlap the student's
-            # MFMA-bound convs (both streams feed the same GPU; order of results is unaffected)
-            main = torch.cuda.current_stream()
-            side = self._side_stream()
-            side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    image_u_aug, label_u_aug, conf_u = cutmix(image_u, label_u_aug, conf_u, boxes)
+                    image_all = torch.cat((image_l, image_u_aug))
+            else:
+                with torch.cuda.stream(side):
+                    image_all = torch.cat((image_l, image_u_aug))
+            # (2) teacher train-mode forward (train_semi.py:360-374)
             teacher.train()
             with torch.cuda.stream(side), torch.no_grad():
                 out_t = teacher(image_all, need_aux=False)
@@ -168,8 +174,14 @@ class SemiTrainer:
                 pt, ldp = K.as_rows(pred_all_t)
                 Cn = pred_all_t.shape[1]
                 K.call("u2pl_softmax_rows_f32", pt, ldp, prob_all_t, Cn, pt.shape[0] * pt.shape[2] * pt.shape[3], Cn)
+            # the student's input is rebuilt on the main stream from the same boxes (no cross-stream wait needed)
+            if image_u_aug is not image_u:
+                image_u_main, _, _ = cutmix(image_u, label_u_aug.new_zeros(label_u_aug.shape), conf_u.new_zeros(conf_u.shape), boxes)
+                image_all_s = torch.cat((image_l, image_u_main))
+            else:
+                image_all_s = torch.cat((image_l, image_u))
             # student forward (train_semi.py:339-358)
-            outs = model(image_all)
+            outs = model(image_all_s)
             pred_all, rep_all = outs["pred"], outs["rep"]
             pred_l_large = H.bilinear_up(pred_all[:B], (h, w))
             pred_u_large = H.bilinear_up(pred_all[B:], (h, w))
@@ -180,9 +192,10 @@ class SemiTrainer:
                 sup_loss = self.sup_loss_fn(pred_l_large, label_l.clone())
             main.wait_stream(side)
             if side is not main:
-                for t_ in (pred_all_t, rep_all_t, prob_all_t):
+                for t_ in (pred_all_t, rep_all_t, prob_all_t, label_u_aug, conf_u):
                     t_.record_stream(main)   # allocated on the side stream, consumed on the main stream
-                image_all.record_stream(side)  # allocated on the main stream, read on the side stream
+                for t_ in (image_u, image_l):
+                    t_.record_stream(side)   # allocated on the main stream, read on the side stream
             with torch.no_grad():
                 # one fused pass: bilinear up-sampling + entropy + valid count + select histogram, then ONE
                 # exact selection for all three percentiles (drop_percent, alpha_t, 100 - alpha_t)

@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--arch", default="resnet101")
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sharpen", type=float, default=40.0,
+    ap.add_argument("--sharpen", type=float, default=4.0,
                     help="scale of the random-init classifier's last layer (student+teacher): random-init logits are "
                          "near-uniform, which would leave the contrastive path (anchors need p>0.3) idle")
     ap.add_argument("--no-bank-prefill", action="store_true")

@@ -71,7 +71,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
     const int wm = wave >> 1, wn = wave & 1;
     const long M = m_end;  // this launch covers output rows [m_begin, m_end)
     const int K = g.R * g.S * g.Cin;
-    const int nk = K / BK;
     const int cpt = g.Cin / BK;  // chunks per tap
     // M tiles fastest: concurrently resident blocks share the same weight tile (L2 reuse)
     const long m0 = m_begin + (long)blockIdx.x * BM;
@@ -96,9 +95,44 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
     }
     float4 ra[RA], rb[RB];
     const int ldxb = (int)ldx * 4;
-    auto load_chunk = [&](int kc) {
-        const int tap = kc / cpt, c0 = (kc - tap * cpt) * BK;
+    // Taps whose gather is out of the image for EVERY row of this tile multiply only padding zeros
+    // (dilated ASPP / layer4 convs near the top and bottom image borders): skip their K chunks.
+    unsigned tapmask = 0;
+    if (g.R * g.S > 1) {
+        for (int r = 0; r < g.R; ++r) {
+            int any_r = 0;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                int t_;
+                any_r |= (int)(mv[i] & gather_coord(bh[i], r, g.step, g.log2div, g.Hin, t_));
+            }
+            any_r = __syncthreads_or(any_r);
+            for (int s2 = 0; s2 < g.S; ++s2) {
+                int any_s = 0;
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    int t_;
+                    any_s |= (int)(mv[i] & gather_coord(bw[i], s2, g.step, g.log2div, g.Win, t_));
+                }
+                any_s = __syncthreads_or(any_s);
+                if (any_r && any_s) tapmask |= 1u << (r * g.S + s2);
+            }
+        }
+        if (tapmask == 0) tapmask = 1u;   // degenerate tile (no valid row): keep one chunk series of zeros
+    } else {
+        tapmask = 1u;
+    }
+    const int nk_live = __popc(tapmask) * cpt;
+    int ltap = __ffs(tapmask) - 1, lc = 0;     // next chunk to load (wave-uniform scalar state)
+    auto load_chunk = [&]() {
+        const int tap = ltap, c0 = lc * BK;
+        const int kc = tap * cpt + lc;
         const int r = tap / g.S, s = tap - r * g.S;
+        if (++lc == cpt) {
+            lc = 0;
+            const unsigned rem = tapmask >> (ltap + 1);
+            ltap = rem ? ltap + __ffs(rem) : ltap;
+        }
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             int ih, iw;
@@ -129,13 +163,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    load_chunk(0);
+    load_chunk();
     store_chunk(0);
     __syncthreads();
     const int li = lane & 31, lh = lane >> 5;
-    for (int kc = 0; kc < nk; ++kc) {
+    for (int kc = 0; kc < nk_live; ++kc) {
         const int buf = kc & 1;
-        if (kc + 1 < nk) load_chunk(kc + 1);
+        if (kc + 1 < nk_live) load_chunk();
         const float* Ab = As + ((long)buf * BM + wm * 32 * TM + li) * LDP + 4 * lh;
         const float* Bb = Bs + ((long)buf * BN + wn * 32 * TN + li) * LDP + 4 * lh;
 #pragma unroll
@@ -156,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
                     }
         }
-        if (kc + 1 < nk) store_chunk(buf ^ 1);
+        if (kc + 1 < nk_live) store_chunk(buf ^ 1);
         __syncthreads();
     }
     // epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -346,13 +380,40 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
     const int li = lane & 31, lh = lane >> 5;
-    if (c_begin < c_end) {
-        load_chunk(c_begin);
+    // Pixel chunks whose 32 pixels are ALL out of the image for this block's tap (r, s) contribute nothing
+    // (dilated convs near the borders): they are skipped without loading.  Valid output-coordinate
+    // intervals of the tap (stride == g.mul > 0):  lo <= o <= hi  <=>  0 <= o*mul + off + tap*step < size
+    auto interval = [&](int off, int tap, int size, int& lo, int& hi) {
+        const int base = off + tap * g.step;            // o*mul + base in [0, size)
+        lo = base >= 0 ? 0 : (-base + g.mul - 1) / g.mul;
+        hi = (size - 1 - base) >= 0 ? (size - 1 - base) / g.mul : -1;
+    };
+    int ylo, yhi, xlo, xhi;
+    interval(g.off_h, r, g.Hin, ylo, yhi);
+    interval(g.off_w, s, g.Win, xlo, xhi);
+    auto dead = [&](long ch) -> bool {
+        const long ma = ch * BK, mb = min(ma + BK, M) - 1;
+        const int woa = (int)(ma % g.Wout), wob = (int)(mb % g.Wout);
+        const long ta = ma / g.Wout, tb = mb / g.Wout;
+        const int hoa = (int)(ta % g.Hout), hob = (int)(tb % g.Hout);
+        if (ta / g.Hout != tb / g.Hout) return false;              // spans two images: keep
+        if (hob < ylo || hoa > yhi) return true;                    // every row of the chunk is out in y
+        if (ta == tb) return wob < xlo || woa > xhi;                // single row: out in x
+        return false;
+    };
+    auto next_live = [&](long ch) -> long {
+        while (ch < c_end && dead(ch)) ++ch;
+        return ch;
+    };
+    long cur = next_live(c_begin);
+    if (cur < c_end) {
+        load_chunk(cur);
         store_chunk(0);
         __syncthreads();
-        for (long ch = c_begin; ch < c_end; ++ch) {
-            const int buf = (int)((ch - c_begin) & 1);
-            if (ch + 1 < c_end) load_chunk(ch + 1);
+        int buf = 0;
+        while (cur < c_end) {
+            const long nxt = next_live(cur + 1);
+            if (nxt < c_end) load_chunk(nxt);
             const float* Ab = As + (long)buf * BK * PA + wm * 32 * TM + li;
             const float* Bb = Bs + (long)buf * BK * PB + wn * 32 * TN + li;
 #pragma unroll
@@ -368,8 +429,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const float* __restrict__
                     for (int b = 0; b < TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
             }
-            if (ch + 1 < c_end) store_chunk(buf ^ 1);
+            if (nxt < c_end) store_chunk(buf ^ 1);
             __syncthreads();
+            buf ^= 1;
+            cur = nxt;
         }
     }
     // partial slab [split][Cout][R*S*Cin]

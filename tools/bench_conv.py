@@ -7,7 +7,7 @@ from u2pl_amd import nn as K
 DEV = "cuda"
 SHAPES = [  # N, Cin, Cout, k, dil, H
     (4, 256, 256, 3, 2, 97), (4, 512, 256, 3, 1, 193), (4, 1024, 256, 1, 1, 97), (4, 256, 1024, 1, 1, 97),
-    (4, 2048, 256, 3, 12, 97), (2, 256, 256, 3, 2, 97), (4, 64, 64, 3, 1, 385), (4, 128, 128, 3, 1, 193),
+    (4, 2048, 256, 3, 12, 97), (4, 2048, 256, 3, 36, 97), (2, 256, 256, 3, 2, 97), (4, 64, 64, 3, 1, 385), (4, 128, 128, 3, 1, 193),
 ]
 reps = int(os.environ.get("REPS", "10"))
 out = []

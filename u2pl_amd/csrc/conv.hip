@@ -29,7 +29,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct ConvGeom {
     int N, Hin, Win, Cin, Hout, Wout, Cout, R, S;
     int mul, off_h, off_w, step, log2div;  // gather: (o*mul + off + r*step) >> log2div
+    int skip;  // host hint: the dilation reach is a sizeable fraction of the image -> look for all-padding taps
 };
+
+static int skip_hint(int R, int dil, int H) { return R > 1 && dil * (R / 2) * 8 >= H; }
 
 // Masked gathers without branches or selects on data: every global read is a raw buffer load
 // (buffer_load_dwordx4 ... offen) through a descriptor whose num_records is the byte size of the
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
     // Taps whose gather is out of the image for EVERY row of this tile multiply only padding zeros
     // (dilated ASPP / layer4 convs near the top and bottom image borders): skip their K chunks.
     unsigned tapmask = 0;
-    if (g.R * g.S > 1) {
+    if (g.skip) {
         for (int r = 0; r < g.R; ++r) {
             int any_r = 0;
 #pragma unroll
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
         }
         if (tapmask == 0) tapmask = 1u;   // degenerate tile (no valid row): keep one chunk series of zeros
     } else {
-        tapmask = 1u;
+        tapmask = (1u << (g.R * g.S)) - 1u;
     }
     const int nk_live = __popc(tapmask) * cpt;
     int ltap = __ffs(tapmask) - 1, lc = 0;     // next chunk to load (wave-uniform scalar state)
@@ -271,7 +274,7 @@ static int run_igemm(const float* x, long ldx, const float* w, const float* bias
 U2PL_API int u2pl_conv2d_fwd_f32(const float* x, long ldx, const float* w, const float* bias, float* y,
                                  long ldy, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
                                  int R, int S, int stride, int pad, int dil, hipStream_t stream) {
-    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
+    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0, skip_hint(R, dil, Hin)};
     return run_igemm(x, ldx, w, bias, y, ldy, g, stream);
 }
 
@@ -283,7 +286,7 @@ U2PL_API int u2pl_conv2d_dgrad_f32(const float* dy, long lddy, const float* wT, 
     int l2 = log2_exact(stride);
     if (l2 < 0) return U2PL_EINVAL;
     // roles swap: the "input" of the gather is dY (Hout x Wout x Cout), the output is dX
-    ConvGeom g = {N, Hout, Wout, Cout, Hin, Win, Cin, R, S, 1, pad, pad, -dil, l2};
+    ConvGeom g = {N, Hout, Wout, Cout, Hin, Win, Cin, R, S, 1, pad, pad, -dil, l2, skip_hint(R, dil, Hin)};
     return run_igemm(dy, lddy, wT, nullptr, dx, lddx, g, stream);
 }
 
@@ -402,7 +405,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const float* __restrict__
         return false;
     };
     auto next_live = [&](long ch) -> long {
-        while (ch < c_end && dead(ch)) ++ch;
+        if (g.skip)
+            while (ch < c_end && dead(ch)) ++ch;
         return ch;
     };
     long cur = next_live(c_begin);
@@ -477,7 +481,7 @@ static void wgrad_plan(const ConvGeom& g, int BM, int BN, int& ctiles, int& nspl
 }
 
 U2PL_API size_t u2pl_conv2d_wgrad_workspace_bytes(int N, int Hout, int Wout, int Cin, int Cout, int R, int S) {
-    ConvGeom g = {N, 0, 0, Cin, Hout, Wout, Cout, R, S, 1, 0, 0, 1, 0};
+    ConvGeom g = {N, 0, 0, Cin, Hout, Wout, Cout, R, S, 1, 0, 0, 1, 0, 0};
     int ct, ns, cps;
     wgrad_plan(g, Cout > 64 ? 128 : 64, Cin > 64 ? 128 : 64, ct, ns, cps);
     return (size_t)ns * Cout * R * S * Cin * sizeof(float);
@@ -509,7 +513,7 @@ U2PL_API int u2pl_conv2d_wgrad_f32(const float* dy, long lddy, const float* x, l
                                    int Wout, int Cout, int R, int S, int stride, int pad, int dil,
                                    hipStream_t stream) {
     if (Cin % 4 || Cout % 4) return U2PL_EINVAL;
-    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
+    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0, skip_hint(R, dil, Hin)};
     const int BM = Cout > 64 ? 128 : 64, BN = Cin > 64 ? 128 : 64;
     int ct, ns, cps;
     wgrad_plan(g, BM, BN, ct, ns, cps);
@@ -555,7 +559,7 @@ __global__ void k_im2col(const float* __restrict__ x, long ldx, float* __restric
 }
 U2PL_API int u2pl_im2col_f32(const float* x, long ldx, float* col, int Kp, int N, int Hin, int Win, int Cin,
                              int Hout, int Wout, int R, int S, int stride, int pad, int dil, hipStream_t stream) {
-    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, 0, R, S, stride, -pad, -pad, dil, 0};
+    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, 0, R, S, stride, -pad, -pad, dil, 0, 0};
     const long total = (long)N * Hout * Wout * Kp;
     hipLaunchKernelGGL(k_im2col, dim3(grid_for(total, 256, 1 << 16)), dim3(256), 0, stream, x, ldx, col, g, Kp);
     U2PL_LAUNCH_CHECK();

@@ -29,10 +29,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct ConvGeom {
     int N, Hin, Win, Cin, Hout, Wout, Cout, R, S;
     int mul, off_h, off_w, step, log2div;  // gather: (o*mul + off + r*step) >> log2div
-    int skip;  // host hint: the dilation reach is a sizeable fraction of the image -> look for all-padding taps
 };
-
-static int skip_hint(int R, int dil, int H) { return R > 1 && dil * (R / 2) * 8 >= H; }
 
 // Masked gathers without branches or selects on data: every global read is a raw buffer load
 // (buffer_load_dwordx4 ... offen) through a descriptor whose num_records is the byte size of the
@@ -74,6 +71,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
     const int wm = wave >> 1, wn = wave & 1;
     const long M = m_end;  // this launch covers output rows [m_begin, m_end)
     const int K = g.R * g.S * g.Cin;
+    const int nk = K / BK;
     const int cpt = g.Cin / BK;  // chunks per tap
     // M tiles fastest: concurrently resident blocks share the same weight tile (L2 reuse)
     const long m0 = m_begin + (long)blockIdx.x * BM;
@@ -98,44 +96,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
     }
     float4 ra[RA], rb[RB];
     const int ldxb = (int)ldx * 4;
-    // Taps whose gather is out of the image for EVERY row of this tile multiply only padding zeros
-    // (dilated ASPP / layer4 convs near the top and bottom image borders): skip their K chunks.
-    unsigned tapmask = 0;
-    if (g.skip) {
-        for (int r = 0; r < g.R; ++r) {
-            int any_r = 0;
-#pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                int t_;
-                any_r |= (int)(mv[i] & gather_coord(bh[i], r, g.step, g.log2div, g.Hin, t_));
-            }
-            any_r = __syncthreads_or(any_r);
-            for (int s2 = 0; s2 < g.S; ++s2) {
-                int any_s = 0;
-#pragma unroll
-                for (int i = 0; i < RA; ++i) {
-                    int t_;
-                    any_s |= (int)(mv[i] & gather_coord(bw[i], s2, g.step, g.log2div, g.Win, t_));
-                }
-                any_s = __syncthreads_or(any_s);
-                if (any_r && any_s) tapmask |= 1u << (r * g.S + s2);
-            }
-        }
-        if (tapmask == 0) tapmask = 1u;   // degenerate tile (no valid row): keep one chunk series of zeros
-    } else {
-        tapmask = (1u << (g.R * g.S)) - 1u;
-    }
-    const int nk_live = __popc(tapmask) * cpt;
-    int ltap = __ffs(tapmask) - 1, lc = 0;     // next chunk to load (wave-uniform scalar state)
-    auto load_chunk = [&]() {
-        const int tap = ltap, c0 = lc * BK;
-        const int kc = tap * cpt + lc;
+    auto load_chunk = [&](int kc) {
+        const int tap = kc / cpt, c0 = (kc - tap * cpt) * BK;
         const int r = tap / g.S, s = tap - r * g.S;
-        if (++lc == cpt) {
-            lc = 0;
-            const unsigned rem = tapmask >> (ltap + 1);
-            ltap = rem ? ltap + __ffs(rem) : ltap;
-        }
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             int ih, iw;
@@ -166,13 +129,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    load_chunk();
+    load_chunk(0);
     store_chunk(0);
     __syncthreads();
     const int li = lane & 31, lh = lane >> 5;
-    for (int kc = 0; kc < nk_live; ++kc) {
+    for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
-        if (kc + 1 < nk_live) load_chunk();
+        if (kc + 1 < nk) load_chunk(kc + 1);
         const float* Ab = As + ((long)buf * BM + wm * 32 * TM + li) * LDP + 4 * lh;
         const float* Bb = Bs + ((long)buf * BN + wn * 32 * TN + li) * LDP + 4 * lh;
 #pragma unroll
@@ -193,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
                     }
         }
-        if (kc + 1 < nk_live) store_chunk(buf ^ 1);
+        if (kc + 1 < nk) store_chunk(buf ^ 1);
         __syncthreads();
     }
     // epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -274,7 +237,7 @@ static int run_igemm(const float* x, long ldx, const float* w, const float* bias
 U2PL_API int u2pl_conv2d_fwd_f32(const float* x, long ldx, const float* w, const float* bias, float* y,
                                  long ldy, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
                                  int R, int S, int stride, int pad, int dil, hipStream_t stream) {
-    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0, skip_hint(R, dil, Hin)};
+    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
     return run_igemm(x, ldx, w, bias, y, ldy, g, stream);
 }
 
@@ -286,7 +249,7 @@ U2PL_API int u2pl_conv2d_dgrad_f32(const float* dy, long lddy, const float* wT, 
     int l2 = log2_exact(stride);
     if (l2 < 0) return U2PL_EINVAL;
     // roles swap: the "input" of the gather is dY (Hout x Wout x Cout), the output is dX
-    ConvGeom g = {N, Hout, Wout, Cout, Hin, Win, Cin, R, S, 1, pad, pad, -dil, l2, skip_hint(R, dil, Hin)};
+    ConvGeom g = {N, Hout, Wout, Cout, Hin, Win, Cin, R, S, 1, pad, pad, -dil, l2};
     return run_igemm(dy, lddy, wT, nullptr, dx, lddx, g, stream);
 }
 
@@ -383,41 +346,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
     const int li = lane & 31, lh = lane >> 5;
-    // Pixel chunks whose 32 pixels are ALL out of the image for this block's tap (r, s) contribute nothing
-    // (dilated convs near the borders): they are skipped without loading.  Valid output-coordinate
-    // intervals of the tap (stride == g.mul > 0):  lo <= o <= hi  <=>  0 <= o*mul + off + tap*step < size
-    auto interval = [&](int off, int tap, int size, int& lo, int& hi) {
-        const int base = off + tap * g.step;            // o*mul + base in [0, size)
-        lo = base >= 0 ? 0 : (-base + g.mul - 1) / g.mul;
-        hi = (size - 1 - base) >= 0 ? (size - 1 - base) / g.mul : -1;
-    };
-    int ylo, yhi, xlo, xhi;
-    interval(g.off_h, r, g.Hin, ylo, yhi);
-    interval(g.off_w, s, g.Win, xlo, xhi);
-    auto dead = [&](long ch) -> bool {
-        const long ma = ch * BK, mb = min(ma + BK, M) - 1;
-        const int woa = (int)(ma % g.Wout), wob = (int)(mb % g.Wout);
-        const long ta = ma / g.Wout, tb = mb / g.Wout;
-        const int hoa = (int)(ta % g.Hout), hob = (int)(tb % g.Hout);
-        if (ta / g.Hout != tb / g.Hout) return false;              // spans two images: keep
-        if (hob < ylo || hoa > yhi) return true;                    // every row of the chunk is out in y
-        if (ta == tb) return wob < xlo || woa > xhi;                // single row: out in x
-        return false;
-    };
-    auto next_live = [&](long ch) -> long {
-        if (g.skip)
-            while (ch < c_end && dead(ch)) ++ch;
-        return ch;
-    };
-    long cur = next_live(c_begin);
-    if (cur < c_end) {
-        load_chunk(cur);
+    if (c_begin < c_end) {
+        load_chunk(c_begin);
         store_chunk(0);
         __syncthreads();
-        int buf = 0;
-        while (cur < c_end) {
-            const long nxt = next_live(cur + 1);
-            if (nxt < c_end) load_chunk(nxt);
+        for (long ch = c_begin; ch < c_end; ++ch) {
+            const int buf = (int)((ch - c_begin) & 1);
+            if (ch + 1 < c_end) load_chunk(ch + 1);
             const float* Ab = As + (long)buf * BK * PA + wm * 32 * TM + li;
             const float* Bb = Bs + (long)buf * BK * PB + wn * 32 * TN + li;
 #pragma unroll
@@ -433,10 +368,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const float* __restrict__
                     for (int b = 0; b < TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
             }
-            if (nxt < c_end) store_chunk(buf ^ 1);
+            if (ch + 1 < c_end) store_chunk(buf ^ 1);
             __syncthreads();
-            buf ^= 1;
-            cur = nxt;
         }
     }
     // partial slab [split][Cout][R*S*Cin]
@@ -481,7 +414,7 @@ static void wgrad_plan(const ConvGeom& g, int BM, int BN, int& ctiles, int& nspl
 }
 
 U2PL_API size_t u2pl_conv2d_wgrad_workspace_bytes(int N, int Hout, int Wout, int Cin, int Cout, int R, int S) {
-    ConvGeom g = {N, 0, 0, Cin, Hout, Wout, Cout, R, S, 1, 0, 0, 1, 0, 0};
+    ConvGeom g = {N, 0, 0, Cin, Hout, Wout, Cout, R, S, 1, 0, 0, 1, 0};
     int ct, ns, cps;
     wgrad_plan(g, Cout > 64 ? 128 : 64, Cin > 64 ? 128 : 64, ct, ns, cps);
     return (size_t)ns * Cout * R * S * Cin * sizeof(float);
@@ -513,7 +446,7 @@ U2PL_API int u2pl_conv2d_wgrad_f32(const float* dy, long lddy, const float* x, l
                                    int Wout, int Cout, int R, int S, int stride, int pad, int dil,
                                    hipStream_t stream) {
     if (Cin % 4 || Cout % 4) return U2PL_EINVAL;
-    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0, skip_hint(R, dil, Hin)};
+    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
     const int BM = Cout > 64 ? 128 : 64, BN = Cin > 64 ? 128 : 64;
     int ct, ns, cps;
     wgrad_plan(g, BM, BN, ct, ns, cps);
@@ -559,7 +492,7 @@ __global__ void k_im2col(const float* __restrict__ x, long ldx, float* __restric
 }
 U2PL_API int u2pl_im2col_f32(const float* x, long ldx, float* col, int Kp, int N, int Hin, int Win, int Cin,
                              int Hout, int Wout, int R, int S, int stride, int pad, int dil, hipStream_t stream) {
-    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, 0, R, S, stride, -pad, -pad, dil, 0, 0};
+    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, 0, R, S, stride, -pad, -pad, dil, 0};
     const long total = (long)N * Hout * Wout * Kp;
     hipLaunchKernelGGL(k_im2col, dim3(grid_for(total, 256, 1 << 16)), dim3(256), 0, stream, x, ldx, col, g, Kp);
     U2PL_LAUNCH_CHECK();

@@ -60,6 +60,12 @@ def main():
     args = parse()
     from u2pl_amd import configs
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # convenience: re-launch ourselves one rank per GPU (the driver calls torch.distributed.run directly)
+        import subprocess
+        port = 29500 + os.getpid() % 2000
+        sys.exit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port)] + sys.argv))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -116,9 +122,14 @@ def main():
     ms = dt / args.steps * 1e3
     imgs = world * 2 * args.batch
     value = imgs / (ms / 1e3)
-    if rank == 0:
-        from u2pl_amd import roofline as RL
+    from u2pl_amd import roofline as RL
 
+    # the roofline leg runs ONE extra (un-timed) step with per-call HIP events; it contains the step's
+    # collectives, so every rank executes it
+    roof = RL.measure(trainer, batches[0], args, ms)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
         out = {
             "metric": "train images/sec at 769x769 (R101-DeepLabv3+)", "value": round(value, 4), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -130,8 +141,8 @@ def main():
                        "global_batch": imgs, "parallelism": f"dp{world}"},
             "losses_last_step": [round(float(x), 5) for x in meters.cpu()],
         }
-        out.update(RL.measure(trainer, batches[0], args, ms))
-        if not args.no_cpu_baseline:
+        out.update(roof)
+        if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N=1 only
             out["cpu_baseline"] = RL.cpu_baseline(args)
         print(json.dumps(out))
     if world > 1:

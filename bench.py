@@ -70,11 +70,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == args.gpus or world == 1, (world, args.gpus)
+    ndev = max(torch.cuda.device_count(), 1)
+    local_rank %= ndev   # (tests share one GPU between two gloo ranks; production: one GPU per rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm; U2PL_DIST_BACKEND=gloo only for the shared-GPU functional test
+        dist.init_process_group(os.environ.get("U2PL_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
     from u2pl_amd.models.model_helper import ModelBuilder
     from u2pl_amd.trainer import SemiTrainer

@@ -104,3 +104,22 @@ def test_two_rank_training_keeps_replicas_and_banks_identical():
     assert r0["w"] == r1["w"] and r0["w2"] == r1["w2"] and r0["t"] == r1["t"]   # weights stay replicated bit-for-bit
     assert r0["bank_len"] == r1["bank_len"] and r0["bank_sum"] == r1["bank_sum"] and sum(r0["bank_len"]) > 0
     assert r0["rm"] == r1["rm"]                                  # SyncBN running stats identical
+
+
+def test_bench_two_ranks_runs_and_reports_weak_scaling_line():
+    """bench.py under torch.distributed.run with 2 ranks (gloo, shared GPU): no hang in the roofline leg,
+    one JSON line from rank 0 with the contract's keys."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, U2PL_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--arch", "resnet50", "--crop", "193"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8 and d["value"] > 0
+    assert "roofline" in d and "cpu_baseline" not in d

@@ -255,25 +255,34 @@ class DeviceMemoryBank:
         self._book(c, n_new)
 
     def append_multi(self, entries, ld):
-        """entries: [(class, rows tensor/ptr, n_new, int32 index list or None)] -> ONE launch."""
-        desc = np.zeros((len(entries), 6), dtype=np.int64)
+        """entries: [(class, rows tensor/ptr, n_new, int32 index list or None)] in FIFO order -> ONE launch.
+        Several entries may target the same class (rank-major blocks of an all-gather): each starts at the
+        tail left by the previous one."""
+        head, length = list(self.head), list(self.length)
+        per_class = {}
+        for c, _, n_new, _ in entries:
+            per_class[c] = per_class.get(c, 0) + n_new
+        if any(n > self.cap[c] for c, n in per_class.items()) and len(entries) > len(per_class):
+            for c, rows, n_new, idx_list in entries:   # wrap-around inside one launch would race: go sequentially
+                self.append_rows(c, rows, ld, n_new, idx_list)
+            return
+        desc = np.zeros((max(len(entries), 1), 6), dtype=np.int64)
         mx = 0
         for k, (c, rows, n_new, idx_list) in enumerate(entries):
             cap = self.cap[c]
-            tail = (self.head[c] + self.length[c]) % cap
+            tail = (head[c] + length[c]) % cap
             desc[k] = (self.buf[c].data_ptr(), cap, tail, _lib._ptr(rows) or 0,
                        idx_list.data_ptr() if idx_list is not None else 0, n_new)
             mx = max(mx, min(n_new, cap))
+            if n_new > 0:
+                length[c] = min(length[c] + n_new, cap)
+                head[c] = ((tail + n_new) % cap - length[c]) % cap
         if mx > 0:
             dd = torch.from_numpy(desc).to(self.buf[0].device, non_blocking=True)
             call("u2pl_bank_append_multi_f32", dd, len(entries), self.D, ld, mx)
-        for c, rows, n_new, idx_list in entries:
-            if n_new > 0:
-                cap = self.cap[c]
-                tail = (self.head[c] + self.length[c]) % cap
-                self.length[c] = min(self.length[c] + n_new, cap)
-                self.head[c] = ((tail + n_new) % cap - self.length[c]) % cap
-            self._book(c, n_new)
+        self.head, self.length = head, length
+        for c, n in per_class.items():
+            self._book(c, n)
 
     def _book(self, c, bs):
         if self.length[c] >= self.cap[c]:

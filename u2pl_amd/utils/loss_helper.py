@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from .. import hipops as H
-from .utils import _world, dequeue_and_enqueue_device, gather_keys
+from .utils import enqueue_all_classes
 
 
 def compute_unsupervised_loss(predict, target, percent, pred_teacher):
@@ -59,13 +59,7 @@ def contra_memobank_core(rep, lbits, num_labeled, prob_l, prob_u, low_mask, high
                               num_labeled, C, h, w, cfg)
         counts = ph1.counts.cpu().numpy()  # the one host sync: RNG bounds live on the host (loss_helper.py:179-196)
         ph1.counts_host = counts
-        if _world() == 1:   # one launch appends every class's keys (row-major pixel order) to its ring
-            new_keys = [int(counts[2][i]) for i in range(C)]
-            memobank.append_multi([(i, rep_t_rows, new_keys[i], ph1.idx[2, i]) for i in range(C)], D)
-        else:
-            new_keys = []
-            for i in range(C):
-                new_keys.append(dequeue_and_enqueue_device(memobank, i, rep_t_rows, D, ph1.idx[2, i], int(counts[2][i])))
+        new_keys = enqueue_all_classes(memobank, rep_t_rows, D, ph1.idx[2], counts[2], C)
     valid_classes = [i for i in range(C) if counts[1][i] > 0]
     LAST_STATS.update(n_keys=int(sum(new_keys)), valid_seg=len(valid_classes), njobs=0,
                       Q=int(cfg["num_queries"]), K=int(cfg["num_negatives"]))

@@ -31,6 +31,47 @@ def gather_keys(keys):
     return torch.cat([o[:k] for o, k in zip(outs, ns)])
 
 
+def enqueue_all_classes(bank, rows, ld, idx, counts_c, C):
+    """dequeue_and_enqueue for every class of one step (loss_helper.py:143-150 -> utils.py:27-47) with ONE
+    count exchange and ONE padded key all-gather instead of a barrier + two object collectives per class.
+    idx[c]: int32 pixel list of class c, counts_c[c]: its length.  Returns the gathered batch size per class."""
+    W = _world()
+    D = bank.D
+    n_loc = [int(counts_c[c]) for c in range(C)]
+    if W == 1:
+        bank.append_multi([(c, rows, n_loc[c], idx[c]) for c in range(C)], ld)
+        return n_loc
+    dev = rows.device
+    tot = sum(n_loc)
+    cnt = torch.tensor(n_loc, dtype=torch.int64, device=dev)
+    cnts = [torch.zeros_like(cnt) for _ in range(W)]
+    dist.all_gather(cnts, cnt)
+    cnts = torch.stack(cnts).cpu().numpy()                 # [W][C] -- the single host sync of the exchange
+    m = int(cnts.sum(1).max())
+    if m == 0:
+        bank.append_multi([(c, rows, 0, None) for c in range(C)], D)
+        return [0] * C
+    pad = torch.zeros((m, D), dtype=torch.float32, device=dev)
+    off = 0
+    for c in range(C):                                       # class-major packing of this rank's keys
+        if n_loc[c]:
+            call("u2pl_gather_rows_f32", rows, ld, D, idx[c], n_loc[c], pad[off:])
+            off += n_loc[c]
+    outs = [torch.empty_like(pad) for _ in range(W)]
+    dist.all_gather(outs, pad)
+    offs = np.concatenate([np.zeros((W, 1), np.int64), np.cumsum(cnts, 1)[:, :-1]], 1)
+    entries = []
+    for c in range(C):                                       # rank-major order inside each class (utils.py:31-32)
+        for r in range(W):
+            n = int(cnts[r][c])
+            if n:
+                entries.append((c, outs[r][int(offs[r][c]):], n, None))
+        if not cnts[:, c].any():
+            entries.append((c, pad, 0, None))
+    bank.append_multi(entries, D)
+    return [int(x) for x in cnts.sum(0)]
+
+
 def dequeue_and_enqueue_device(bank, c, rows, ld, idx_list, n_local):
     """utils.py:27-47 on the device ring; returns the gathered batch size."""
     if _world() == 1:

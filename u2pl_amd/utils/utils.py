@@ -1,5 +1,6 @@
 """Host-side helpers with the reference's names (u2pl/utils/utils.py) for the
 pieces on the hot path: memory-bank enqueue with cross-rank key gather."""
+import numpy as np
 import torch
 import torch.distributed as dist
 

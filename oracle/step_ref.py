@@ -183,3 +183,24 @@ def timed_cpu_baseline(crop=769, arch="resnet101", batch=1):
             "sample": f"1 full U2PL step (teacher eval fwd, student fwd+bwd, teacher train fwd, OHEM+unsup+contrastive "
                       f"losses, SGD, EMA) of oracle/step_ref.py on {batch} labeled + {batch} unlabeled {crop}x{crop} "
                       f"crops ({arch}), torch-CPU fp32 with {ncores} threads + numpy; {dt:.1f} s"}
+
+
+def validate_ref(model, batches, num_classes, ignore=255):
+    """CPU restatement of validate() (train_semi.py:595-654, utils.py:568-580): bilinear up, argmax,
+    intersection / union histograms, mIoU = mean(I / (U + 1e-10))."""
+    model.eval()
+    inter = np.zeros(num_classes)
+    union = np.zeros(num_classes)
+    with torch.no_grad():
+        for images, labels in batches:
+            out = _up(model(images)["pred"], labels.shape[1:]).argmax(1).numpy()
+            tgt = labels.numpy()
+            out = np.where(tgt == ignore, ignore, out)
+            hit = out[out == tgt]
+            ai = np.bincount(hit[hit != ignore], minlength=num_classes)[:num_classes]
+            ao = np.bincount(out[out != ignore], minlength=num_classes)[:num_classes]
+            at = np.bincount(tgt[tgt != ignore], minlength=num_classes)[:num_classes]
+            inter += ai
+            union += ao + at - ai
+    iou = inter / (union + 1e-10)
+    return float(iou.mean()), iou

@@ -134,6 +134,15 @@ int u2pl_confusion_hist_f32(const float* logits_nchw, const long long* target, i
 int u2pl_conv2d_fwd_f32(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, int N,
                         int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S, int stride,
                         int pad, int dil, hipStream_t stream);
+/* forward + the train-mode BatchNorm statistics of its output in the conv epilogue (conv -> BN pairs:
+ * resnet.py:120-140, base.py:23-83, decoder.py:60-106): per-tile pivot-shifted sums, finished by
+ * u2pl_colreduce_finish_f32 */
+int u2pl_conv2d_fwd_stat_blocks(int N, int Hout, int Wout, int Cout);
+int u2pl_conv2d_fwd_bnstats_f32(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
+                                int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S,
+                                int stride, int pad, int dil, const float* pivot, float* stats_partial,
+                                hipStream_t stream);
+int u2pl_colreduce_finish_f32(const float* partial, int nblk, int C, double* sums, hipStream_t stream);
 /* autograd of nn.Conv2d under loss.backward() (train_semi.py:527): data and weight gradients */
 int u2pl_conv2d_dgrad_f32(const float* dy, long lddy, const float* wT, float* dx, long lddx, int N, int Hin,
                           int Win, int Cin, int Hout, int Wout, int Cout, int R, int S, int stride, int pad,

@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
                                                        long ldy, ConvGeom g, unsigned xbytes, unsigned wbytes,
-                                                       long m_begin, long m_end) {
+                                                       long m_begin, long m_end, float* __restrict__ stats,
+                                                       const float* __restrict__ pivot) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32, RB = BN / 32;  // rows per thread per chunk
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, xbytes), rw = make_rsrc(w, wbytes);
@@ -173,11 +174,49 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
                 if (m < M) y[m * ldy + co] = acc[a][b][e] + bv;
             }
         }
+    // Fused BatchNorm statistics (saves the separate read pass over y): per-tile pivot-shifted column sums
+    // S1 = sum(v - p), S2 = sum((v - p)^2) over the tile's valid rows, written in the two-stage column-reduce
+    // partial format [tile][2][Cout]; the ordered double-precision finish is k_colreduce_final.
+    if (stats) {
+        float* red = smem;   // [2 (wm)][2][BN]; the K loop's last barrier has passed, LDS is free
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int cl = wn * 32 * TN + b * 32 + li, co = n0 + cl;
+            const bool cv = co < g.Cout;
+            const float sh = (cv ? (bias ? bias[co] : 0.f) : 0.f) - (cv && pivot ? pivot[co] : 0.f);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const long m = m0 + wm * 32 * TM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const float v = m < M ? acc[a][b][e] + sh : 0.f;
+                    s1 += v;
+                    s2 += v * v;
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lh == 0) {
+                red[(wm * 2 + 0) * BN + cl] = s1;
+                red[(wm * 2 + 1) * BN + cl] = s2;
+            }
+        }
+        __syncthreads();
+        float* out = stats + (long)blockIdx.x * 2 * g.Cout;
+        for (int c = tid; c < BN; c += 256) {
+            const int co = n0 + c;
+            if (co < g.Cout) {
+                out[co] = red[0 * BN + c] + red[2 * BN + c];
+                out[g.Cout + co] = red[1 * BN + c] + red[3 * BN + c];
+            }
+        }
+    }
 }
 
 template <int TM, int TN>
 static int launch_igemm(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
-                        const ConvGeom& g, long m_begin, long m_end, hipStream_t stream) {
+                        const ConvGeom& g, long m_begin, long m_end, hipStream_t stream, float* stats = nullptr,
+                        const float* pivot = nullptr) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     if (m_end <= m_begin) return 0;
     const size_t lds = (size_t)2 * (BM + BN) * LDP * sizeof(float);
@@ -192,7 +231,7 @@ static int launch_igemm(const float* x, long ldx, const float* w, const float* b
     if (xb >= (1L << 31) || wb >= (1L << 31)) return U2PL_EINVAL;
     dim3 grid((unsigned)cdiv(m_end - m_begin, BM), (unsigned)cdiv(g.Cout, BN));
     hipLaunchKernelGGL((k_conv_igemm<TM, TN>), grid, dim3(256), lds, stream, x, ldx, w, bias, y, ldy, g, (unsigned)xb,
-                       (unsigned)wb, m_begin, m_end);
+                       (unsigned)wb, m_begin, m_end, stats, pivot);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -212,25 +251,40 @@ static double tail_cost(long rows, int cout, int bm, int bn, double eff) {
     const long nblk = (long)cdiv(rows, bm) * cdiv(cout, bn);
     return (double)cdiv(nblk, NUM_CUS) * bm * bn / eff;
 }
-static int run_igemm(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
-                     const ConvGeom& g, hipStream_t stream) {
-    if (g.Cin % BK) return U2PL_EINVAL;
+// the planner's decisions, shared by the launcher and by the stat-block query
+struct IgemmPlan { long m_body; int tail_tm, tail_tn; int nblk_body, nblk_tail; };
+static IgemmPlan plan_igemm(const ConvGeom& g) {
     const long M = (long)g.N * g.Hout * g.Wout;
-    if (g.Cout <= 64) return launch_igemm<2, 1>(x, ldx, w, bias, y, ldy, g, 0, M, stream);
+    IgemmPlan p = {M, 0, 0, 0, 0};
+    if (g.Cout <= 64) { p.nblk_body = cdiv(M, 128); return p; }   // single <2,1> launch
     const int nt = cdiv(g.Cout, 128);
     const long mtiles = cdiv(M, 128);
-    long body_tiles = (mtiles * nt / NUM_CUS) * NUM_CUS / nt;   // M tiles covered by whole rounds
+    long body_tiles = (mtiles * nt / NUM_CUS) * NUM_CUS / nt;      // M tiles covered by whole rounds
     if (body_tiles > mtiles) body_tiles = mtiles;
-    long m_body = body_tiles * 128;
-    if (m_body > M) m_body = M;
-    const long tail = M - m_body;
-    int rc = launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, 0, m_body, stream);
-    if (rc || tail <= 0) return rc;
+    p.m_body = body_tiles * 128 > M ? M : body_tiles * 128;
+    p.nblk_body = cdiv(p.m_body, 128);
+    const long tail = M - p.m_body;
+    if (tail <= 0) return p;
     const double c22 = tail_cost(tail, g.Cout, 128, 128, 1.0), c12 = tail_cost(tail, g.Cout, 64, 128, 0.9);
     const double c11 = tail_cost(tail, g.Cout, 64, 64, 0.8);
-    if (c22 <= c12 && c22 <= c11) return launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, m_body, M, stream);
-    if (c12 <= c11) return launch_igemm<1, 2>(x, ldx, w, bias, y, ldy, g, m_body, M, stream);
-    return launch_igemm<1, 1>(x, ldx, w, bias, y, ldy, g, m_body, M, stream);
+    if (c22 <= c12 && c22 <= c11) { p.tail_tm = 2; p.tail_tn = 2; }
+    else if (c12 <= c11) { p.tail_tm = 1; p.tail_tn = 2; }
+    else { p.tail_tm = 1; p.tail_tn = 1; }
+    p.nblk_tail = cdiv(tail, 64 * p.tail_tm);
+    return p;
+}
+static int run_igemm(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
+                     const ConvGeom& g, hipStream_t stream, float* stats = nullptr, const float* pivot = nullptr) {
+    if (g.Cin % BK) return U2PL_EINVAL;
+    const long M = (long)g.N * g.Hout * g.Wout;
+    const IgemmPlan p = plan_igemm(g);
+    if (g.Cout <= 64) return launch_igemm<2, 1>(x, ldx, w, bias, y, ldy, g, 0, M, stream, stats, pivot);
+    int rc = launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, 0, p.m_body, stream, stats, pivot);
+    if (rc || p.nblk_tail == 0) return rc;
+    float* st = stats ? stats + (long)p.nblk_body * 2 * g.Cout : nullptr;
+    if (p.tail_tm == 2) return launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot);
+    if (p.tail_tn == 2) return launch_igemm<1, 2>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot);
+    return launch_igemm<1, 1>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot);
 }
 
 // nn.Conv2d forward: resnet.py:25-41,178-186; base.py:23-83; decoder.py:60-106,132-138
@@ -239,6 +293,21 @@ U2PL_API int u2pl_conv2d_fwd_f32(const float* x, long ldx, const float* w, const
                                  int R, int S, int stride, int pad, int dil, hipStream_t stream) {
     ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
     return run_igemm(x, ldx, w, bias, y, ldy, g, stream);
+}
+
+// forward fused with the BatchNorm statistics of its output (train-mode conv -> BN pairs): also writes the
+// per-tile pivot-shifted column sums [nblk][2][Cout] (nblk = u2pl_conv2d_fwd_stat_blocks) to stats_partial
+U2PL_API int u2pl_conv2d_fwd_stat_blocks(int N, int Hout, int Wout, int Cout) {
+    ConvGeom g = {N, 0, 0, 32, Hout, Wout, Cout, 1, 1, 1, 0, 0, 1, 0};
+    const IgemmPlan p = plan_igemm(g);
+    return p.nblk_body + p.nblk_tail;
+}
+U2PL_API int u2pl_conv2d_fwd_bnstats_f32(const float* x, long ldx, const float* w, const float* bias, float* y,
+                                         long ldy, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
+                                         int R, int S, int stride, int pad, int dil, const float* pivot,
+                                         float* stats_partial, hipStream_t stream) {
+    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
+    return run_igemm(x, ldx, w, bias, y, ldy, g, stream, stats_partial, pivot);
 }
 
 // data gradient: dX[n,hi,wi,ci] = sum_{r,s,co} dY[n,(hi+pad-r*dil)/st,(wi+pad-s*dil)/st,co] * W[co][r][s][ci]

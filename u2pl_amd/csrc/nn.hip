@@ -143,6 +143,13 @@ static int run_colreduce(Op op, long Mseg, int nseg, int C, void* ws, double* ou
     return 0;
 }
 
+// ordered finish of externally produced partials (conv epilogue statistics): [nblk][2][C] float -> double [2][C]
+U2PL_API int u2pl_colreduce_finish_f32(const float* partial, int nblk, int C, double* sums, hipStream_t stream) {
+    hipLaunchKernelGGL(k_colreduce_final, dim3(cdiv(2 * C, 64), 1), dim3(1024), 0, stream, partial, nblk, C, sums);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
 // nn.SyncBatchNorm / nn.BatchNorm2d training statistics (base.py:6-8): local
 // shifted sums  S1 = sum(x - pivot), S2 = sum((x - pivot)^2)  -> out double [2][C]
 U2PL_API int u2pl_bn_stats_f32(const float* x, long ld, long M, int C, const float* pivot, void* workspace,

@@ -42,9 +42,9 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.bn1(self.conv1(x), relu=True)
+        out = K.conv_bn(self.conv1, self.bn1, x, relu=True)
         identity = x if self.downsample is None else K.run_seq(self.downsample, x)
-        return self.bn2(self.conv2(out), res=identity, relu=True)
+        return K.conv_bn(self.conv2, self.bn2, out, res=identity, relu=True)
 
 
 class Bottleneck(nn.Module):
@@ -67,10 +67,10 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.bn1(self.conv1(x), relu=True)
-        out = self.bn2(self.conv2(out), relu=True)
+        out = K.conv_bn(self.conv1, self.bn1, x, relu=True)
+        out = K.conv_bn(self.conv2, self.bn2, out, relu=True)
         identity = x if self.downsample is None else K.run_seq(self.downsample, x)
-        return self.bn3(self.conv3(out), res=identity, relu=True)
+        return K.conv_bn(self.conv3, self.bn3, out, res=identity, relu=True)
 
 
 class ResNet(nn.Module):
@@ -147,7 +147,9 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = self.bn1(K.run_seq(self.conv1, x), relu=True)
+        stem = list(self.conv1)
+        x = K.run_seq(nn.Sequential(*stem[:-1]), x)
+        x = K.conv_bn(stem[-1], self.bn1, x, relu=True)
         x = self.maxpool(x)
         x1 = self.layer1(x)
         x2 = self.layer2(x1)

@@ -60,7 +60,9 @@ def _grad_sink(p):
 # ------------------------------------------------------------------ convolution
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, dil, wsink, bsink):
+    def forward(ctx, x, weight, bias, stride, pad, dil, wsink, bsink, pivot=None):
+        """pivot (a BatchNorm running_mean) requests the fused train-mode BN statistics of the output:
+        returns (y, sums) with sums = double [2C+1] (S1, S2 pivot-shifted; last slot spare for the count)."""
         x, ldx = as_rows(x)
         N, Cin, H, W = x.shape
         Cout, _, R, S = weight.shape
@@ -77,16 +79,28 @@ class _ConvFn(torch.autograd.Function):
             wp = torch.zeros((Cout, Kp), dtype=torch.float32, device=x.device)
             wp[:, : R * S * Cin] = weight.permute(0, 2, 3, 1).reshape(Cout, R * S * Cin)
             call("u2pl_conv2d_fwd_f32", col, Kp, wp, bias, y, Cout, N, Ho, Wo, Kp, Ho, Wo, Cout, 1, 1, 1, 0, 1)
+        elif pivot is not None:
+            nblk = query("u2pl_conv2d_fwd_stat_blocks", N, Ho, Wo, Cout)
+            part = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=x.device)
+            call("u2pl_conv2d_fwd_bnstats_f32", x, ldx, weight, bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S, stride,
+                 pad, dil, pivot, part)
+            sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=x.device)
+            call("u2pl_colreduce_finish_f32", part, nblk, Cout, sums)
         else:
             call("u2pl_conv2d_fwd_f32", x, ldx, weight, bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil)
         ctx.save_for_backward(x, weight, col)
         ctx.geom = (N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ldx)
         ctx.has_bias = bias is not None
         ctx.wsink, ctx.bsink = wsink, bsink
+        if pivot is not None:
+            if Cin % 32:   # stem (im2col path): statistics by the stand-alone pass
+                return y, None
+            ctx.mark_non_differentiable(sums)
+            return y, sums
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gsums=None):
         x, weight, col = ctx.saved_tensors
         N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ldx = ctx.geom
         gy, ldg = as_rows(gy)
@@ -141,7 +155,7 @@ class _ConvFn(torch.autograd.Function):
             else:
                 db = torch.empty(Cout, dtype=torch.float32, device=dev)
                 call("u2pl_sums_to_f32", sums, Cout, 1.0, 0, db)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class Conv2d(nn.Module):
@@ -164,9 +178,11 @@ class Conv2d(nn.Module):
         else:
             self.register_parameter("bias", None)
 
-    def forward(self, x):
-        return _ConvFn.apply(x, self.weight, self.bias, self.stride, self.padding, self.dilation,
-                             _grad_sink(self.weight), _grad_sink(self.bias) if self.bias is not None else None)
+    def forward(self, x, stat_pivot=None):
+        """stat_pivot: running_mean of a following train-mode BatchNorm -> returns (y, fused BN sums)."""
+        out = _ConvFn.apply(x, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                            _grad_sink(self.weight), _grad_sink(self.bias) if self.bias is not None else None, stat_pivot)
+        return out
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}, p={self.padding}, d={self.dilation}"
@@ -175,7 +191,7 @@ class Conv2d(nn.Module):
 # ------------------------------------------------------------------ batch norm (+res +relu +dropout)
 class _BNFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, res, drop, mod, relu, gsink, bsink):
+    def forward(ctx, x, gamma, beta, res, drop, mod, relu, gsink, bsink, pre_sums=None):
         x, ldx = as_rows(x)
         N, C, H, W = x.shape
         M = N * H * W
@@ -188,9 +204,12 @@ class _BNFn(torch.autograd.Function):
         sync = mod.sync and _world() > 1
         if training:
             pivot = mod.running_mean
-            sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
-            wsb = _ws(query("u2pl_colreduce_workspace_bytes", M, 1, C), dev)
-            call("u2pl_bn_stats_f32", x, ldx, M, C, pivot, wsb, sums)
+            if pre_sums is not None:     # statistics came out of the producing conv's epilogue
+                sums = pre_sums
+            else:
+                sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+                wsb = _ws(query("u2pl_colreduce_workspace_bytes", M, 1, C), dev)
+                call("u2pl_bn_stats_f32", x, ldx, M, C, pivot, wsb, sums)
             count = float(M)
             if sync:
                 sums[2 * C] = float(M)
@@ -200,7 +219,7 @@ class _BNFn(torch.autograd.Function):
             invstd = torch.empty(C, dtype=torch.float32, device=dev)
             call("u2pl_bn_finalize_f32", sums, count, pivot, C, mod.eps, mod.momentum, mean, invstd, mod.running_mean,
                  mod.running_var)
-            mod.num_batches_tracked += 1
+            mod._nbt += 1   # host counter; the buffer is materialised lazily (see BatchNorm2d)
         else:
             mean = mod.running_mean
             invstd = torch.empty(C, dtype=torch.float32, device=dev)
@@ -240,7 +259,7 @@ class _BNFn(torch.autograd.Function):
         if dx is not None:
             call("u2pl_bn_bwd_apply_f32", gy, ldg, x, ldx, y, C, mean, invstd, gamma, drop, H * W,
                  sums if training else None, count, dx, C, dres, C, M, C)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
 
 
 class BatchNorm2d(nn.Module):
@@ -256,10 +275,24 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        # torch bumps num_batches_tracked with one tiny kernel per BN per forward (236 launches / step);
+        # the count is kept on the host and written into the buffer only when a state_dict is taken.
+        self._nbt = 0
+        self.register_state_dict_pre_hook(lambda m, prefix, keep_vars: m.num_batches_tracked.fill_(m._nbt))
+        self.register_load_state_dict_post_hook(lambda m, incompatible: setattr(m, "_nbt", int(m.num_batches_tracked)))
 
-    def forward(self, x, res=None, relu=False, drop=None):
+    def forward(self, x, res=None, relu=False, drop=None, pre_sums=None):
         return _BNFn.apply(x, self.weight, self.bias, res, drop, self, relu, _grad_sink(self.weight),
-                           _grad_sink(self.bias))
+                           _grad_sink(self.bias), pre_sums)
+
+
+def conv_bn(conv, bn, x, res=None, relu=False, drop=None):
+    """conv -> BatchNorm (+residual, ReLU, Dropout2d scale).  In training mode the BN statistics are
+    produced by the conv kernel's epilogue (no separate read pass over the conv output)."""
+    if bn.training and conv.in_channels % 32 == 0:
+        y, sums = conv(x, stat_pivot=bn.running_mean)
+        return bn(y, res=res, relu=relu, drop=drop, pre_sums=sums)
+    return bn(conv(x), res=res, relu=relu, drop=drop)
 
 
 class SyncBatchNorm(BatchNorm2d):
@@ -280,8 +313,13 @@ def run_seq(seq, x, drop_override=None):
     BN + ReLU + Dropout2d into one kernel (indices/names unchanged)."""
     mods = list(seq)
     i = 0
+    pending_conv = None
     while i < len(mods):
         m = mods[i]
+        if isinstance(m, Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], BatchNorm2d):
+            pending_conv = m      # executed together with the BatchNorm that follows (fused statistics)
+            i += 1
+            continue
         if isinstance(m, BatchNorm2d):
             relu, drop, j = False, None, i + 1
             if j < len(mods) and isinstance(mods[j], nn.ReLU):
@@ -292,7 +330,11 @@ def run_seq(seq, x, drop_override=None):
                 else:
                     drop = dropout2d_scale(mods[j].p, x.shape[0], x.shape[1], x.device, mods[j].training)
                 j += 1
-            x = m(x, relu=relu, drop=drop)
+            if pending_conv is not None:
+                x = conv_bn(pending_conv, m, x, relu=relu, drop=drop)
+                pending_conv = None
+            else:
+                x = m(x, relu=relu, drop=drop)
             i = j
         elif isinstance(m, (nn.ReLU, nn.Dropout2d)):
             raise HipError("un-fused ReLU/Dropout2d marker in Sequential")

@@ -12,11 +12,13 @@ GEMMs and state_dicts stay interchangeable with the reference.
 Sequential indices); ``run_seq`` fuses them into the BatchNorm apply kernel.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from . import _lib
 from ._lib import HipError, call, query
 
 _CL = torch.channels_last
@@ -50,6 +52,33 @@ def _ws(nbytes, device):
 
 def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+# Weight-gradient kernels are leaves of the backward graph: they run on a side HIP stream so the
+# memory-bound BatchNorm-backward passes and the next layer's dgrad (main stream) overlap the MFMA-bound
+# wgrad.  wgrad_stream_sync() must be called before the optimizer reads the gradient arena.
+_WGRAD = {"stream": None, "enabled": os.environ.get("U2PL_NO_WGRAD_STREAM") is None}
+
+
+def _wgrad_stream():
+    if not _WGRAD["enabled"] or _lib.PROFILE is not None:
+        return None
+    if _WGRAD["stream"] is None:
+        _WGRAD["stream"] = torch.cuda.Stream()
+    return _WGRAD["stream"]
+
+
+def wgrad_stream_sync():
+    _WGRAD["queued"] = False
+    if _WGRAD["stream"] is not None:
+        torch.cuda.current_stream().wait_stream(_WGRAD["stream"])
+
+
+def _queue_wgrad_join():
+    """Join the side stream when the running backward pass finishes (once per pass)."""
+    if not _WGRAD.get("queued"):
+        _WGRAD["queued"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(wgrad_stream_sync)
 
 
 def _grad_sink(p):
@@ -123,6 +152,15 @@ class _ConvFn(torch.autograd.Function):
             call("u2pl_weight_transpose_f32", weight_k, wT, Cp, R * S, Cin)
             dx = new_act(N, Cin, H, W, dev)
             call("u2pl_conv2d_dgrad_f32", gy, ldg, wT, dx, Cin, N, H, W, Cin, Ho, Wo, Cp, R, S, stride, pad, dil)
+        side = _wgrad_stream() if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            for t_ in (gy, x, col):
+                if t_ is not None:
+                    t_.record_stream(side)
+            _queue_wgrad_join()
+            stream_ctx = torch.cuda.stream(side)
+            stream_ctx.__enter__()
         if ctx.needs_input_grad[1]:
             sink = ctx.wsink
             if col is not None:  # 3-channel stem: gradient of the padded [Cout][Kp] patch-matrix weights
@@ -155,6 +193,12 @@ class _ConvFn(torch.autograd.Function):
             else:
                 db = torch.empty(Cout, dtype=torch.float32, device=dev)
                 call("u2pl_sums_to_f32", sums, Cout, 1.0, 0, db)
+        if side is not None:
+            stream_ctx.__exit__(None, None, None)
+            for t_ in (dw, db):
+                if t_ is not None:   # returned to autograd on the main stream
+                    torch.cuda.current_stream().wait_stream(side)
+                    break
         return dx, dw, db, None, None, None, None, None, None
 
 

@@ -111,6 +111,7 @@ class SemiTrainer:
         return None
 
     def _reduce_grads_and_step(self, lrs):
+        K.wgrad_stream_sync()   # weight gradients are produced on a side stream
         W = _world()
         if W > 1:
             dist.all_reduce(self.arena.grad)  # one flat RCCL all-reduce (DDP mean folded into the SGD launch)
@@ -287,6 +288,7 @@ class SupTrainer:
         else:
             loss = self.sup_loss_fn(pred, label)
         loss.backward()
+        K.wgrad_stream_sync()
         W = _world()
         if W > 1:
             dist.all_reduce(self.arena.grad)

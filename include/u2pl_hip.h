@@ -84,11 +84,14 @@ int u2pl_unpack_class_bits(const unsigned* bits, int N, int C, int h, int w, lon
 int u2pl_contra_classify(const float* prob, long sn, long sc, long sp, const unsigned* lbits,
                          const float* low_mask, const float* high_mask, int N2, int num_labeled, int C, int h,
                          int w, float thr_p, float thr_n, int low_rank, int high_rank, unsigned* abits,
-                         unsigned* lowbits, unsigned* nbits, hipStream_t stream);
-/* boolean-mask indexing order (loss_helper.py:115-116,119-123,142): idx int32 [3][32][cap], counts u32 [3][32] */
+                         unsigned* lowbits, unsigned* nbits, void* compact_workspace, hipStream_t stream);
+/* boolean-mask indexing order (loss_helper.py:115-116,119-123,142): idx int32 [3][32][cap] (plane 0 anchors,
+   plane 2 negative keys; plane 1 (low-valid) is counted only), counts u32 [3][32].
+   compact_workspace (u2pl_compact_workspace_bytes) handed to u2pl_contra_classify receives the per-block
+   counts as a by-product; pass counted=1 to u2pl_compact_lists then (NULL / 0 otherwise). */
 size_t u2pl_compact_workspace_bytes(long P);
 int u2pl_compact_lists(const unsigned* abits, const unsigned* lowbits, const unsigned* nbits, long P, int C,
-                       void* workspace, int* idx, long cap, unsigned* counts, hipStream_t stream);
+                       void* workspace, int* idx, long cap, unsigned* counts, int counted, hipStream_t stream);
 /* torch.mean(rep_teacher[low_valid], dim=0): loss_helper.py:119-123 */
 size_t u2pl_proto_workspace_bytes(long P, int C, int D);
 int u2pl_class_prototypes(const float* rows, long ld, int D, const int* idx, long cap, const unsigned* counts,

@@ -3,6 +3,7 @@
 // prototypes, device-resident per-class memory bank (FIFO ring), and the
 // pixel-wise InfoNCE loss + gradient with wave64 shuffle reductions.
 // Reference: u2pl/utils/loss_helper.py:51-235, u2pl/utils/utils.py:27-47.
+#include <stdlib.h>
 #include "common.h"
 #include "u2pl_hip.h"
 
@@ -18,20 +19,25 @@
 // prob is addressed through strides so NCHW or NHWC both work.
 // ---------------------------------------------------------------------------
 #define MAXC 32
-__global__ void k_contra_classify(const float* __restrict__ prob, long sn, long sc, long sp,
-                                  const unsigned* __restrict__ lbits, const float* __restrict__ low_mask,
-                                  const float* __restrict__ high_mask, int N2, int num_labeled, int C,
-                                  long hw, float thr_p, float thr_n, int low_rank, int high_rank,
-                                  unsigned* __restrict__ abits, unsigned* __restrict__ lowbits,
-                                  unsigned* __restrict__ nbits) {
-    long total = (long)N2 * hw;
-    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total;
-         p += (long)gridDim.x * blockDim.x) {
-        long n = p / hw, q = p % hw;
+#define CP_PIX 256          // pixels per block of the classify / compaction kernels (one per thread)
+// The classify kernel also counts, per block of CP_PIX pixels, the members of every (kind, class) list:
+// blk[(kind*32 + c) * nblk + b]   (kinds: 0 = anchor, 1 = low-valid, 2 = negative)
+__global__ __launch_bounds__(CP_PIX) void k_contra_classify(
+    const float* __restrict__ prob, long sn, long sc, long sp, const unsigned* __restrict__ lbits,
+    const float* __restrict__ low_mask, const float* __restrict__ high_mask, int N2, int num_labeled, int C,
+    long hw, float thr_p, float thr_n, int low_rank, int high_rank, unsigned* __restrict__ abits,
+    unsigned* __restrict__ lowbits, unsigned* __restrict__ nbits, unsigned* __restrict__ blk, int nblk) {
+    __shared__ unsigned cnt[3 * MAXC];
+    if (threadIdx.x < 3 * MAXC) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const long total = (long)N2 * hw;
+    const long p = blockIdx.x * (long)CP_PIX + threadIdx.x;
+    if (p < total) {
+        const long n = p / hw, q = p % hw;
         const unsigned lb = lbits[p];
-        const bool lo = low_mask[p] != 0.f, hi = high_mask[p] != 0.f;
         unsigned a = 0, l = 0, ng = 0;
         if (lb != 0) {   // every output needs label_i == 1 (labeled negatives are structurally empty, Q2)
+            const bool lo = low_mask[p] != 0.f, hi = high_mask[p] != 0.f;
             const float* b = prob + n * sn + q * sp;
             float pr[MAXC];
 #pragma unroll
@@ -55,20 +61,29 @@ __global__ void k_contra_classify(const float* __restrict__ prob, long sn, long 
         abits[p] = a;
         lowbits[p] = l;
         nbits[p] = ng;
+        if (blk) {   // sparse: one LDS atomic per set bit
+            for (unsigned x = a; x; x &= x - 1) atomicAdd(&cnt[0 * MAXC + __ffs(x) - 1], 1u);
+            for (unsigned x = l; x; x &= x - 1) atomicAdd(&cnt[1 * MAXC + __ffs(x) - 1], 1u);
+            for (unsigned x = ng; x; x &= x - 1) atomicAdd(&cnt[2 * MAXC + __ffs(x) - 1], 1u);
+        }
     }
+    if (!blk) return;
+    __syncthreads();
+    if (threadIdx.x < 3 * MAXC) blk[(long)threadIdx.x * nblk + blockIdx.x] = cnt[threadIdx.x];
 }
 
 U2PL_API int u2pl_contra_classify(const float* prob, long sn, long sc, long sp, const unsigned* lbits,
                                   const float* low_mask, const float* high_mask, int N2, int num_labeled,
                                   int C, int h, int w, float thr_p, float thr_n, int low_rank,
                                   int high_rank, unsigned* abits, unsigned* lowbits, unsigned* nbits,
-                                  hipStream_t stream) {
+                                  void* compact_workspace, hipStream_t stream) {
     if (C > MAXC) return U2PL_EINVAL;
     long total = (long)N2 * h * w;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_contra_classify, dim3(grid_for(total, 256)), dim3(256), 0, stream, prob, sn, sc, sp,
-                       lbits, low_mask, high_mask, N2, num_labeled, C, (long)h * w, thr_p, thr_n, low_rank,
-                       high_rank, abits, lowbits, nbits);
+    const int nblk = cdiv(total, CP_PIX);
+    hipLaunchKernelGGL(k_contra_classify, dim3(nblk), dim3(CP_PIX), 0, stream, prob, sn, sc, sp, lbits, low_mask,
+                       high_mask, N2, num_labeled, C, (long)h * w, thr_p, thr_n, low_rank, high_rank, abits,
+                       lowbits, nbits, (unsigned*)compact_workspace, nblk);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -76,248 +91,305 @@ U2PL_API int u2pl_contra_classify(const float* prob, long sn, long sc, long sp, 
 // ---------------------------------------------------------------------------
 // Phase 1b: ordered compaction.  Lists are in row-major (n,y,x) pixel order,
 // exactly the order of torch boolean-mask indexing (loss_helper.py:115-116,142).
-// kinds: 0 = anchor, 1 = low-valid, 2 = negative.  Integer-only => exact.
-//   pass A: per block (1024 pixels) counts   [nblk][3][C]
-//   pass B: exclusive scan over blocks       (one thread per (kind,class))
-//   pass C: re-evaluate ballots and write    idx[kind][class][cap]
+// kinds: 0 = anchor, 1 = low-valid (counts only: the prototypes stream the
+// bitmask, nobody reads that list), 2 = negative.  Integer-only => exact.
+//   pass A: per block (256 pixels) counts [3*32][nblk]  (by the classify kernel, or k_compact_count)
+//   pass B: exclusive scan over blocks, one block per (kind, class)
+//   pass C: per wave ballots over the classes PRESENT in the wave, write idx[kind][class][cap]
 // ---------------------------------------------------------------------------
-#define CP_PIX 1024
 __device__ __forceinline__ unsigned long long lanemask_lt() {
     unsigned lane = threadIdx.x & 63;
     return lane ? (~0ull >> (64 - lane)) : 0ull;
 }
-
-__global__ void k_compact_count(const unsigned* __restrict__ b0, const unsigned* __restrict__ b1,
-                                const unsigned* __restrict__ b2, long P, int C, unsigned* __restrict__ blk) {
-    __shared__ unsigned cnt[3 * MAXC];
-    for (int i = threadIdx.x; i < 3 * MAXC; i += blockDim.x) cnt[i] = 0;
-    __syncthreads();
-    const long base = (long)blockIdx.x * CP_PIX;
-    for (int it = 0; it < CP_PIX / 256; ++it) {
-        long p = base + it * 256 + threadIdx.x;
-        unsigned v0 = p < P ? b0[p] : 0, v1 = p < P ? b1[p] : 0, v2 = p < P ? b2[p] : 0;
-        for (int c = 0; c < C; ++c) {
-            unsigned long long m0 = __ballot((v0 >> c) & 1u), m1 = __ballot((v1 >> c) & 1u), m2 = __ballot((v2 >> c) & 1u);
-            if ((threadIdx.x & 63) == 0) {
-                if (m0) atomicAdd(&cnt[0 * MAXC + c], (unsigned)__popcll(m0));
-                if (m1) atomicAdd(&cnt[1 * MAXC + c], (unsigned)__popcll(m1));
-                if (m2) atomicAdd(&cnt[2 * MAXC + c], (unsigned)__popcll(m2));
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 3 * MAXC; i += blockDim.x) blk[(long)blockIdx.x * 3 * MAXC + i] = cnt[i];
+__device__ __forceinline__ unsigned wave_or_uniform(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+    return __builtin_amdgcn_readfirstlane(v);
 }
 
-// exclusive scan over blocks: one wave64 per (kind, class) pair, shuffle scan in chunks of 64 blocks
-__global__ void k_compact_scan(unsigned* __restrict__ blk, int nblk, unsigned* __restrict__ counts) {
-    const int i = blockIdx.x, lane = threadIdx.x;   // grid = 3*MAXC, block = 64
+__global__ __launch_bounds__(CP_PIX) void k_compact_count(const unsigned* __restrict__ b0, const unsigned* __restrict__ b1,
+                                const unsigned* __restrict__ b2, long P, unsigned* __restrict__ blk, int nblk) {
+    __shared__ unsigned cnt[3 * MAXC];
+    if (threadIdx.x < 3 * MAXC) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const long p = blockIdx.x * (long)CP_PIX + threadIdx.x;
+    if (p < P) {
+        for (unsigned x = b0[p]; x; x &= x - 1) atomicAdd(&cnt[0 * MAXC + __ffs(x) - 1], 1u);
+        for (unsigned x = b1[p]; x; x &= x - 1) atomicAdd(&cnt[1 * MAXC + __ffs(x) - 1], 1u);
+        for (unsigned x = b2[p]; x; x &= x - 1) atomicAdd(&cnt[2 * MAXC + __ffs(x) - 1], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * MAXC) blk[(long)threadIdx.x * nblk + blockIdx.x] = cnt[threadIdx.x];
+}
+
+// exclusive scan over blocks: one 256-thread block per (kind, class) row of blk (contiguous)
+__global__ __launch_bounds__(256) void k_compact_scan(unsigned* __restrict__ blk, int nblk, unsigned* __restrict__ counts) {
+    __shared__ unsigned wsum[4];
+    unsigned* row = blk + (long)blockIdx.x * nblk;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     unsigned carry = 0;
-    for (int base = 0; base < nblk; base += 64) {
-        const int b = base + lane;
-        const unsigned v = b < nblk ? blk[(long)b * 3 * MAXC + i] : 0;
+    for (int base = 0; base < nblk; base += 256) {
+        const int b = base + t;
+        const unsigned v = b < nblk ? row[b] : 0;
         unsigned x = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             unsigned u = __shfl_up(x, o, 64);
             if (lane >= o) x += u;
         }
-        if (b < nblk) blk[(long)b * 3 * MAXC + i] = carry + x - v;
-        carry += __shfl(x, 63, 64);
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        unsigned wb = 0;
+        for (int w2 = 0; w2 < wave; ++w2) wb += wsum[w2];
+        const unsigned tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (b < nblk) row[b] = carry + wb + x - v;
+        carry += tot;
+        __syncthreads();
     }
-    if (lane == 0) counts[i] = carry;
+    if (t == 0) counts[blockIdx.x] = carry;
 }
 
-__global__ void k_compact_write(const unsigned* __restrict__ b0, const unsigned* __restrict__ b1,
-                                const unsigned* __restrict__ b2, long P, int C,
-                                const unsigned* __restrict__ blk, int* __restrict__ idx, long cap) {
-    // per (wave-iteration, kind, class) counts -> in-block exclusive offsets
-    __shared__ unsigned wcnt[16][3 * MAXC];
+__global__ __launch_bounds__(CP_PIX) void k_compact_write(const unsigned* __restrict__ b0, const unsigned* __restrict__ b2, long P,
+                                const unsigned* __restrict__ blk, int nblk, int* __restrict__ idx, long cap) {
+    __shared__ unsigned wcnt[4][2 * MAXC];   // kinds {0, 2}: per-wave counts -> in-block exclusive offsets
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long base = (long)blockIdx.x * CP_PIX;
-    unsigned v[4][3];
+    const long p = blockIdx.x * (long)CP_PIX + threadIdx.x;
+    unsigned v[2];
+    v[0] = p < P ? b0[p] : 0;
+    v[1] = p < P ? b2[p] : 0;
+    if (threadIdx.x < 2 * MAXC) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        long p = base + it * 256 + threadIdx.x;
-        v[it][0] = p < P ? b0[p] : 0;
-        v[it][1] = p < P ? b1[p] : 0;
-        v[it][2] = p < P ? b2[p] : 0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            for (int c = 0; c < C; ++c) {
-                unsigned long long m = __ballot((v[it][k] >> c) & 1u);
-                if (lane == 0) wcnt[it * 4 + wave][k * MAXC + c] = (unsigned)__popcll(m);
-            }
+        for (int w2 = 0; w2 < 4; ++w2) wcnt[w2][threadIdx.x] = 0;
     }
     __syncthreads();
-    // exclusive scan over the 16 wave-iterations (pixel order: it-major, wave-minor)
-    for (int i = threadIdx.x; i < 3 * MAXC; i += blockDim.x) {
-        unsigned run = blk[(long)blockIdx.x * 3 * MAXC + i];
-        for (int s = 0; s < 16; ++s) {
-            unsigned t = wcnt[s][i];
-            wcnt[s][i] = run;
+    unsigned pres[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        pres[k] = wave_or_uniform(v[k]);
+        for (unsigned x = pres[k]; x; x &= x - 1) {
+            const int c = __ffs(x) - 1;
+            const unsigned long long m = __ballot((v[k] >> c) & 1u);
+            if (lane == 0) wcnt[wave][k * MAXC + c] = (unsigned)__popcll(m);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * MAXC) {
+        const int k = threadIdx.x >> 5, c = threadIdx.x & 31;
+        unsigned run = blk[((long)(2 * k) * MAXC + c) * nblk + blockIdx.x];
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+            const unsigned t = wcnt[w2][threadIdx.x];
+            wcnt[w2][threadIdx.x] = run;
             run += t;
         }
     }
     __syncthreads();
     const unsigned long long lt = lanemask_lt();
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        long p = base + it * 256 + threadIdx.x;
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            for (int c = 0; c < C; ++c) {
-                bool on = (v[it][k] >> c) & 1u;
-                unsigned long long m = __ballot(on);
-                if (on) {
-                    unsigned pos = wcnt[it * 4 + wave][k * MAXC + c] + (unsigned)__popcll(m & lt);
-                    idx[((long)k * MAXC + c) * cap + pos] = (int)p;
-                }
+    for (int k = 0; k < 2; ++k)
+        for (unsigned x = pres[k]; x; x &= x - 1) {
+            const int c = __ffs(x) - 1;
+            const bool on = (v[k] >> c) & 1u;
+            const unsigned long long m = __ballot(on);
+            if (on) {
+                const unsigned pos = wcnt[wave][k * MAXC + c] + (unsigned)__popcll(m & lt);
+                idx[((long)(2 * k) * MAXC + c) * cap + pos] = (int)p;
             }
-    }
+        }
 }
 
 U2PL_API size_t u2pl_compact_workspace_bytes(long P) {
     return (size_t)cdiv(P, CP_PIX) * 3 * MAXC * sizeof(unsigned);
 }
 
-// idx: int32 [3][32][cap] ; counts: u32 [3][32]
+// idx: int32 [3][32][cap] (plane 1 is not written) ; counts: u32 [3][32]
+// counted != 0: `workspace` already holds the per-block counts (written by u2pl_contra_classify)
 U2PL_API int u2pl_compact_lists(const unsigned* abits, const unsigned* lowbits, const unsigned* nbits, long P,
-                                int C, void* workspace, int* idx, long cap, unsigned* counts,
+                                int C, void* workspace, int* idx, long cap, unsigned* counts, int counted,
                                 hipStream_t stream) {
     if (C > MAXC || P <= 0) return U2PL_EINVAL;
     int nblk = cdiv(P, CP_PIX);
     unsigned* blk = (unsigned*)workspace;
-    hipLaunchKernelGGL(k_compact_count, dim3(nblk), dim3(256), 0, stream, abits, lowbits, nbits, P, C, blk);
+    if (!counted) {
+        hipLaunchKernelGGL(k_compact_count, dim3(nblk), dim3(CP_PIX), 0, stream, abits, lowbits, nbits, P, blk, nblk);
+        U2PL_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_compact_scan, dim3(3 * MAXC), dim3(256), 0, stream, blk, nblk, counts);
     U2PL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_compact_scan, dim3(3 * MAXC), dim3(64), 0, stream, blk, nblk, counts);
-    U2PL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_compact_write, dim3(nblk), dim3(256), 0, stream, abits, lowbits, nbits, P, C, blk, idx, cap);
+    hipLaunchKernelGGL(k_compact_write, dim3(nblk), dim3(CP_PIX), 0, stream, abits, nbits, P, blk, nblk, idx, cap);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
 
 // ---------------------------------------------------------------------------
-// Phase 1c: class prototypes = mean of rep_teacher rows over the low-valid list
+// Phase 1c: class prototypes = mean of rep_teacher rows over the low-valid set
 // (loss_helper.py:119-123).  rows: row r of the (pixel, D) view = base + r*ld.
-// Deterministic two-stage sum: chunks of PR_ROWS rows -> partial[C][nchunk][D]
-// (float), then an ordered double-precision finish.
+// Streaming formulation: every pixel row that belongs to at least one class is read ONCE (1 KiB
+// coalesced, lane l owns channels [4l, 4l+4)) and added into per-class REGISTER accumulators; the class
+// bits of the row are wave-uniform scalars, so only the classes that are set cost any VALU work.
+// 4 waves per block, wave w streams pixels w, w+4, ... of the block's 128 (8 row loads in flight while
+// the previous 8 are accumulated), combined across the waves through LDS in a fixed order
+// => deterministic.  Blocks without members (images other than {0, B}: quirk Q0) only write flag 0.
+// Then an ordered double-precision finish over the flagged blocks.
 // ---------------------------------------------------------------------------
-// Streaming formulation: every pixel row of rep_teacher that belongs to at least one class is read ONCE
-// (1 KiB coalesced by D/4 lanes) and added into a per-block [C][D] LDS accumulator; thread d owns column
-// d of every class, visits the block's pixels in order => deterministic.  Only images {0, B} carry class
-// bits (Q0), so ~2*h*w rows are streamed instead of sum_c |low_valid_c| gathered rows.
-#define PR_PIX 256
-// 4 waves per block; wave w streams pixels w, w+4, ... of the block's range (8 row loads in flight per
-// wave), lane l owns channels [4l, 4l+4) (D == 256) or strides over D; per-class accumulators live in
-// registers (class loop fully unrolled and predicated), combined across the 4 waves through LDS in a
-// fixed order => deterministic.
+#define PR_PIX 128
 template <int CT>
-__global__ __launch_bounds__(256, 2) void k_proto_stream(const float* __restrict__ rows, long ld, int D, const unsigned* __restrict__ lowbits,
-                               long P, float* __restrict__ partial) {
+__global__ __launch_bounds__(256, 2) void k_proto_stream(const float* __restrict__ rows, long ld, int D,
+                                                         const unsigned* __restrict__ lowbits, long P,
+                                                         float* __restrict__ partial, unsigned* __restrict__ flags,
+                                                         int ppb) {
     extern __shared__ float red[];   // [4][CT][D]
+    __shared__ int any_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long p0 = (long)blockIdx.x * PR_PIX;
-    float* out = partial + (long)blockIdx.x * CT * D;
-    for (int d0 = 0; d0 < D; d0 += 256) {       // D <= 256: one trip
-        const int d = d0 + lane * 4;
-        float4 acc[CT];
-#pragma unroll
-        for (int c = 0; c < CT; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool act = d < D;       // lanes beyond D only take part in the ballots / broadcasts
-        {
-            // this wave's 64 pixels are wave + 4*i; lane i holds the class bits of pixel i of that set
-            const long pmine = p0 + wave + 4 * lane;
-            const unsigned mybits = pmine < P ? lowbits[pmine] : 0u;
-            unsigned long long todo = __ballot(mybits != 0);
-            while (todo) {          // wave-uniform loop: up to 8 contributing pixels per trip
-                int sel[8];
-                int nsel = 0;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    sel[u] = 0;
-                    if (todo) {
-                        sel[u] = __ffsll((long long)todo) - 1;
-                        todo &= todo - 1;
-                        nsel = u + 1;
-                    }
-                }
-                float4 v[8];
-                unsigned bits[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {   // unconditional loads (sel[u] = 0 is a valid pixel of the set)
-                    v[u] = act ? *(const float4*)(rows + (p0 + wave + 4 * (long)sel[u]) * ld + d) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    bits[u] = u < nsel ? __shfl(mybits, sel[u], 64) : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-#pragma unroll
-                    for (int c = 0; c < CT; ++c)
-                        if ((bits[u] >> c) & 1u) {
-                            acc[c].x += v[u].x; acc[c].y += v[u].y; acc[c].z += v[u].z; acc[c].w += v[u].w;
-                        }
-            }
-            if (act) {
-#pragma unroll
-                for (int c = 0; c < CT; ++c) *(float4*)(red + ((long)wave * CT + c) * D + d) = acc[c];
-            }
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < CT * D / 4; i += blockDim.x) {
-            const float4 a = ((float4*)red)[i], b2 = ((float4*)red)[CT * D / 4 + i];
-            const float4 c2 = ((float4*)red)[2 * CT * D / 4 + i], e = ((float4*)red)[3 * CT * D / 4 + i];
-            float4 r;
-            r.x = (a.x + b2.x) + (c2.x + e.x); r.y = (a.y + b2.y) + (c2.y + e.y);
-            r.z = (a.z + b2.z) + (c2.z + e.z); r.w = (a.w + b2.w) + (c2.w + e.w);
-            ((float4*)out)[i] = r;
-        }
-        __syncthreads();
+    const long p0 = (long)blockIdx.x * ppb;
+    const long pmine = p0 + wave + 4 * lane;   // lane i holds the class bits of pixel i of this wave's set
+    const unsigned mybits = (4 * lane < ppb && pmine < P) ? lowbits[pmine] : 0u;
+    unsigned long long todo = __ballot(mybits != 0);
+    if (threadIdx.x == 0) any_s = 0;
+    __syncthreads();
+    if (lane == 0 && todo) any_s = 1;
+    __syncthreads();
+    if (!any_s) {
+        if (threadIdx.x == 0) flags[blockIdx.x] = 0;
+        return;
     }
+    const int d = lane * 4;
+    const bool act = d < D;       // D <= 256
+    const float* rbase = rows + (p0 + wave) * ld + (act ? d : 0);
+    float4 acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 va[8], vb[8];
+    unsigned ba[8], bb[8];
+#define PROTO_FETCH(V, B)                                                                     \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                           \
+        B[u] = 0;                                                                             \
+        if (todo) {                                                                           \
+            const int sel = __ffsll((long long)todo) - 1;                                     \
+            todo &= todo - 1;                                                                 \
+            B[u] = __builtin_amdgcn_readlane(mybits, sel);                                    \
+            V[u] = *(const float4*)(rbase + 4 * (long)sel * ld);                              \
+        }                                                                                     \
+    }
+#define PROTO_ACC(V, B)                                                                       \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                           \
+        if (B[u]) {                                                                           \
+            _Pragma("unroll") for (int c = 0; c < CT; ++c)                                    \
+                if ((B[u] >> c) & 1u) {  /* scalar branch: the asm keeps it from being if-converted */ \
+                    asm volatile("");                                                         \
+                    acc[c].x += V[u].x; acc[c].y += V[u].y; acc[c].z += V[u].z; acc[c].w += V[u].w; \
+                }                                                                             \
+        }                                                                                     \
+    }
+    PROTO_FETCH(va, ba)
+    while (true) {
+        const bool more_b = todo != 0;
+        PROTO_FETCH(vb, bb)
+        PROTO_ACC(va, ba)
+        if (!more_b) break;
+        const bool more_a = todo != 0;
+        PROTO_FETCH(va, ba)
+        PROTO_ACC(vb, bb)
+        if (!more_a) break;
+    }
+#undef PROTO_FETCH
+#undef PROTO_ACC
+    if (act) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) *(float4*)(red + ((long)wave * CT + c) * D + d) = acc[c];
+    }
+    __syncthreads();
+    float* out = partial + (long)blockIdx.x * CT * D;
+    for (int i = threadIdx.x; i < CT * D / 4; i += blockDim.x) {
+        const float4 a = ((float4*)red)[i], b2 = ((float4*)red)[CT * D / 4 + i];
+        const float4 c2 = ((float4*)red)[2 * CT * D / 4 + i], e = ((float4*)red)[3 * CT * D / 4 + i];
+        float4 r;
+        r.x = (a.x + b2.x) + (c2.x + e.x); r.y = (a.y + b2.y) + (c2.y + e.y);
+        r.z = (a.z + b2.z) + (c2.z + e.z); r.w = (a.w + b2.w) + (c2.w + e.w);
+        ((float4*)out)[i] = r;
+    }
+    if (threadIdx.x == 0) flags[blockIdx.x] = 1;
 }
-// grid (C, D/64): 64 channels x 4 partial groups per block, 8 loads in flight per thread
-__global__ void k_proto_finish(const float* __restrict__ partial, int D, const unsigned* __restrict__ counts,
-                               int nblk, int C, float* __restrict__ proto) {
-    __shared__ double sh[4][64];
+// grid (C, D/64), 1024 threads: 64 channels x 16 row groups; the flagged blocks are first compacted (in
+// ascending order) into an LDS list so that the partial loads are independent (8 in flight per thread)
+#define PF_MAXBLK 4096
+__global__ __launch_bounds__(1024) void k_proto_finish(const float* __restrict__ partial, int D,
+                                                       const unsigned* __restrict__ counts, int nblk, int C,
+                                                       const unsigned* __restrict__ flags, float* __restrict__ proto) {
+    __shared__ double sh[16][64];
+    __shared__ int act[PF_MAXBLK];
+    __shared__ int wtot[16];
     const int c = blockIdx.x, cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int d = blockIdx.y * 64 + cl;
+    int base = 0;
+    for (int b0 = 0; b0 < nblk; b0 += 1024) {
+        const int b = b0 + threadIdx.x;
+        const bool on = b < nblk && flags[b] != 0;
+        const unsigned long long m = __ballot(on);
+        if (cl == 0) wtot[rg] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w2 = 0; w2 < rg; ++w2) off += wtot[w2];
+        if (on) act[off + __popcll(m & (cl ? (~0ull >> (64 - cl)) : 0ull))] = b;
+        int tot = 0;
+        for (int w2 = 0; w2 < 16; ++w2) tot += wtot[w2];
+        base += tot;
+        __syncthreads();
+    }
+    const int n_act = base;
     const unsigned n = counts[1 * MAXC + c];
     double acc = 0.0;
     if (d < D) {
         const float* p = partial + (long)c * D + d;
-        int b = rg;
-        for (; b + 7 * 4 < nblk; b += 8 * 4) {
+        int i = rg;
+        for (; i + 7 * 16 < n_act; i += 8 * 16) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = p[(long)(b + 4 * u) * C * D];
+            for (int u = 0; u < 8; ++u) v[u] = p[(long)act[i + 16 * u] * C * D];
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc += (double)v[u];
         }
-        for (; b < nblk; b += 4) acc += (double)p[(long)b * C * D];
+        for (; i < n_act; i += 16) acc += (double)p[(long)act[i] * C * D];
     }
     sh[rg][cl] = acc;
     __syncthreads();
     if (rg == 0 && d < D) {
-        const double t = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += sh[g][cl];
         proto[(long)c * D + d] = n ? (float)(t / (double)n) : __uint_as_float(0x7fc00000u);
     }
 }
 
+static int proto_ppb() {   // pixels per block of the streaming kernel (tuning knob)
+    static int v = 0;
+    if (!v) {
+        const char* e = getenv("U2PL_PROTO_PIX");
+        v = e ? atoi(e) : PR_PIX;
+        if (v != 64 && v != 128 && v != 256) v = PR_PIX;
+    }
+    return v;
+}
 U2PL_API size_t u2pl_proto_workspace_bytes(long P, int C, int D) {
-    return (size_t)cdiv(P, PR_PIX) * C * D * sizeof(float);
+    const size_t nblk = cdiv(P, proto_ppb());
+    return nblk * C * D * sizeof(float) + nblk * sizeof(unsigned);
 }
 // idx/cap are unused by the streaming formulation (kept in the ABI for list-based callers)
 U2PL_API int u2pl_class_prototypes(const float* rows, long ld, int D, const int* idx, long cap,
                                    const unsigned* counts, int C, long P, void* workspace, float* proto,
                                    const unsigned* lowbits, hipStream_t stream) {
     (void)idx; (void)cap;
-    const int nblk = cdiv(P, PR_PIX);
-    if (D % 4 || D > 256) return U2PL_EINVAL;
+    const int ppb = proto_ppb();
+    const int nblk = cdiv(P, ppb);
+    if (D % 4 || D > 256 || nblk > PF_MAXBLK) return U2PL_EINVAL;
     const size_t lds = (size_t)4 * C * D * sizeof(float);
+    float* partial = (float*)workspace;
+    unsigned* flags = (unsigned*)(partial + (size_t)nblk * C * D);
 #define PROTO_CASE(CT)                                                                                           \
     case CT: {                                                                                                   \
         static bool set_##CT = false;                                                                            \
         if (!set_##CT) { (void)hipFuncSetAttribute((const void*)k_proto_stream<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * CT * 256 * 4)); set_##CT = true; } \
-        hipLaunchKernelGGL(k_proto_stream<CT>, dim3(nblk), dim3(256), lds, stream, rows, ld, D, lowbits, P, (float*)workspace); \
+        hipLaunchKernelGGL(k_proto_stream<CT>, dim3(nblk), dim3(256), lds, stream, rows, ld, D, lowbits, P, partial, flags, ppb); \
     } break;
     switch (C) {
         PROTO_CASE(19) PROTO_CASE(21) PROTO_CASE(32)
@@ -325,7 +397,7 @@ U2PL_API int u2pl_class_prototypes(const float* rows, long ld, int D, const int*
     }
 #undef PROTO_CASE
     U2PL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_proto_finish, dim3(C, cdiv(D, 64)), dim3(256), 0, stream, (const float*)workspace, D, counts, nblk, C, proto);
+    hipLaunchKernelGGL(k_proto_finish, dim3(C, cdiv(D, 64)), dim3(1024), 0, stream, partial, D, counts, nblk, C, flags, proto);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -462,14 +534,16 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
         const long r = pre ? __shfl(myrow, j - 1, 64) : (J.bank_head + J.idx_n[(long)q * K + (j - 1)]) % J.bank_cap;
         return J.bank + r * D + lane * VPL;
     };
-    for (int j0 = 0; j0 <= K; j0 += 4) {
-        float f[4][VPL], nf[4], dot[4];
+    auto load4 = [&](float (&f)[4][VPL], int j0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float* fr = row_ptr(min(j0 + u, K));
 #pragma unroll
             for (int i = 0; i < VPL; ++i) f[u][i] = fr[i];
         }
+    };
+    auto process4 = [&](float (&f)[4][VPL], int j0) {
+        float nf[4], dot[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             nf[u] = 0.f;
@@ -485,7 +559,7 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
             nf[u] = fmaxf(sqrtf(nf[u]), 1e-8f);
             dot[u] = 0.f;
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) { f[u][i] = f[u][i] / nf[u]; dot[u] += ah[i] * f[u][i]; }
+            for (int i = 0; i < VPL; ++i) dot[u] += ah[i] * f[u][i];
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
@@ -494,21 +568,34 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (j0 + u > K) continue;
-            const float cosv = dot[u];
+            // one division per row (wave-uniform) instead of one per element: cos = (ahat . f) / |f|
+            const float cosv = dot[u] / nf[u];
             const float l = cosv * inv_temp;
             if (j0 + u == 0) {
                 l0 = l;
 #pragma unroll
-                for (int i = 0; i < VPL; ++i) f0h[i] = f[u][i];
+                for (int i = 0; i < VPL; ++i) f0h[i] = f[u][i] / nf[u];
             }
             const float mn = fmaxf(m, l);
             const float sc = expf(m - mn), w = expf(l - mn);
             s = s * sc + w;
             cw = cw * sc + w * cosv;
+            const float wn = w / nf[u];   // softmax weight x 1/|f| : acc accumulates w * fhat
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) acc[i] = acc[i] * sc + w * f[u][i];
+            for (int i = 0; i < VPL; ++i) acc[i] = acc[i] * sc + wn * f[u][i];
             m = mn;
         }
+    };
+    // two batches of four rows in flight: the next batch is requested before the current one is reduced
+    float fa[4][VPL], fb[4][VPL];
+    load4(fa, 0);
+    for (int j0 = 0; j0 <= K; j0 += 8) {
+        const bool hb = j0 + 4 <= K;
+        if (hb) load4(fb, j0 + 4);
+        process4(fa, j0);
+        if (!hb) break;
+        if (j0 + 8 <= K) load4(fa, j0 + 8);
+        process4(fb, j0 + 4);
     }
     const float lse = m + logf(s);
     if (lane == 0) {

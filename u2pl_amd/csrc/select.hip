@@ -33,41 +33,8 @@ struct SelState {            // lives in LDS
     int leader[MAXS];        // first slot carrying the same prefix (owner of the histogram)
     unsigned nd[MAXS], nk[MAXS];
     float gamma[MAXS / 2];
-    unsigned wsum[4];
+    unsigned wsum[MAXS][4];
 };
-
-// All 256 threads: ONE block-wide inclusive scan of `hist` (wave64 shuffle scans + one LDS hop), then
-// every slot whose histogram owner is `leader` locates the bin where the cumulative count crosses its
-// rank.  Two barriers per histogram, independent of the number of slots.
-__device__ void find_multi(const unsigned* __restrict__ hist, int nbins, int leader, int nslots, SelState& S) {
-    const int per = nbins / 256, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    unsigned loc = 0;
-    for (int i = 0; i < per; ++i) loc += hist[t * per + i];
-    unsigned v = loc;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        unsigned u = __shfl_up(v, o, 64);
-        if (lane >= o) v += u;
-    }
-    if (lane == 63) S.wsum[wave] = v;
-    __syncthreads();
-    unsigned base = 0;
-    for (int w2 = 0; w2 < wave; ++w2) base += S.wsum[w2];
-    const unsigned incl = base + v, excl = incl - loc;
-    for (int s = 0; s < nslots; ++s) {
-        if (S.leader[s] != leader) continue;
-        const unsigned k = S.rank[s];
-        if (k >= excl && k < incl) {
-            unsigned run = excl;
-            for (int i = 0; i < per; ++i) {
-                const unsigned h = hist[t * per + i];
-                if (k < run + h) { S.nd[s] = t * per + i; S.nk[s] = k - run; break; }
-                run += h;
-            }
-        }
-    }
-    __syncthreads();
-}
 
 __device__ void set_leaders(SelState& S, int nslots) {
     if (threadIdx.x < nslots) {
@@ -79,15 +46,70 @@ __device__ void set_leaders(SelState& S, int nslots) {
     __syncthreads();
 }
 
-__device__ void resolve_level(const unsigned* __restrict__ hbase, int nbins, int per_leader_stride, int shift,
-                              int nslots, SelState& S) {
-    for (int l = 0; l < nslots; ++l) {
-        if (S.leader[l] != l) continue;   // uniform: S.leader is in LDS
-        find_multi(hbase + (long)l * per_leader_stride, nbins, l, nslots, S);
+// One level of the chain for ALL slots at once (256 threads).  Every leader's histogram is fetched with
+// b128 loads issued back to back (one memory latency per level, not one per leader), scanned with wave64
+// shuffle scans + one LDS hop, and every slot locates the bin where the cumulative count crosses its rank
+// from the register copy.  Three barriers per level, independent of the number of slots.
+template <int PER>   // bins per thread: 8 (2048 bins) or 4 (1024 bins)
+__device__ void resolve_level(const unsigned* __restrict__ hbase, int per_leader_stride, int shift, int nslots,
+                              SelState& S) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    unsigned h[MAXS][PER];
+    bool lead[MAXS];
+#pragma unroll
+    for (int l = 0; l < MAXS; ++l) {
+        lead[l] = l < nslots && S.leader[l] == l;   // uniform (LDS)
+        if (lead[l]) {
+            const uint4* hp = (const uint4*)(hbase + (long)l * per_leader_stride + t * PER);
+#pragma unroll
+            for (int i = 0; i < PER / 4; ++i) {
+                const uint4 x = hp[i];
+                h[l][4 * i] = x.x; h[l][4 * i + 1] = x.y; h[l][4 * i + 2] = x.z; h[l][4 * i + 3] = x.w;
+            }
+        }
     }
-    if (threadIdx.x < nslots) {
-        S.prefix[threadIdx.x] |= S.nd[threadIdx.x] << shift;
-        S.rank[threadIdx.x] = S.nk[threadIdx.x];
+    unsigned loc[MAXS], scan[MAXS];
+#pragma unroll
+    for (int l = 0; l < MAXS; ++l) {
+        loc[l] = scan[l] = 0;
+        if (lead[l]) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) loc[l] += h[l][i];
+            unsigned v = loc[l];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned u = __shfl_up(v, o, 64);
+                if (lane >= o) v += u;
+            }
+            scan[l] = v;
+            if (lane == 63) S.wsum[l][wave] = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < MAXS; ++l) {
+        if (!lead[l]) continue;
+        unsigned base = 0;
+        for (int w2 = 0; w2 < wave; ++w2) base += S.wsum[l][w2];
+        const unsigned incl = base + scan[l], excl = incl - loc[l];
+        for (int s = l; s < nslots; ++s) {
+            if (S.leader[s] != l) continue;
+            const unsigned k = S.rank[s];
+            if (k >= excl && k < incl) {
+                unsigned run = excl;
+                bool done = false;
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    if (!done && k < run + h[l][i]) { S.nd[s] = t * PER + i; S.nk[s] = k - run; done = true; }
+                    run += h[l][i];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (t < nslots) {
+        S.prefix[t] |= S.nd[t] << shift;
+        S.rank[t] = S.nk[t];
     }
     __syncthreads();
     set_leaders(S, nslots);
@@ -123,11 +145,11 @@ __device__ void resolve_chain(int upto, int nspec, const int* __restrict__ kind,
     }
     if (t < MAXS) { S.leader[t] = 0; S.nd[t] = 0; S.nk[t] = 0; }   // pass 0: one shared histogram (owner 0)
     __syncthreads();
-    resolve_level(ws + SEL_H0, 2048, 0, 21, nslots, S);
+    resolve_level<8>(ws + SEL_H0, 0, 21, nslots, S);
     if (upto < 2) return;
-    resolve_level(ws + SEL_H1, 2048, 2048, 10, nslots, S);
+    resolve_level<8>(ws + SEL_H1, 2048, 10, nslots, S);
     if (upto < 3) return;
-    resolve_level(ws + SEL_H2, 1024, 1024, 0, nslots, S);
+    resolve_level<4>(ws + SEL_H2, 1024, 0, nslots, S);
 }
 
 // pass-0 histogram for callers that hand over a plain value array
@@ -135,7 +157,13 @@ __global__ void k_sel_hist0(const float* __restrict__ v, long n, unsigned* __res
     __shared__ unsigned sh[2048];
     for (int i = threadIdx.x; i < 2048; i += blockDim.x) sh[i] = 0;
     __syncthreads();
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    const long n4 = ((reinterpret_cast<uintptr_t>(v) & 15) == 0) ? (n >> 2) : 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 x = ((const float4*)v)[i];
+        atomicAdd(&sh[f32_key(x.x) >> 21], 1u); atomicAdd(&sh[f32_key(x.y) >> 21], 1u);
+        atomicAdd(&sh[f32_key(x.z) >> 21], 1u); atomicAdd(&sh[f32_key(x.w) >> 21], 1u);
+    }
+    for (long i = 4 * n4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         atomicAdd(&sh[f32_key(v[i]) >> 21], 1u);
     __syncthreads();
     for (int i = threadIdx.x; i < 2048; i += blockDim.x)
@@ -172,14 +200,21 @@ __global__ void k_sel_pass(const float* __restrict__ v, long n, int nspec, const
 #pragma unroll
         for (int j = 0; j < GROUP; ++j) pf[j] = j < cnt ? (S.prefix[lead[base + j]] >> SHIFT) : 0xffffffffu;
         __syncthreads();
-        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-            const unsigned k = f32_key(v[i]);
+        auto put = [&](float f) {
+            const unsigned k = f32_key(f);
             const unsigned hi = k >> SHIFT;
             const unsigned d = PASS == 1 ? ((k >> 10) & 2047u) : (k & 1023u);
 #pragma unroll
             for (int j = 0; j < GROUP; ++j)
                 if (hi == pf[j]) atomicAdd(&sh[j * NB + d], 1u);
+        };
+        const long n4 = ((reinterpret_cast<uintptr_t>(v) & 15) == 0) ? (n >> 2) : 0;
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+            const float4 x = ((const float4*)v)[i];
+            put(x.x); put(x.y); put(x.z); put(x.w);
         }
+        for (long i = 4 * n4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+            put(v[i]);
         __syncthreads();
         for (int i = threadIdx.x; i < cnt * NB; i += blockDim.x)
             if (sh[i]) atomicAdd(&gh[lead[base + i / NB] * NB + (i % NB)], sh[i]);
@@ -218,7 +253,7 @@ U2PL_API int u2pl_select_f32(const float* values, long n, int nspec, const int* 
                              const long long* kparam, const float* fparam, unsigned* ws, int hist0_done,
                              hipStream_t stream) {
     if (nspec < 1 || 2 * nspec > MAXS) return U2PL_EINVAL;
-    const int grid = grid_for(n, 256, 512);
+    const int grid = grid_for(n / 4 + 1, 256, 256);   // one block per CU: fewer histogram flushes
     if (!hist0_done) {
         hipLaunchKernelGGL(k_sel_hist0, dim3(grid), dim3(256), 0, stream, values, n, ws);
         U2PL_LAUNCH_CHECK();

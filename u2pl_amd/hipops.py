@@ -323,15 +323,15 @@ def contra_phase1(rep_teacher_rows, ld, D, prob, prob_strides, lbits, low_mask, 
     abits = torch.empty(P, dtype=torch.int32, device=dev)
     lowbits = torch.empty(P, dtype=torch.int32, device=dev)
     nbits = torch.empty(P, dtype=torch.int32, device=dev)
+    work = torch.empty(query("u2pl_compact_workspace_bytes", P), dtype=torch.uint8, device=dev)
     call("u2pl_contra_classify", prob, *prob_strides, lbits, low_mask, high_mask, N2, num_labeled, C, h, w,
          float(cfg["current_class_threshold"]), float(cfg["current_class_negative_threshold"]),
-         int(cfg["low_rank"]), int(cfg["high_rank"]), abits, lowbits, nbits)
+         int(cfg["low_rank"]), int(cfg["high_rank"]), abits, lowbits, nbits, work)
     out = ContraPhase1()
     out.cap = P
     out.idx = torch.empty((3, MAXC, P), dtype=torch.int32, device=dev)
     out.counts = torch.empty((3, MAXC), dtype=torch.int32, device=dev)
-    work = torch.empty(query("u2pl_compact_workspace_bytes", P), dtype=torch.uint8, device=dev)
-    call("u2pl_compact_lists", abits, lowbits, nbits, P, C, work, out.idx, P, out.counts)
+    call("u2pl_compact_lists", abits, lowbits, nbits, P, C, work, out.idx, P, out.counts, 1)
     pw = torch.empty(query("u2pl_proto_workspace_bytes", P, C, D), dtype=torch.uint8, device=dev)
     out.proto = torch.empty((C, D), dtype=torch.float32, device=dev)
     call("u2pl_class_prototypes", rep_teacher_rows, ld, D, out.idx, P, out.counts, C, P, pw, out.proto, lowbits)

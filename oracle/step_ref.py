@@ -48,7 +48,7 @@ class CpuStepRef:
         self.base_lr = [g["lr"] for g in self.opt.param_groups]
         self.C, self.aux = num_classes, aux
         self.epochs, self.spe, self.ema_decay, self.sup_only_epoch = epochs, steps_per_epoch, ema_decay, sup_only_epoch
-        self.drop_percent, self.ohem, self.contra, self.apply_aug = drop_percent, ohem, contra, apply_aug
+        self.drop_percent, self.ohem, self.contra, self.apply_aug = drop_percent, ohem, contra, apply_aug   # ohem=None: plain CE
         self.bank = [[np.zeros((0, 256), np.float32)] for _ in range(num_classes)]
         self.ptr = [[0] for _ in range(num_classes)]
         self.qsize = [queue[0]] + [queue[1]] * (num_classes - 1)
@@ -56,6 +56,8 @@ class CpuStepRef:
 
     # ---- pieces -------------------------------------------------------------------------
     def _ohem(self, pred, target):
+        if self.ohem is None:   # Criterion (CELoss, loss_helper.py:295-320), no aux weighting needed here
+            return F.cross_entropy(pred, target, ignore_index=255)
         thresh, min_kept = self.ohem
         _, kept, _ = R.ohem_ce(pred.detach().numpy(), target.numpy(), thresh, min_kept)
         return F.cross_entropy(pred, torch.from_numpy(kept), ignore_index=255)
@@ -112,6 +114,20 @@ class CpuStepRef:
         student, teacher = self.student, self.teacher
         student.train()
         out = {}
+        if epoch < self.sup_only_epoch:   # train_semi.py:288-307: labeled images only, teacher BN stats still move
+            outs = student(image_l)
+            pred = _up(outs["pred"], (h, w))
+            aux = _up(outs["aux"], (h, w)) if self.aux else None
+            sup_loss = self._sup(pred, aux, label_l)
+            teacher.train()
+            with torch.no_grad():
+                teacher(image_l)
+            loss = sup_loss + 0 * outs["rep"].sum() + 0 * outs["rep"].sum()
+            self.opt.zero_grad()
+            loss.backward()
+            self.opt.step()
+            out.update(sup=float(sup_loss), unsup=0.0, contra=0.0)
+            return out
         if epoch == self.sup_only_epoch:
             with torch.no_grad():
                 for t, s in zip(teacher.parameters(), student.parameters()):

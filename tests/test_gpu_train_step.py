@@ -105,3 +105,62 @@ def test_train_step_matches_cpu_port(arch, S):
     for k, (err, upd) in worst.items():
         assert err <= 0.15 * upd + 1e-6, (k, err, upd)  # first-layer grads carry ~3%/step fp32 noise (see model golden: ref32 vs f64)
     assert terr <= 0.05 * worst["decoder.classifier.8.weight"][1] + 1e-6
+
+
+def test_voc_config_sup_only_then_semi_matches_cpu_port():
+    """BASELINE configs[2] family (experiments/pascal/1464/ours): C=21, no aux head, plain CE, head lr x10,
+    sup_only_epoch = 1 -> two supervised-only steps (train_semi.py:288-307; the teacher only refreshes its
+    BN running statistics), then the first semi-supervised steps (teacher <- student copy, EMA decay 0)."""
+    from oracle.step_ref import CpuStepRef
+    from u2pl_amd import configs
+    from u2pl_amd.models.model_helper import ModelBuilder
+    from u2pl_amd.trainer import SemiTrainer
+    from u2pl_amd.utils.loss_helper import get_criterion
+    import copy
+
+    arch, S, B, C, spe = "resnet50", 97, 2, 21, 2
+    cfg = configs.pascal_semi(arch=arch, crop=S, batch_size=B, sync_bn=False, epochs=20)
+    assert "aux_loss" not in cfg["net"] and cfg["trainer"].get("sup_only_epoch", 1) == 1
+    cfg["trainer"]["contrastive"]["current_class_threshold"] = 0.05
+    torch.manual_seed(1)
+    model, teacher = ModelBuilder(cfg["net"]), ModelBuilder(cfg["net"])
+    sd = {k: v.detach().clone().contiguous() for k, v in model.state_dict().items()}
+    tsd = {k: v.detach().clone().contiguous() for k, v in teacher.state_dict().items()}
+    model, teacher = model.to(DEV), teacher.to(DEV)
+    for m in list(model.modules()) + list(teacher.modules()):
+        if isinstance(m, nn.Dropout2d):
+            m.p = 0.0
+    tr = SemiTrainer(cfg, model, teacher, get_criterion(cfg), steps_per_epoch=spe)
+    ok = cfg["trainer"]["optimizer"]["kwargs"]
+    ref = CpuStepRef(arch=arch, num_classes=C, aux=False, epochs=20, steps_per_epoch=spe, lr=ok["lr"],
+                     weight_decay=ok["weight_decay"], lr_times=10, sup_only_epoch=1, ohem=None, p_drop=0.0,
+                     contra=copy.deepcopy(cfg["trainer"]["contrastive"]), state_dict={k: v.clone() for k, v in sd.items()})
+    ref.teacher.load_state_dict({k: v.clone() for k, v in tsd.items()})
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    for step in range(4):
+        il, ll, iu = _inputs(B, S, C, 300 + step)
+        epoch = step // spe
+        np.random.seed(11 + step)
+        r_ref, _ = _gen_randint(70 + step)
+        o = ref.step(il, ll, iu, epoch, randint=lambda hi, n, f=r_ref: f(hi, n).numpy())
+        np.random.seed(11 + step)
+        r_hip, _ = _gen_randint(70 + step)
+        m = [float(x) for x in tr.train_step(il.to(DEV), ll.to(DEV), iu.to(DEV), epoch, randint=r_hip).cpu()]
+        print(dict(step=step, epoch=epoch, hip=m, ref=[o["sup"], o["unsup"], o["contra"]]))
+        tol = 1e-4 if step == 0 else 2e-3
+        for a, b in zip(m, [o["sup"], o["unsup"], o["contra"]]):
+            assert abs(a - b) <= tol * max(1.0, abs(b)), (step, m, o["sup"], o["unsup"], o["contra"])
+        if epoch == 0:
+            assert m[1] == 0.0 and m[2] == 0.0
+            # the teacher's BN buffers moved (train-mode forward), its parameters did not
+            rm = dict(teacher.named_buffers())["encoder.bn1.running_mean"].cpu()
+            rr = ref.teacher.state_dict()["encoder.bn1.running_mean"]
+            assert torch.allclose(rm, rr, rtol=1e-4, atol=1e-6)
+            w = dict(teacher.named_parameters())["encoder.conv1.0.weight"].detach().cpu()
+            assert torch.equal(w, tsd["encoder.conv1.0.weight"])
+    # after the first semi step the EMA decay is 0: teacher == student (train_semi.py:531-548)
+    s_w = dict(model.named_parameters())["decoder.classifier.8.weight"].detach().cpu()
+    t_w = dict(teacher.named_parameters())["decoder.classifier.8.weight"].detach().cpu()
+    assert (s_w - t_w).abs().max().item() <= 0.02 * (s_w - sd["decoder.classifier.8.weight"]).abs().max().item() + 1e-7
+    # head learning-rate multiplier (x10 on pascal) reached the arena step
+    assert tr.lr_mult == [1, 10]

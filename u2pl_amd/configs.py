@@ -31,3 +31,15 @@ def cityscapes_semi(arch="resnet101", crop=769, batch_size=2, epochs=200, sync_b
     if aux:
         cfg["net"]["aux_loss"] = dict(aux_plane=1024, loss_weight=0.4)
     return copy.deepcopy(cfg)
+
+
+def pascal_semi(arch="resnet101", crop=513, batch_size=4, epochs=80, sync_bn=True):
+    """experiments/pascal/1464/ours/config.yaml (BASELINE configs[2] family): C=21, no aux head, plain CE,
+    lr 0.001 with x10 on the heads (train_semi.py:100-110), sup_only_epoch default 1."""
+    cfg = cityscapes_semi(arch=arch, crop=crop, batch_size=batch_size, epochs=epochs, sync_bn=sync_bn, aux=False,
+                          num_classes=21)
+    cfg["dataset"].update(type="pascal_semi", n_sup=1464)
+    cfg["trainer"].pop("sup_only_epoch")          # reference default: 1
+    cfg["trainer"]["optimizer"]["kwargs"].update(lr=0.001, weight_decay=0.0001)
+    cfg["criterion"] = dict(type="CELoss", kwargs=dict(use_weight=False))
+    return cfg

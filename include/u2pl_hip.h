@@ -146,6 +146,32 @@ int u2pl_conv2d_fwd_bnstats_f32(const float* x, long ldx, const float* w, const 
                                 int stride, int pad, int dil, const float* pivot, float* stats_partial,
                                 hipStream_t stream);
 int u2pl_colreduce_finish_f32(const float* partial, int nblk, int C, double* sums, hipStream_t stream);
+/* batch independent row-major GEMMs Y_z[M][Nn] = X_z[M][K] * W_z[Nn][K]^T on the fp32 matrix cores (element
+   strides zx/zw/zy between the problems): the component products of the Winograd convolutions below */
+int u2pl_gemm_batched_f32(const float* x, long ldx, long zx, const float* w, long zw, float* y, long ldy, long zy,
+                          long M, int K, int Nn, int batch, hipStream_t stream);
+/* Winograd F(mt x mt, 3x3), mt = 2 or 4, for nn.Conv2d(k=3, stride=1, padding=dil, dilation=dil) (resnet.py:25-41,
+   base.py:54-83, decoder.py:60-106,132-138): V[a*a][tiles][C] <- x ; U[a*a][O][C] <- w ([O][3][3][C]);
+   Mb[a*a][tiles][O] = V . U^T (u2pl_gemm_batched_f32) ; y <- Mb (+bias).  a = mt + 2, tiles = u2pl_wino_tiles.
+   transposed = 1 builds U'[a*a][C][O] (taps rotated) for the data gradient.  stats_partial (rows =
+   u2pl_wino_stat_blocks) receives the pivot-shifted BatchNorm column sums of y like u2pl_conv2d_fwd_bnstats_f32. */
+size_t u2pl_wino_tiles(int N, int H, int W, int dil, int mt);
+int u2pl_wino_stat_blocks(long tiles, int O);
+int u2pl_wino_input_f32(const float* x, long ldx, int N, int H, int W, int C, int dil, int mt, float* V,
+                        hipStream_t stream);
+int u2pl_wino_weight_f32(const float* w, int O, int C, int transposed, int mt, float* U, hipStream_t stream);
+/* weight-gradient side: Mg[a*a][tiles][O] <- A dY A^T per tile ; batched P_z = Mg_z^T V_z over the tile rows
+   (slabs [nsplit][O][a*a][C], nsplit = u2pl_wgrad_batched_splits) ; dw[O][3][3][C] (+)= G^T (sum of slabs) G */
+int u2pl_wino_gy_f32(const float* gy, long ldg, int N, int H, int W, int O, int dil, int mt, float* Mg,
+                     hipStream_t stream);
+int u2pl_wgrad_batched_splits(long M, int Cin, int Cout, int batch);
+size_t u2pl_wgrad_batched_workspace_bytes(long M, int Cin, int Cout, int batch);
+int u2pl_wgrad_batched_f32(const float* dy, long lddy, long zdy, const float* x, long ldx, long zx, float* part,
+                           long M, int Cin, int Cout, int batch, hipStream_t stream);
+int u2pl_wino_wgrad_finish_f32(const float* part, int nsplit, int O, int C, int mt, int accumulate, float* dw,
+                               hipStream_t stream);
+int u2pl_wino_output_f32(const float* Mb, int N, int H, int W, int O, int dil, int mt, const float* bias, float* y,
+                         long ldy, float* stats_partial, const float* pivot, hipStream_t stream);
 /* autograd of nn.Conv2d under loss.backward() (train_semi.py:527): data and weight gradients */
 int u2pl_conv2d_dgrad_f32(const float* dy, long lddy, const float* wT, float* dx, long lddx, int N, int Hin,
                           int Win, int Cin, int Hout, int Wout, int Cout, int R, int S, int stride, int pad,

@@ -44,9 +44,22 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("Cin,Cout,k,stride,dil,H,bias", CONV_CASES)
-def test_conv2d_fwd_bwd_vs_torch(Cin, Cout, k, stride, dil, H, bias):
+@pytest.fixture(params=[0, 2, 4], ids=["direct", "wino2", "wino4"])
+def conv_algo(request):
+    """every conv test runs on the direct implicit-GEMM kernel and with the 3x3 stride-1 layers forced onto
+    the Winograd F(2x2) / F(4x4) path (min_gain 0: also the dilations the production policy leaves direct)"""
     Kn = K()
+    saved = dict(Kn.CONV_ALGO)
+    Kn.CONV_ALGO.update(wino=request.param, min_gain=0.0)
+    yield request.param
+    Kn.CONV_ALGO.update(saved)
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,dil,H,bias", CONV_CASES)
+def test_conv2d_fwd_bwd_vs_torch(Cin, Cout, k, stride, dil, H, bias, conv_algo):
+    Kn = K()
+    if conv_algo and not (k == 3 and stride == 1 and Cin % 32 == 0):
+        pytest.skip("layer is not Winograd-eligible: covered by the direct run")
     g = torch.Generator().manual_seed(Cin * 7 + Cout + k + dil)
     N, W = 2, H + 2
     pad = dil * (k // 2)
@@ -75,6 +88,42 @@ def test_conv2d_fwd_bwd_vs_torch(Cin, Cout, k, stride, dil, H, bias):
     _close(mine.weight.grad, ref.weight.grad, rtol=3e-4, what="wgrad")
     if bias:
         _close(mine.bias.grad, ref.bias.grad, rtol=3e-4, what="bgrad")
+
+
+def test_winograd_accuracy_and_fused_bn_statistics():
+    """Winograd F(2x2)/F(4x4) against a float64 convolution: F(2x2) is as accurate as the direct fp32 kernel,
+    F(4x4) within the documented 8x of it; the fused BatchNorm statistics equal the stand-alone pass."""
+    Kn = K()
+    g = torch.Generator().manual_seed(5)
+    N, C, O, H, W, d = 2, 256, 256, 49, 45, 2
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(O, C, 3, 3, generator=g) / (9 * C) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), padding=d, dilation=d)
+    errs = {}
+    saved = dict(Kn.CONV_ALGO)
+    try:
+        for algo in (0, 2, 4):
+            Kn.CONV_ALGO.update(wino=algo, min_gain=0.0)
+            conv = Kn.Conv2d(C, O, 3, padding=d, dilation=d, bias=False).to(DEV)
+            with torch.no_grad():
+                conv.weight.copy_(w.to(DEV))
+            bn = Kn.BatchNorm2d(O).to(DEV)
+            bn.train()
+            xd = x.to(DEV).contiguous(memory_format=CL)
+            y = conv(xd)
+            errs[algo] = (y.cpu().double() - ref).abs().max().item()
+            # conv -> BN with the statistics produced by the conv's epilogue / output transform
+            out_fused = Kn.conv_bn(conv, bn, xd, relu=False)
+            bn2 = Kn.BatchNorm2d(O).to(DEV)
+            bn2.train()
+            out_plain = bn2(conv(xd))
+            _close(out_fused, out_plain, rtol=2e-5, atol=2e-6, what=f"fused stats algo {algo}")
+            _close(bn.running_var, bn2.running_var, rtol=1e-5, atol=1e-7, what="running_var")
+    finally:
+        Kn.CONV_ALGO.update(saved)
+    print("max abs error vs float64:", errs)
+    assert errs[2] <= 2.0 * errs[0] + 1e-7
+    assert errs[4] <= 40.0 * errs[0] + 1e-7 and errs[4] < 1e-4
 
 
 def test_conv_large_pixel_count_splitk():

@@ -89,3 +89,18 @@ __device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
     int s = (int)floorf(__fmul_rn((float)dst, scale));
     return s < in_size - 1 ? s : in_size - 1;
 }
+
+// ---- raw buffer loads (hardware out-of-range -> 0) --------------------------
+// Masked gathers without branches or selects on data: every global read is a raw buffer load
+// (buffer_load_dwordx4 ... offen) through a descriptor whose num_records is the byte size of the
+// tensor; an out-of-image tap / out-of-range row gets the offset OOB_OFF, for which the hardware
+// returns zeros.  All loads are unconditional, so they stay in flight under the MFMAs.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define OOB_OFF ((int)0x80000000u)   // >= num_records for every tensor (host checks bytes < 2^31)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}

@@ -31,20 +31,6 @@ struct ConvGeom {
     int mul, off_h, off_w, step, log2div;  // gather: (o*mul + off + r*step) >> log2div
 };
 
-// Masked gathers without branches or selects on data: every global read is a raw buffer load
-// (buffer_load_dwordx4 ... offen) through a descriptor whose num_records is the byte size of the
-// tensor; an out-of-image tap / out-of-range row gets the offset OOB_OFF, for which the hardware
-// returns zeros.  All loads are unconditional, so they stay in flight under the MFMAs.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-#define OOB_OFF ((int)0x80000000u)   // >= num_records for every tensor (host checks bytes < 2^31)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)p, (short)0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, int byte_off) {
-    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-
 // branch-free: returns validity, writes a coordinate that is ALWAYS in [0, lim).
 __device__ __forceinline__ bool gather_coord(int base, int tap, int step, int log2div, int lim, int& out) {
     const int v = base + tap * step;
@@ -60,9 +46,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
                                                        const float* __restrict__ bias, float* __restrict__ y,
                                                        long ldy, ConvGeom g, unsigned xbytes, unsigned wbytes,
                                                        long m_begin, long m_end, float* __restrict__ stats,
-                                                       const float* __restrict__ pivot) {
+                                                       const float* __restrict__ pivot, long zx, long zw, long zy) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32, RB = BN / 32;  // rows per thread per chunk
+    // batched use (Winograd components): blockIdx.z selects an independent GEMM, element strides zx/zw/zy
+    x += (long)blockIdx.z * zx;
+    w += (long)blockIdx.z * zw;
+    y += (long)blockIdx.z * zy;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, xbytes), rw = make_rsrc(w, wbytes);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                  // [2][BM][LDP]
@@ -216,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
 template <int TM, int TN>
 static int launch_igemm(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
                         const ConvGeom& g, long m_begin, long m_end, hipStream_t stream, float* stats = nullptr,
-                        const float* pivot = nullptr) {
+                        const float* pivot = nullptr, int batch = 1, long zx = 0, long zw = 0, long zy = 0) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     if (m_end <= m_begin) return 0;
     const size_t lds = (size_t)2 * (BM + BN) * LDP * sizeof(float);
@@ -229,9 +219,9 @@ static int launch_igemm(const float* x, long ldx, const float* w, const float* b
     const long xb = (((long)g.N * g.Hin * g.Win - 1) * ldx + g.Cin) * 4;
     const long wb = (long)g.Cout * g.R * g.S * g.Cin * 4;
     if (xb >= (1L << 31) || wb >= (1L << 31)) return U2PL_EINVAL;
-    dim3 grid((unsigned)cdiv(m_end - m_begin, BM), (unsigned)cdiv(g.Cout, BN));
+    dim3 grid((unsigned)cdiv(m_end - m_begin, BM), (unsigned)cdiv(g.Cout, BN), (unsigned)batch);
     hipLaunchKernelGGL((k_conv_igemm<TM, TN>), grid, dim3(256), lds, stream, x, ldx, w, bias, y, ldy, g, (unsigned)xb,
-                       (unsigned)wb, m_begin, m_end, stats, pivot);
+                       (unsigned)wb, m_begin, m_end, stats, pivot, zx, zw, zy);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -253,11 +243,11 @@ static double tail_cost(long rows, int cout, int bm, int bn, double eff) {
 }
 // the planner's decisions, shared by the launcher and by the stat-block query
 struct IgemmPlan { long m_body; int tail_tm, tail_tn; int nblk_body, nblk_tail; };
-static IgemmPlan plan_igemm(const ConvGeom& g) {
+static IgemmPlan plan_igemm(const ConvGeom& g, int batch = 1) {
     const long M = (long)g.N * g.Hout * g.Wout;
     IgemmPlan p = {M, 0, 0, 0, 0};
     if (g.Cout <= 64) { p.nblk_body = cdiv(M, 128); return p; }   // single <2,1> launch
-    const int nt = cdiv(g.Cout, 128);
+    const int nt = cdiv(g.Cout, 128) * batch;
     const long mtiles = cdiv(M, 128);
     long body_tiles = (mtiles * nt / NUM_CUS) * NUM_CUS / nt;      // M tiles covered by whole rounds
     if (body_tiles > mtiles) body_tiles = mtiles;
@@ -265,8 +255,8 @@ static IgemmPlan plan_igemm(const ConvGeom& g) {
     p.nblk_body = cdiv(p.m_body, 128);
     const long tail = M - p.m_body;
     if (tail <= 0) return p;
-    const double c22 = tail_cost(tail, g.Cout, 128, 128, 1.0), c12 = tail_cost(tail, g.Cout, 64, 128, 0.9);
-    const double c11 = tail_cost(tail, g.Cout, 64, 64, 0.8);
+    const double c22 = tail_cost(tail, g.Cout * batch, 128, 128, 1.0), c12 = tail_cost(tail, g.Cout * batch, 64, 128, 0.9);
+    const double c11 = tail_cost(tail, g.Cout * batch, 64, 64, 0.8);
     if (c22 <= c12 && c22 <= c11) { p.tail_tm = 2; p.tail_tn = 2; }
     else if (c12 <= c11) { p.tail_tm = 1; p.tail_tn = 2; }
     else { p.tail_tm = 1; p.tail_tn = 1; }
@@ -274,17 +264,27 @@ static IgemmPlan plan_igemm(const ConvGeom& g) {
     return p;
 }
 static int run_igemm(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
-                     const ConvGeom& g, hipStream_t stream, float* stats = nullptr, const float* pivot = nullptr) {
+                     const ConvGeom& g, hipStream_t stream, float* stats = nullptr, const float* pivot = nullptr,
+                     int batch = 1, long zx = 0, long zw = 0, long zy = 0) {
     if (g.Cin % BK) return U2PL_EINVAL;
     const long M = (long)g.N * g.Hout * g.Wout;
-    const IgemmPlan p = plan_igemm(g);
-    if (g.Cout <= 64) return launch_igemm<2, 1>(x, ldx, w, bias, y, ldy, g, 0, M, stream, stats, pivot);
-    int rc = launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, 0, p.m_body, stream, stats, pivot);
+    const IgemmPlan p = plan_igemm(g, batch);
+    if (g.Cout <= 64) return launch_igemm<2, 1>(x, ldx, w, bias, y, ldy, g, 0, M, stream, stats, pivot, batch, zx, zw, zy);
+    int rc = launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, 0, p.m_body, stream, stats, pivot, batch, zx, zw, zy);
     if (rc || p.nblk_tail == 0) return rc;
     float* st = stats ? stats + (long)p.nblk_body * 2 * g.Cout : nullptr;
-    if (p.tail_tm == 2) return launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot);
-    if (p.tail_tn == 2) return launch_igemm<1, 2>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot);
-    return launch_igemm<1, 1>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot);
+    if (p.tail_tm == 2) return launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy);
+    if (p.tail_tn == 2) return launch_igemm<1, 2>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy);
+    return launch_igemm<1, 1>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy);
+}
+
+// batch independent row-major GEMMs  Y_z[M][Nn] = X_z[M][K] * W_z[Nn][K]^T  (the Winograd component products)
+U2PL_API int u2pl_gemm_batched_f32(const float* x, long ldx, long zx, const float* w, long zw, float* y, long ldy,
+                                   long zy, long M, int K, int Nn, int batch, hipStream_t stream) {
+    if (M <= 0 || batch <= 0) return 0;
+    if (M >= (1L << 31)) return U2PL_EINVAL;
+    ConvGeom g = {1, (int)M, 1, K, (int)M, 1, Nn, 1, 1, 1, 0, 0, 1, 0};
+    return run_igemm(x, ldx, w, nullptr, y, ldy, g, stream, nullptr, nullptr, batch, zx, zw, zy);
 }
 
 // nn.Conv2d forward: resnet.py:25-41,178-186; base.py:23-83; decoder.py:60-106,132-138
@@ -354,8 +354,15 @@ template <int TM, int TN>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const float* __restrict__ dy, long lddy,
                                                        const float* __restrict__ x, long ldx,
                                                        float* __restrict__ part, ConvGeom g, int ctiles,
-                                                       int chunks_per_split, unsigned dybytes, unsigned xbytes) {
+                                                       int chunks_per_split, unsigned dybytes, unsigned xbytes,
+                                                       long zdy, long zx) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
+    // batched use (Winograd components as "taps" with an identity gather): tap t reads dy + t*zdy, x + t*zx
+    {
+        const int tap_b = blockIdx.x / ctiles;
+        dy += (long)tap_b * zdy;
+        x += (long)tap_b * zx;
+    }
     const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, dybytes), rx = make_rsrc(x, xbytes);
     constexpr int PA = BM + 4, PB = BN + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -462,10 +469,24 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const float* __restrict__
 // dW = (accumulate ? dW : 0) + sum_z part[z]   (ordered => deterministic)
 __global__ void k_wgrad_reduce(const float* __restrict__ part, long wsz, int nsplit, int accumulate,
                                float* __restrict__ dw) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < wsz; i += (long)gridDim.x * blockDim.x) {
-        float acc = accumulate ? dw[i] : 0.f;
-        for (int z = 0; z < nsplit; ++z) acc += part[(long)z * wsz + i];
-        dw[i] = acc;
+    // wsz % 4 == 0 (Cin % 4 == 0); 8 independent slab loads in flight, added in slab order
+    const long w4 = wsz >> 2;
+    const float4* p4 = (const float4*)part;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < w4; i += (long)gridDim.x * blockDim.x) {
+        float4 acc = accumulate ? ((const float4*)dw)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        int z = 0;
+        for (; z + 8 <= nsplit; z += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p4[(long)(z + u) * w4 + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        for (; z < nsplit; ++z) {
+            const float4 v = p4[(long)z * w4 + i];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        ((float4*)dw)[i] = acc;
     }
 }
 
@@ -491,7 +512,7 @@ U2PL_API size_t u2pl_conv2d_wgrad_workspace_bytes(int N, int Hout, int Wout, int
 
 template <int TM, int TN>
 static int launch_wgrad(const float* dy, long lddy, const float* x, long ldx, float* part, const ConvGeom& g,
-                        int ctiles, int nsplit, int cps, hipStream_t stream) {
+                        int ctiles, int nsplit, int cps, hipStream_t stream, long zdy = 0, long zx = 0) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     const size_t lds = (size_t)2 * BK * (BM + 4 + BN + 4) * sizeof(float);
     static bool attr_set = false;
@@ -504,7 +525,7 @@ static int launch_wgrad(const float* dy, long lddy, const float* x, long ldx, fl
     if (dyb >= (1L << 31) || xb >= (1L << 31)) return U2PL_EINVAL;
     dim3 grid((unsigned)(ctiles * g.R * g.S), (unsigned)cdiv(g.Cout, BM), (unsigned)nsplit);
     hipLaunchKernelGGL((k_conv_wgrad<TM, TN>), grid, dim3(256), lds, stream, dy, lddy, x, ldx, part, g, ctiles, cps,
-                       (unsigned)dyb, (unsigned)xb);
+                       (unsigned)dyb, (unsigned)xb, zdy, zx);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -527,9 +548,38 @@ U2PL_API int u2pl_conv2d_wgrad_f32(const float* dy, long lddy, const float* x, l
     else rc = launch_wgrad<1, 1>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
     if (rc) return rc;
     const long wsz = (long)Cout * R * S * Cin;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(grid_for(wsz, 256)), dim3(256), 0, stream, part, wsz, ns, accumulate, dw);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(grid_for(wsz / 4, 256)), dim3(256), 0, stream, part, wsz, ns, accumulate, dw);
     U2PL_LAUNCH_CHECK();
     return 0;
+}
+
+// batch independent weight-gradient GEMMs  P_z[Cout][Cin] = dY_z[M][Cout]^T * X_z[M][Cin]  (Winograd components;
+// reduction over the M tile rows, split into slabs like the direct wgrad).  part: [nsplit][Cout][batch][Cin]
+static ConvGeom batched_wgrad_geom(long M, int Cin, int Cout, int batch) {
+    // identity gather for every "tap": step = 0, offsets 0
+    ConvGeom g = {1, (int)M, 1, Cin, (int)M, 1, Cout, batch, 1, 1, 0, 0, 0, 0};
+    return g;
+}
+U2PL_API int u2pl_wgrad_batched_splits(long M, int Cin, int Cout, int batch) {
+    ConvGeom g = batched_wgrad_geom(M, Cin, Cout, batch);
+    int ct, ns, cps;
+    wgrad_plan(g, Cout > 64 ? 128 : 64, Cin > 64 ? 128 : 64, ct, ns, cps);
+    return ns;
+}
+U2PL_API size_t u2pl_wgrad_batched_workspace_bytes(long M, int Cin, int Cout, int batch) {
+    return (size_t)u2pl_wgrad_batched_splits(M, Cin, Cout, batch) * Cout * batch * Cin * sizeof(float);
+}
+U2PL_API int u2pl_wgrad_batched_f32(const float* dy, long lddy, long zdy, const float* x, long ldx, long zx,
+                                    float* part, long M, int Cin, int Cout, int batch, hipStream_t stream) {
+    if (Cin % 4 || Cout % 4 || M <= 0 || M >= (1L << 31)) return U2PL_EINVAL;
+    ConvGeom g = batched_wgrad_geom(M, Cin, Cout, batch);
+    const int BM = Cout > 64 ? 128 : 64, BN = Cin > 64 ? 128 : 64;
+    int ct, ns, cps;
+    wgrad_plan(g, BM, BN, ct, ns, cps);
+    if (BM == 128 && BN == 128) return launch_wgrad<2, 2>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx);
+    if (BM == 128) return launch_wgrad<2, 1>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx);
+    if (BN == 128) return launch_wgrad<1, 2>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx);
+    return launch_wgrad<1, 1>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx);
 }
 
 // ---------------------------------------------------------------------------

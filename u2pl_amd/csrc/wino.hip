@@ -1,0 +1,468 @@
+// Winograd minimal-filtering form of the stride-1 3x3 (dilated, "same") convolutions of the ResNet /
+// DeepLabv3+ stack (reference: nn.Conv2d(k=3, padding=d, dilation=d) in u2pl/models/resnet.py:25-41,
+// base.py:54-83, decoder.py:60-106,132-138; the reference's cuDNN path picks the same algorithm class for
+// fp32).  All arithmetic is fp32; the component products run on the fp32 matrix cores through the batched
+// implicit-GEMM kernel of conv.hip (u2pl_gemm_batched_f32).
+//
+//   F(m x m, 3 x 3), m = 2 or 4, a = m + 2:   Y = A^T [ (G g G^T) . (B^T d B) ] A     (Lavin & Gray)
+//
+// Dilation d is handled by polyphase decomposition: the outputs with (oy, ox) = (py, px) mod d form an
+// undilated pad-1 convolution over the sub-image x[py + d*u, px + d*v]; tiles are laid over the sub-images.
+//   tile id t = (((n*d + py)*d + px)*Ty + ty)*Tx + tx        Ty = ceil(ceil(H/d)/m), Tx likewise
+//   V  [a*a][tiles][Cin]   transformed input  (GEMM A operand, K = Cin contiguous)
+//   U  [a*a][Cout][Cin]    transformed weights (GEMM B operand)
+//   Mb [a*a][tiles][Cout]  component products
+// The data-gradient of such a convolution is the same convolution with the taps rotated by 180 degrees and
+// the channel roles swapped: `transposed` in the weight transform produces U'[a*a][Cin][Cout] for it.
+#include "common.h"
+#include "u2pl_hip.h"
+
+struct WinoGeom {
+    int N, H, W, C, dil, Ty, Tx;
+    long tiles;
+};
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4mul(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+// a + s*b written as separate multiply and add (-ffp-contract=off keeps it that way)
+__device__ __forceinline__ float4 f4axpy(float4 a, float s, float4 b) { return f4add(a, f4mul(s, b)); }
+
+// B^T d for one 6-vector / 4-vector of float4 (applied to columns, then to rows)
+template <int MT> struct WinoT;
+template <> struct WinoT<4> {
+    static constexpr int A = 6;
+    __device__ static __forceinline__ void bt(const float4 (&d)[6], float4 (&r)[6]) {
+        const float4 p = f4axpy(d[4], -4.f, d[2]);   // d4 - 4 d2
+        const float4 q = f4axpy(d[3], -4.f, d[1]);   // d3 - 4 d1
+        const float4 s = f4sub(d[4], d[2]);          // d4 - d2
+        const float4 t = f4mul(2.f, f4sub(d[3], d[1]));
+        r[0] = f4add(f4axpy(f4mul(4.f, d[0]), -5.f, d[2]), d[4]);
+        r[1] = f4add(p, q);
+        r[2] = f4sub(p, q);
+        r[3] = f4add(s, t);
+        r[4] = f4sub(s, t);
+        r[5] = f4add(f4axpy(f4mul(4.f, d[1]), -5.f, d[3]), d[5]);
+    }
+    // A^T m : 6 -> 4
+    __device__ static __forceinline__ void at(const float4 (&m)[6], float4 (&y)[4]) {
+        const float4 s12 = f4add(m[1], m[2]), d12 = f4sub(m[1], m[2]);
+        const float4 s34 = f4add(m[3], m[4]), d34 = f4sub(m[3], m[4]);
+        y[0] = f4add(f4add(m[0], s12), s34);
+        y[1] = f4axpy(d12, 2.f, d34);
+        y[2] = f4axpy(s12, 4.f, s34);
+        y[3] = f4add(f4axpy(d12, 8.f, d34), m[5]);
+    }
+    // A v : 4 -> 6 (transpose of the output transform: weight-gradient side)
+    __device__ static __forceinline__ void av(const float4 (&v)[4], float4 (&r)[6]) {
+        const float4 e = f4add(v[0], v[2]), o = f4add(v[1], v[3]);
+        const float4 e4 = f4axpy(v[0], 4.f, v[2]), o4 = f4axpy(f4mul(2.f, v[1]), 8.f, v[3]);
+        r[0] = v[0];
+        r[1] = f4add(e, o);
+        r[2] = f4sub(e, o);
+        r[3] = f4add(e4, o4);
+        r[4] = f4sub(e4, o4);
+        r[5] = v[3];
+    }
+    // G^T v : 6 -> 3 (scalar)
+    __device__ static __forceinline__ void gt(const float (&v)[6], float (&r)[3]) {
+        const float s12 = v[1] + v[2], s34 = v[3] + v[4];
+        r[0] = v[0] * 0.25f - s12 * (1.f / 6.f) + s34 * (1.f / 24.f);
+        r[1] = (v[2] - v[1]) * (1.f / 6.f) + (v[3] - v[4]) * (1.f / 12.f);
+        r[2] = (s34 - s12) * (1.f / 6.f) + v[5];
+    }
+    // G g : 3 -> 6 (scalar)
+    __device__ static __forceinline__ void gg(const float (&g)[3], float (&r)[6]) {
+        const float a = (g[0] + g[2]) * (-1.f / 6.f), b = g[1] * (1.f / 6.f);
+        const float c = g[0] * (1.f / 24.f) + g[2] * (1.f / 6.f), e = g[1] * (1.f / 12.f);
+        r[0] = g[0] * 0.25f;
+        r[1] = a - b;
+        r[2] = a + b;
+        r[3] = c + e;
+        r[4] = c - e;
+        r[5] = g[2];
+    }
+};
+template <> struct WinoT<2> {
+    static constexpr int A = 4;
+    __device__ static __forceinline__ void bt(const float4 (&d)[4], float4 (&r)[4]) {
+        r[0] = f4sub(d[0], d[2]);
+        r[1] = f4add(d[1], d[2]);
+        r[2] = f4sub(d[2], d[1]);
+        r[3] = f4sub(d[1], d[3]);
+    }
+    __device__ static __forceinline__ void at(const float4 (&m)[4], float4 (&y)[2]) {
+        y[0] = f4add(f4add(m[0], m[1]), m[2]);
+        y[1] = f4sub(f4sub(m[1], m[2]), m[3]);
+    }
+    __device__ static __forceinline__ void av(const float4 (&v)[2], float4 (&r)[4]) {
+        r[0] = v[0];
+        r[1] = f4add(v[0], v[1]);
+        r[2] = f4sub(v[0], v[1]);
+        r[3] = f4mul(-1.f, v[1]);
+    }
+    __device__ static __forceinline__ void gt(const float (&v)[4], float (&r)[3]) {
+        r[0] = v[0] + 0.5f * (v[1] + v[2]);
+        r[1] = 0.5f * (v[1] - v[2]);
+        r[2] = 0.5f * (v[1] + v[2]) + v[3];
+    }
+    __device__ static __forceinline__ void gg(const float (&g)[3], float (&r)[4]) {
+        r[0] = g[0];
+        r[1] = 0.5f * ((g[0] + g[2]) + g[1]);
+        r[2] = 0.5f * ((g[0] + g[2]) - g[1]);
+        r[3] = g[2];
+    }
+};
+
+__device__ __forceinline__ void tile_coords(const WinoGeom& g, long t, int& n, int& py, int& px, int& ty, int& tx) {
+    tx = (int)(t % g.Tx); t /= g.Tx;
+    ty = (int)(t % g.Ty); t /= g.Ty;
+    px = (int)(t % g.dil); t /= g.dil;
+    py = (int)(t % g.dil);
+    n = (int)(t / g.dil);
+}
+
+// ---- input transform: one thread per (tile, 4 channels) ----------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void k_wino_input(const float* __restrict__ x, long ldx, unsigned xbytes, WinoGeom g,
+                                                    float* __restrict__ V) {
+    constexpr int A = WinoT<MT>::A;
+    const int C4 = g.C >> 2;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= g.tiles * C4) return;
+    const int c4 = (int)(idx % C4);
+    const long t = idx / C4;
+    int n, py, px, ty, tx;
+    tile_coords(g, t, n, py, px, ty, tx);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, xbytes);
+    const int ldxb = (int)ldx * 4;
+    const int iy0 = py + g.dil * (ty * MT - 1), ix0 = px + g.dil * (tx * MT - 1);
+    float4 d[A][A];
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        const int iy = iy0 + i * g.dil;
+        const bool oky = iy >= 0 && iy < g.H;
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            const int ix = ix0 + j * g.dil;
+            const bool ok = oky && ix >= 0 && ix < g.W;
+            const int off = ((n * g.H + iy) * g.W + ix) * ldxb + c4 * 16;
+            d[i][j] = buf_load4(rx, ok ? off : OOB_OFF);
+        }
+    }
+    // columns: t[:, j] = B^T d[:, j]
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+        float4 col[A], r[A];
+#pragma unroll
+        for (int i = 0; i < A; ++i) col[i] = d[i][j];
+        WinoT<MT>::bt(col, r);
+#pragma unroll
+        for (int i = 0; i < A; ++i) d[i][j] = r[i];
+    }
+    // rows: V[i, :] = B^T (t[i, :])^T   (t B == (B^T t^T)^T)
+    const long comp_stride = g.tiles * (long)g.C;
+    float* out = V + t * g.C + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        float4 r[A];
+        WinoT<MT>::bt(d[i], r);
+#pragma unroll
+        for (int j = 0; j < A; ++j) *(float4*)(out + (long)(i * A + j) * comp_stride) = r[j];
+    }
+}
+
+// ---- weight transform: one thread per (o, c) ------------------------------------------------------------------
+// w: [O][3][3][C] (channels_last OIHW).  transposed = 0: U[comp][O][C] = G g G^T
+// transposed = 1 (data gradient): taps rotated 180 degrees, U[comp][C][O]
+template <int MT>
+__global__ void k_wino_weight(const float* __restrict__ w, int O, int C, int transposed, float* __restrict__ U) {
+    constexpr int A = WinoT<MT>::A;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= (long)O * C) return;
+    // forward: c fastest (coalesced reads and writes); transposed: o fastest (coalesced U' writes, 4x the volume
+    // of the reads)
+    const int c = transposed ? (int)(idx / O) : (int)(idx % C), o = transposed ? (int)(idx % O) : (int)(idx / C);
+    float gk[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int rr = transposed ? 2 - r : r, ss = transposed ? 2 - s : s;
+            gk[r][s] = w[(((long)o * 3 + rr) * 3 + ss) * C + c];
+        }
+    float t[A][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        float col[3] = {gk[0][s], gk[1][s], gk[2][s]}, r[A];
+        WinoT<MT>::gg(col, r);
+#pragma unroll
+        for (int i = 0; i < A; ++i) t[i][s] = r[i];
+    }
+    const long comp_stride = (long)O * C;
+    const long base = transposed ? (long)c * O + o : (long)o * C + c;
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        float r[A];
+        WinoT<MT>::gg(t[i], r);
+#pragma unroll
+        for (int j = 0; j < A; ++j) U[(long)(i * A + j) * comp_stride + base] = r[j];
+    }
+}
+
+// ---- output transform: one thread per (tile, 4 output channels) -------------------------------------------
+// Optionally produces the following BatchNorm's statistics (pivot-shifted column sums, the two-stage
+// column-reduce partial format [nblk][2][O]): a block covers 256 / (O/4) consecutive tiles x all channels.
+template <int MT>
+__global__ __launch_bounds__(256) void k_wino_output(const float* __restrict__ Mb, WinoGeom g, int O,
+                                                     const float* __restrict__ bias, float* __restrict__ y, long ldy,
+                                                     float* __restrict__ stats, const float* __restrict__ pivot) {
+    constexpr int A = WinoT<MT>::A;
+    __shared__ __attribute__((aligned(16))) float red[2][256][4];
+    const int O4 = O >> 2;
+    const int tpb = 256 / O4 > 0 ? 256 / O4 : 1;      // tiles per block when stats are requested
+    long t;
+    int o4;
+    bool live;
+    if (stats) {
+        o4 = threadIdx.x % O4;
+        const int tl = threadIdx.x / O4;
+        t = (long)blockIdx.x * tpb + tl;
+        live = tl < tpb && t < g.tiles;
+    } else {
+        const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+        o4 = (int)(idx % O4);
+        t = idx / O4;
+        live = t < g.tiles;
+    }
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    if (live) {
+        int n, py, px, ty, tx;
+        tile_coords(g, t, n, py, px, ty, tx);
+        const long comp_stride = g.tiles * (long)O;
+        const float* in = Mb + t * O + o4 * 4;
+        float4 m[A][A];
+#pragma unroll
+        for (int i = 0; i < A; ++i)
+#pragma unroll
+            for (int j = 0; j < A; ++j) m[i][j] = *(const float4*)(in + (long)(i * A + j) * comp_stride);
+        float4 tmp[MT][A];
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            float4 col[A], r[MT];
+#pragma unroll
+            for (int i = 0; i < A; ++i) col[i] = m[i][j];
+            WinoT<MT>::at(col, r);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) tmp[i][j] = r[i];
+        }
+        const float* bp = bias + o4 * 4;
+        const float* pp = pivot + o4 * 4;
+        const float4 bv = bias ? make_float4(bp[0], bp[1], bp[2], bp[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 pv = (stats && pivot) ? make_float4(pp[0], pp[1], pp[2], pp[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float4 r[MT];
+            WinoT<MT>::at(tmp[i], r);
+            const int oy = py + g.dil * (ty * MT + i);
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int ox = px + g.dil * (tx * MT + j);
+                if (oy < g.H && ox < g.W) {
+                    const float4 v = f4add(r[j], bv);
+                    *(float4*)(y + ((long)(n * g.H + oy) * g.W + ox) * ldy + o4 * 4) = v;
+                    const float4 dv = f4sub(v, pv);
+                    s1 = f4add(s1, dv);
+                    s2 = f4add(s2, make_float4(dv.x * dv.x, dv.y * dv.y, dv.z * dv.z, dv.w * dv.w));
+                }
+            }
+        }
+    }
+    if (!stats) return;
+    *(float4*)red[0][threadIdx.x] = s1;
+    *(float4*)red[1][threadIdx.x] = s2;
+    __syncthreads();
+    // thread c < O sums its channel over the block's tiles in tile order (deterministic)
+    for (int c = threadIdx.x; c < O; c += 256) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int tl = 0; tl < tpb; ++tl) {
+            a1 += red[0][tl * O4 + (c >> 2)][c & 3];
+            a2 += red[1][tl * O4 + (c >> 2)][c & 3];
+        }
+        stats[(long)blockIdx.x * 2 * O + c] = a1;
+        stats[(long)blockIdx.x * 2 * O + O + c] = a2;
+    }
+}
+
+// ---- weight-gradient side ----------------------------------------------------------------------------------
+// dU[comp] = sum_tiles (A dY_tile A^T)[comp] (x) V[comp]  ;  dg = G^T dU G
+// gy transform: one thread per (tile, 4 channels of dY): MT x MT output-gradient tile -> a x a components
+template <int MT>
+__global__ __launch_bounds__(256) void k_wino_gy(const float* __restrict__ gy, long ldg, unsigned gbytes, WinoGeom g,
+                                                 float* __restrict__ Mg) {
+    constexpr int A = WinoT<MT>::A;
+    const int C4 = g.C >> 2;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= g.tiles * C4) return;
+    const int c4 = (int)(idx % C4);
+    const long t = idx / C4;
+    int n, py, px, ty, tx;
+    tile_coords(g, t, n, py, px, ty, tx);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(gy, gbytes);
+    const int ldb = (int)ldg * 4;
+    float4 v[MT][MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int oy = py + g.dil * (ty * MT + i);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int ox = px + g.dil * (tx * MT + j);
+            const bool ok = oy < g.H && ox < g.W;
+            const int off = ((n * g.H + oy) * g.W + ox) * ldb + c4 * 16;
+            v[i][j] = buf_load4(rg, ok ? off : OOB_OFF);
+        }
+    }
+    float4 tmp[A][MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        float4 col[MT], r[A];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) col[i] = v[i][j];
+        WinoT<MT>::av(col, r);
+#pragma unroll
+        for (int i = 0; i < A; ++i) tmp[i][j] = r[i];
+    }
+    const long comp_stride = g.tiles * (long)g.C;
+    float* out = Mg + t * g.C + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        float4 r[A];
+        WinoT<MT>::av(tmp[i], r);
+#pragma unroll
+        for (int j = 0; j < A; ++j) *(float4*)(out + (long)(i * A + j) * comp_stride) = r[j];
+    }
+}
+
+// part: [nsplit][O][a*a][C] partial slabs of the batched weight-gradient GEMMs -> dw [O][3][3][C]
+// (slabs summed in order, then G^T . G); one thread per (o, c)
+template <int MT>
+__global__ void k_wino_wgrad_finish(const float* __restrict__ part, int nsplit, int O, int C, int accumulate,
+                                    float* __restrict__ dw) {
+    constexpr int A = WinoT<MT>::A;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= (long)O * C) return;
+    const int c = (int)(idx % C), o = (int)(idx / C);
+    const long slab = (long)O * A * A * C;
+    const float* p = part + (long)o * A * A * C + c;
+    float u[A][A];
+#pragma unroll
+    for (int i = 0; i < A; ++i)
+#pragma unroll
+        for (int j = 0; j < A; ++j) u[i][j] = 0.f;
+    for (int z = 0; z < nsplit; ++z)
+#pragma unroll
+        for (int i = 0; i < A; ++i)
+#pragma unroll
+            for (int j = 0; j < A; ++j) u[i][j] += p[(long)z * slab + (long)(i * A + j) * C];
+    float t[3][A];
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+        float col[A], r[3];
+#pragma unroll
+        for (int i = 0; i < A; ++i) col[i] = u[i][j];
+        WinoT<MT>::gt(col, r);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i][j] = r[i];
+    }
+#pragma unroll
+    for (int r3 = 0; r3 < 3; ++r3) {
+        float r[3];
+        WinoT<MT>::gt(t[r3], r);
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            float* d = dw + (((long)o * 3 + r3) * 3 + s3) * C + c;
+            *d = accumulate ? *d + r[s3] : r[s3];
+        }
+    }
+}
+
+static int wino_geom(int N, int H, int W, int C, int dil, int mt, WinoGeom& g) {
+    if (mt != 2 && mt != 4) return U2PL_EINVAL;
+    if (dil < 1 || C % 4) return U2PL_EINVAL;
+    g.N = N; g.H = H; g.W = W; g.C = C; g.dil = dil;
+    g.Ty = cdiv(cdiv(H, dil), mt);
+    g.Tx = cdiv(cdiv(W, dil), mt);
+    g.tiles = (long)N * dil * dil * g.Ty * g.Tx;
+    return 0;
+}
+
+U2PL_API size_t u2pl_wino_tiles(int N, int H, int W, int dil, int mt) {
+    WinoGeom g;
+    if (wino_geom(N, H, W, 4, dil, mt, g)) return 0;
+    return (size_t)g.tiles;
+}
+// rows of the [nblk][2][O] statistics partials written by u2pl_wino_output_f32
+U2PL_API int u2pl_wino_stat_blocks(long tiles, int O) {
+    const int tpb = 256 / (O / 4) > 0 ? 256 / (O / 4) : 1;
+    return (int)((tiles + tpb - 1) / tpb);
+}
+
+U2PL_API int u2pl_wino_input_f32(const float* x, long ldx, int N, int H, int W, int C, int dil, int mt, float* V,
+                                 hipStream_t stream) {
+    WinoGeom g;
+    if (wino_geom(N, H, W, C, dil, mt, g)) return U2PL_EINVAL;
+    const long xb = (((long)N * H * W - 1) * ldx + C) * 4;
+    if (xb >= (1L << 31)) return U2PL_EINVAL;
+    const long total = g.tiles * (C / 4);
+    const dim3 grid((unsigned)cdiv(total, 256)), block(256);
+    if (mt == 4) hipLaunchKernelGGL(k_wino_input<4>, grid, block, 0, stream, x, ldx, (unsigned)xb, g, V);
+    else hipLaunchKernelGGL(k_wino_input<2>, grid, block, 0, stream, x, ldx, (unsigned)xb, g, V);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+U2PL_API int u2pl_wino_weight_f32(const float* w, int O, int C, int transposed, int mt, float* U, hipStream_t stream) {
+    if (mt != 2 && mt != 4) return U2PL_EINVAL;
+    const dim3 grid((unsigned)cdiv((long)O * C, 256)), block(256);
+    if (mt == 4) hipLaunchKernelGGL(k_wino_weight<4>, grid, block, 0, stream, w, O, C, transposed, U);
+    else hipLaunchKernelGGL(k_wino_weight<2>, grid, block, 0, stream, w, O, C, transposed, U);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+U2PL_API int u2pl_wino_output_f32(const float* Mb, int N, int H, int W, int O, int dil, int mt, const float* bias,
+                                  float* y, long ldy, float* stats_partial, const float* pivot, hipStream_t stream) {
+    WinoGeom g;
+    if (wino_geom(N, H, W, O, dil, mt, g)) return U2PL_EINVAL;
+    if (stats_partial && (O / 4 > 256 || (O & 3))) return U2PL_EINVAL;
+    const long total = g.tiles * (O / 4);
+    const unsigned nblk = stats_partial ? (unsigned)u2pl_wino_stat_blocks(g.tiles, O) : (unsigned)cdiv(total, 256);
+    if (mt == 4) hipLaunchKernelGGL(k_wino_output<4>, dim3(nblk), dim3(256), 0, stream, Mb, g, O, bias, y, ldy, stats_partial, pivot);
+    else hipLaunchKernelGGL(k_wino_output<2>, dim3(nblk), dim3(256), 0, stream, Mb, g, O, bias, y, ldy, stats_partial, pivot);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+U2PL_API int u2pl_wino_gy_f32(const float* gy, long ldg, int N, int H, int W, int O, int dil, int mt, float* Mg,
+                              hipStream_t stream) {
+    WinoGeom g;
+    if (wino_geom(N, H, W, O, dil, mt, g)) return U2PL_EINVAL;
+    const long gb = (((long)N * H * W - 1) * ldg + O) * 4;
+    if (gb >= (1L << 31)) return U2PL_EINVAL;
+    const long total = g.tiles * (O / 4);
+    const dim3 grid((unsigned)cdiv(total, 256)), block(256);
+    if (mt == 4) hipLaunchKernelGGL(k_wino_gy<4>, grid, block, 0, stream, gy, ldg, (unsigned)gb, g, Mg);
+    else hipLaunchKernelGGL(k_wino_gy<2>, grid, block, 0, stream, gy, ldg, (unsigned)gb, g, Mg);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+U2PL_API int u2pl_wino_wgrad_finish_f32(const float* part, int nsplit, int O, int C, int mt, int accumulate, float* dw,
+                                        hipStream_t stream) {
+    if (mt != 2 && mt != 4) return U2PL_EINVAL;
+    const dim3 grid((unsigned)cdiv((long)O * C, 256)), block(256);
+    if (mt == 4) hipLaunchKernelGGL(k_wino_wgrad_finish<4>, grid, block, 0, stream, part, nsplit, O, C, accumulate, dw);
+    else hipLaunchKernelGGL(k_wino_wgrad_finish<2>, grid, block, 0, stream, part, nsplit, O, C, accumulate, dw);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}

@@ -87,6 +87,47 @@ def _grad_sink(p):
 
 
 # ------------------------------------------------------------------ convolution
+# Stride-1 "same" 3x3 convolutions can run in Winograd form (csrc/wino.hip): F(4x4,3x3) does 1/4 of the direct
+# multiplies (F(2x2,3x3): 4/9) in fp32 on the same matrix cores, at the cost of two HBM-bound transform passes.
+# U2PL_CONV_WINO = 0 (direct implicit GEMM only) | 2 | 4 (tile size; default 4).  Dilated convolutions are
+# decomposed into d*d sub-images; a layer only takes the Winograd path when the multiply reduction that is
+# left after tile padding is worth the transforms.
+CONV_ALGO = {"wino": int(os.environ.get("U2PL_CONV_WINO", "4")), "min_gain": float(os.environ.get("U2PL_WINO_MIN_GAIN", "1.7")),
+             "wgrad": int(os.environ.get("U2PL_WINO_WGRAD", "1"))}
+
+
+def wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W):
+    """-> Winograd output-tile size (2 / 4) for this layer, or 0 for the direct kernel."""
+    mt = CONV_ALGO["wino"]
+    if mt not in (2, 4) or R != 3 or S != 3 or stride != 1 or pad != dil or Cin % 32 or Cout % 4 or Cout < 32:
+        return 0
+    th, tw = -(-(-(-H // dil)) // mt), -(-(-(-W // dil)) // mt)
+    eff = (H * W) / float(dil * dil * th * tw * mt * mt)          # useful / computed outputs
+    gain = 9.0 * mt * mt / ((mt + 2) ** 2) * eff                    # direct multiplies / Winograd multiplies
+    return mt if gain >= CONV_ALGO["min_gain"] else 0
+
+
+def _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, mt, transposed, pivot=None):
+    """y <- conv3x3(x) in Winograd form; transposed: data-gradient (x = dY with Cout channels, y = dX with Cin).
+    Returns the fused BatchNorm partial sums (or None)."""
+    dev = x.device
+    a2 = (mt + 2) ** 2
+    Ci, Co = (Cout, Cin) if transposed else (Cin, Cout)
+    tiles = query("u2pl_wino_tiles", N, H, W, dil, mt)
+    U = torch.empty(a2 * Cout * Cin, dtype=torch.float32, device=dev)
+    call("u2pl_wino_weight_f32", weight, Cout, Cin, int(transposed), mt, U)
+    V = torch.empty(a2 * tiles * Ci, dtype=torch.float32, device=dev)
+    call("u2pl_wino_input_f32", x, ldx, N, H, W, Ci, dil, mt, V)
+    Mb = torch.empty(a2 * tiles * Co, dtype=torch.float32, device=dev)
+    call("u2pl_gemm_batched_f32", V, Ci, tiles * Ci, U, Co * Ci, Mb, Co, tiles * Co, tiles, Ci, Co, a2)
+    part = None
+    if pivot is not None:
+        nblk = query("u2pl_wino_stat_blocks", tiles, Co)
+        part = torch.empty((nblk, 2, Co), dtype=torch.float32, device=dev)
+    call("u2pl_wino_output_f32", Mb, N, H, W, Co, dil, mt, bias, y, Co if y.dim() != 4 else y.shape[1], part, pivot)
+    return part
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil, wsink, bsink, pivot=None):
@@ -108,6 +149,12 @@ class _ConvFn(torch.autograd.Function):
             wp = torch.zeros((Cout, Kp), dtype=torch.float32, device=x.device)
             wp[:, : R * S * Cin] = weight.permute(0, 2, 3, 1).reshape(Cout, R * S * Cin)
             call("u2pl_conv2d_fwd_f32", col, Kp, wp, bias, y, Cout, N, Ho, Wo, Kp, Ho, Wo, Cout, 1, 1, 1, 0, 1)
+        elif wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W):
+            mt = wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W)
+            part = _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, mt, False, pivot)
+            if pivot is not None:
+                sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=x.device)
+                call("u2pl_colreduce_finish_f32", part, part.shape[0], Cout, sums)
         elif pivot is not None:
             nblk = query("u2pl_conv2d_fwd_stat_blocks", N, Ho, Wo, Cout)
             part = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=x.device)
@@ -148,10 +195,14 @@ class _ConvFn(torch.autograd.Function):
             weight_k = weight
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wT = torch.empty(Cin * R * S * Cp, dtype=torch.float32, device=dev)
-            call("u2pl_weight_transpose_f32", weight_k, wT, Cp, R * S, Cin)
             dx = new_act(N, Cin, H, W, dev)
-            call("u2pl_conv2d_dgrad_f32", gy, ldg, wT, dx, Cin, N, H, W, Cin, Ho, Wo, Cp, R, S, stride, pad, dil)
+            mt = wino_tile(Cp, Cin, R, S, stride, pad, dil, H, W) if Cp == Cout else 0
+            if mt:   # data gradient = the same convolution with rotated taps and swapped channel roles
+                _wino_conv(gy, ldg, weight_k, None, dx, N, H, W, Cin, Cout, dil, mt, True)
+            else:
+                wT = torch.empty(Cin * R * S * Cp, dtype=torch.float32, device=dev)
+                call("u2pl_weight_transpose_f32", weight_k, wT, Cp, R * S, Cin)
+                call("u2pl_conv2d_dgrad_f32", gy, ldg, wT, dx, Cin, N, H, W, Cin, Ho, Wo, Cp, R, S, stride, pad, dil)
         side = _wgrad_stream() if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) else None
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
@@ -173,6 +224,22 @@ class _ConvFn(torch.autograd.Function):
                     sink.add_(g)
                 else:
                     dw = g.contiguous(memory_format=_CL)
+            elif Cp == Cout and CONV_ALGO.get("wgrad", 1) and wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W):
+                # Winograd weight gradient: dU = sum_tiles (A dY A^T) (x) (B^T x B), dW = G^T dU G
+                mt = wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W)
+                a2 = (mt + 2) ** 2
+                tiles = query("u2pl_wino_tiles", N, H, W, dil, mt)
+                V = torch.empty(a2 * tiles * Cin, dtype=torch.float32, device=dev)
+                call("u2pl_wino_input_f32", x, ldx, N, H, W, Cin, dil, mt, V)
+                Mg = torch.empty(a2 * tiles * Cout, dtype=torch.float32, device=dev)
+                call("u2pl_wino_gy_f32", gy, ldg, N, H, W, Cout, dil, mt, Mg)
+                ns = query("u2pl_wgrad_batched_splits", tiles, Cin, Cout, a2)
+                part = torch.empty(ns * Cout * a2 * Cin, dtype=torch.float32, device=dev)
+                call("u2pl_wgrad_batched_f32", Mg, Cout, tiles * Cout, V, Cin, tiles * Cin, part, tiles, Cin, Cout, a2)
+                tgt = sink if sink is not None else torch.empty_like(weight)
+                call("u2pl_wino_wgrad_finish_f32", part, ns, Cout, Cin, mt, int(sink is not None), tgt)
+                if sink is None:
+                    dw = tgt
             else:
                 wsb = _ws(query("u2pl_conv2d_wgrad_workspace_bytes", N, Ho, Wo, Cin, Cp, R, S), dev)
                 direct = sink is not None and Cp == Cout
@@ -546,16 +613,18 @@ class ParamArena:
         """groups: list of lists of nn.Parameter (each group = one lr segment, kept contiguous)."""
         self.params = [p for g in groups for p in g]
         dev = self.params[0].device
-        sizes = [p.numel() for p in self.params]
-        self.n = sum(sizes)
-        self.bounds, acc = [], 0
+        ALIGN = 64          # every parameter starts on a 256-byte boundary (b128 loads/stores on weight views)
+        offs, self.bounds, acc = [], [], 0
         for g in groups:
-            acc += sum(p.numel() for p in g)
+            for p in g:
+                offs.append(acc)
+                acc += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
             self.bounds.append(acc)
-        self.flat = torch.empty(self.n, dtype=torch.float32, device=dev)
+        self.n = acc
+        # padding stays zero in every arena (zero grad, zero weight => SGD / EMA keep it zero)
+        self.flat = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.n, dtype=torch.float32, device=dev) if with_grad else None
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, offs):
             n = p.numel()
             view = self.flat[off:off + n].as_strided(p.shape, p.stride())
             view.copy_(p.data)
@@ -564,7 +633,6 @@ class ParamArena:
                 gv = self.grad[off:off + n].as_strided(p.shape, p.stride())
                 p._u2pl_grad = gv
                 p.grad = gv
-            off += n
         self.momentum_buf = None
         self.steps = 0
 

@@ -18,6 +18,12 @@ _CONV_GEOM = {
 
 
 def _conv_flops(name, args):
+    if name == "u2pl_gemm_batched_f32":      # (x, ldx, zx, w, zw, y, ldy, zy, M, K, Nn, batch)
+        M, K, Nn, batch = args[8:12]
+        return 2.0 * M * K * Nn * batch
+    if name == "u2pl_wgrad_batched_f32":     # (dy, lddy, zdy, x, ldx, zx, part, M, Cin, Cout, batch)
+        M, Cin, Cout, batch = args[7:11]
+        return 2.0 * M * Cin * Cout * batch
     i = _CONV_GEOM[name]
     N, Hin, Win, Cin, Hout, Wout, Cout, R, S = args[i:i + 9]
     return 2.0 * N * Hout * Wout * Cout * R * S * Cin
@@ -37,7 +43,17 @@ def profile_step(step_fn):
         ms = e0.elapsed_time(e1)
         d["ms"] += ms
         d["calls"] += 1
-        if name in _CONV_GEOM:
+        if name == "u2pl_wgrad_batched_f32":
+            d["flops"] += _conv_flops(name, args)
+        elif name == "u2pl_gemm_batched_f32":
+            fl = _conv_flops(name, args)
+            d["flops"] += fl
+            key = ("wino_gemm", args[11], args[8], 1, args[9], args[8], 1, args[10], 1, 1, 1, 0, 1)
+            sd = shapes.setdefault(key, dict(ms=0.0, calls=0, flops=0.0))
+            sd["ms"] += ms
+            sd["calls"] += 1
+            sd["flops"] += fl
+        elif name in _CONV_GEOM:
             fl = _conv_flops(name, args)
             d["flops"] += fl
             i = _CONV_GEOM[name]
@@ -79,20 +95,22 @@ def measure(trainer, batch, args, ms_per_step):
         out["conv_shapes"] = [dict(op=k[0], N=k[1], Hin=k[2], Cin=k[4], Hout=k[5], Cout=k[7], k=k[8], s=k[10], d=k[12],
                                    calls=v["calls"], ms=round(v["ms"], 2),
                                    tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)) for k, v in top]
-    ig = [agg.get("u2pl_conv2d_fwd_f32"), agg.get("u2pl_conv2d_fwd_bnstats_f32"), agg.get("u2pl_conv2d_dgrad_f32")]
+    ig = [agg.get("u2pl_conv2d_fwd_f32"), agg.get("u2pl_conv2d_fwd_bnstats_f32"), agg.get("u2pl_conv2d_dgrad_f32"),
+          agg.get("u2pl_gemm_batched_f32")]
     ig = [x for x in ig if x]
     if ig:
         fl, t, n = sum(x["flops"] for x in ig), sum(x["ms"] for x in ig), sum(x["calls"] for x in ig)
         ach = fl / (t * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "k_conv_igemm (conv fwd [+BN-stat epilogue] + dgrad, fp32 MFMA)", "bound": "mfma",
+        out["roofline"] = {"kernel": "k_conv_igemm (direct conv fwd [+BN-stat epilogue] + dgrad, and the batched Winograd component GEMMs; fp32 MFMA, executed FLOPs)", "bound": "mfma",
                            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                            "launches_per_step": n, "avg_launch_ms": round(t / n, 4),
                            "algorithmic_tflop_per_step": round(fl / 1e12, 3), "ms_per_step": round(t, 2)}
-    wg = agg.get("u2pl_conv2d_wgrad_f32")
+    wgs = [x for x in (agg.get("u2pl_conv2d_wgrad_f32"), agg.get("u2pl_wgrad_batched_f32")) if x]
+    wg = dict(flops=sum(x["flops"] for x in wgs), ms=sum(x["ms"] for x in wgs), calls=sum(x["calls"] for x in wgs)) if wgs else None
     if wg:
         ach = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
-        out["roofline_wgrad"] = {"kernel": "k_conv_wgrad (+ordered slab reduce)", "bound": "mfma",
+        out["roofline_wgrad"] = {"kernel": "k_conv_wgrad (direct, + ordered slab reduce; and the batched Winograd component products; executed FLOPs)", "bound": "mfma",
                                  "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                  "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                                  "launches_per_step": wg["calls"], "ms_per_step": round(wg["ms"], 2)}

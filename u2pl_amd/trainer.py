@@ -49,7 +49,7 @@ def cutmix(image, label, conf, boxes):
     """generate_unsup_data(mode='cutmix') (augmentation.py:498-541) in one launch."""
     B, C, Hh, Ww = image.shape
     image = image.contiguous()
-    bx = torch.tensor(boxes, dtype=torch.int32).to(image.device, non_blocking=True)
+    bx = H.h2d(torch.tensor(boxes, dtype=torch.int32), image.device)
     oi, ol, oc = torch.empty_like(image), torch.empty_like(label), torch.empty_like(conf)
     K.call("u2pl_cutmix_f32", image, label, conf, bx, B, C, Hh, Ww, oi, ol, oc)
     return oi, ol, oc

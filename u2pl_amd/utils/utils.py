@@ -18,7 +18,7 @@ def gather_keys(keys):
     W = _world()
     if W == 1:
         return keys
-    n = torch.tensor([keys.shape[0]], dtype=torch.int64, device=keys.device)
+    n = H.h2d(torch.tensor([keys.shape[0]], dtype=torch.int64), keys.device)
     ns = [torch.zeros_like(n) for _ in range(W)]
     dist.all_gather(ns, n)
     ns = [int(x) for x in torch.cat(ns).cpu()]
@@ -44,7 +44,7 @@ def enqueue_all_classes(bank, rows, ld, idx, counts_c, C):
         return n_loc
     dev = rows.device
     tot = sum(n_loc)
-    cnt = torch.tensor(n_loc, dtype=torch.int64, device=dev)
+    cnt = H.h2d(torch.tensor(n_loc, dtype=torch.int64), dev)
     cnts = [torch.zeros_like(cnt) for _ in range(W)]
     dist.all_gather(cnts, cnt)
     cnts = torch.stack(cnts).cpu().numpy()                 # [W][C] -- the single host sync of the exchange

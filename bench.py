@@ -132,6 +132,12 @@ def main():
     roof = RL.measure(trainer, batches[0], args, ms)
     if world > 1:
         dist.barrier()
+    from u2pl_amd import nn as KN
+    wt = KN.CONV_ALGO["wino"]
+    conv_algo = ("fp32 implicit GEMM on v_mfma_f32_32x32x2_f32 for every layer (U2PL_CONV_WINO=0)" if wt not in (2, 4) else
+                 f"fp32 Winograd F({wt}x{wt},3x3) for the stride-1 3x3 layers whose tile padding leaves >= "
+                 f"{KN.CONV_ALGO['min_gain']}x fewer multiplies (forward, data and weight gradients; component products on "
+                 "the same fp32 MFMA kernel), direct fp32 implicit GEMM elsewhere; U2PL_CONV_WINO=0|2|4 selects")
     if rank == 0:
         out = {
             "metric": "train images/sec at 769x769 (R101-DeepLabv3+)", "value": round(value, 4), "unit": "images/s",
@@ -141,7 +147,7 @@ def main():
             "config": {"workload": f"U2PL semi {args.arch}-DeepLabv3+ Cityscapes-shaped {args.crop}x{args.crop}, per-GPU "
                                    f"batch {args.batch} labeled + {args.batch} unlabeled, C=19, OHEM+aux, cutmix, "
                                    "contrastive bank 30000x256 pre-filled (BASELINE configs[2]/[3])",
-                       "global_batch": imgs, "parallelism": f"dp{world}"},
+                       "global_batch": imgs, "parallelism": f"dp{world}", "conv_algo": conv_algo},
             "losses_last_step": [round(float(x), 5) for x in meters.cpu()],
         }
         out.update(roof)

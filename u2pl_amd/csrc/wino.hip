@@ -344,44 +344,62 @@ __global__ __launch_bounds__(256) void k_wino_gy(const float* __restrict__ gy, l
 }
 
 // part: [nsplit][O][a*a][C] partial slabs of the batched weight-gradient GEMMs -> dw [O][3][3][C]
-// (slabs summed in order, then G^T . G); one thread per (o, c)
+// (slabs summed in order, then G^T . G); one thread per (o, 4 channels): 16-byte loads, a*a of them in flight
 template <int MT>
-__global__ void k_wino_wgrad_finish(const float* __restrict__ part, int nsplit, int O, int C, int accumulate,
-                                    float* __restrict__ dw) {
+__global__ __launch_bounds__(256) void k_wino_wgrad_finish(const float* __restrict__ part, int nsplit, int O, int C,
+                                                           int accumulate, float* __restrict__ dw) {
     constexpr int A = WinoT<MT>::A;
+    const int C4 = C >> 2;
     const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (idx >= (long)O * C) return;
-    const int c = (int)(idx % C), o = (int)(idx / C);
+    if (idx >= (long)O * C4) return;
+    const int c4 = (int)(idx % C4), o = (int)(idx / C4);
     const long slab = (long)O * A * A * C;
-    const float* p = part + (long)o * A * A * C + c;
-    float u[A][A];
+    const float* p = part + (long)o * A * A * C + c4 * 4;
+    float4 u[A][A];
 #pragma unroll
     for (int i = 0; i < A; ++i)
 #pragma unroll
-        for (int j = 0; j < A; ++j) u[i][j] = 0.f;
-    for (int z = 0; z < nsplit; ++z)
+        for (int j = 0; j < A; ++j) u[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < nsplit; ++z) {
+        float4 v[A][A];
 #pragma unroll
         for (int i = 0; i < A; ++i)
 #pragma unroll
-            for (int j = 0; j < A; ++j) u[i][j] += p[(long)z * slab + (long)(i * A + j) * C];
-    float t[3][A];
+            for (int j = 0; j < A; ++j) v[i][j] = *(const float4*)(p + (long)z * slab + (long)(i * A + j) * C);
+#pragma unroll
+        for (int i = 0; i < A; ++i)
+#pragma unroll
+            for (int j = 0; j < A; ++j) u[i][j] = f4add(u[i][j], v[i][j]);
+    }
+    // G^T u G, channel by channel (the scalar transform helpers are reused on the 4 components)
+    float4 t[3][A];
 #pragma unroll
     for (int j = 0; j < A; ++j) {
-        float col[A], r[3];
+        float cx[A], cy[A], cz[A], cw[A], rx[3], ry[3], rz[3], rw[3];
 #pragma unroll
-        for (int i = 0; i < A; ++i) col[i] = u[i][j];
-        WinoT<MT>::gt(col, r);
+        for (int i = 0; i < A; ++i) { cx[i] = u[i][j].x; cy[i] = u[i][j].y; cz[i] = u[i][j].z; cw[i] = u[i][j].w; }
+        WinoT<MT>::gt(cx, rx); WinoT<MT>::gt(cy, ry); WinoT<MT>::gt(cz, rz); WinoT<MT>::gt(cw, rw);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) t[i][j] = r[i];
+        for (int i = 0; i < 3; ++i) t[i][j] = make_float4(rx[i], ry[i], rz[i], rw[i]);
     }
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(dw) & 15) == 0;
 #pragma unroll
     for (int r3 = 0; r3 < 3; ++r3) {
-        float r[3];
-        WinoT<MT>::gt(t[r3], r);
+        float cx[A], cy[A], cz[A], cw[A], rx[3], ry[3], rz[3], rw[3];
+#pragma unroll
+        for (int j = 0; j < A; ++j) { cx[j] = t[r3][j].x; cy[j] = t[r3][j].y; cz[j] = t[r3][j].z; cw[j] = t[r3][j].w; }
+        WinoT<MT>::gt(cx, rx); WinoT<MT>::gt(cy, ry); WinoT<MT>::gt(cz, rz); WinoT<MT>::gt(cw, rw);
 #pragma unroll
         for (int s3 = 0; s3 < 3; ++s3) {
-            float* d = dw + (((long)o * 3 + r3) * 3 + s3) * C + c;
-            *d = accumulate ? *d + r[s3] : r[s3];
+            float* d = dw + (((long)o * 3 + r3) * 3 + s3) * C + c4 * 4;
+            float4 val = make_float4(rx[s3], ry[s3], rz[s3], rw[s3]);
+            if (vec_ok) {
+                if (accumulate) val = f4add(*(const float4*)d, val);
+                *(float4*)d = val;
+            } else {
+                d[0] = accumulate ? d[0] + val.x : val.x; d[1] = accumulate ? d[1] + val.y : val.y;
+                d[2] = accumulate ? d[2] + val.z : val.z; d[3] = accumulate ? d[3] + val.w : val.w;
+            }
         }
     }
 }
@@ -460,7 +478,8 @@ U2PL_API int u2pl_wino_gy_f32(const float* gy, long ldg, int N, int H, int W, in
 U2PL_API int u2pl_wino_wgrad_finish_f32(const float* part, int nsplit, int O, int C, int mt, int accumulate, float* dw,
                                         hipStream_t stream) {
     if (mt != 2 && mt != 4) return U2PL_EINVAL;
-    const dim3 grid((unsigned)cdiv((long)O * C, 256)), block(256);
+    if (C % 4) return U2PL_EINVAL;
+    const dim3 grid((unsigned)cdiv((long)O * (C / 4), 256)), block(256);
     if (mt == 4) hipLaunchKernelGGL(k_wino_wgrad_finish<4>, grid, block, 0, stream, part, nsplit, O, C, accumulate, dw);
     else hipLaunchKernelGGL(k_wino_wgrad_finish<2>, grid, block, 0, stream, part, nsplit, O, C, accumulate, dw);
     U2PL_LAUNCH_CHECK();

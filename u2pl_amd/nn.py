@@ -124,8 +124,8 @@ def _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, mt, transposed,
     if pivot is not None:
         nblk = query("u2pl_wino_stat_blocks", tiles, Co)
         part = torch.empty((nblk, 2, Co), dtype=torch.float32, device=dev)
-    call("u2pl_wino_output_f32", Mb, N, H, W, Co, dil, mt, bias, y, Co if y.dim() != 4 else y.shape[1], part, pivot)
-    return part
+    call("u2pl_wino_output_f32", Mb, N, H, W, Co, dil, mt, bias, y, Co, part, pivot)
+    return part, V
 
 
 class _ConvFn(torch.autograd.Function):
@@ -151,7 +151,9 @@ class _ConvFn(torch.autograd.Function):
             call("u2pl_conv2d_fwd_f32", col, Kp, wp, bias, y, Cout, N, Ho, Wo, Kp, Ho, Wo, Cout, 1, 1, 1, 0, 1)
         elif wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W):
             mt = wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W)
-            part = _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, mt, False, pivot)
+            part, V = _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, mt, False, pivot)
+            if ctx.needs_input_grad[1]:
+                col = V     # the transformed input is the weight gradient's operand: keep it instead of redoing it
             if pivot is not None:
                 sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=x.device)
                 call("u2pl_colreduce_finish_f32", part, part.shape[0], Cout, sums)
@@ -198,7 +200,7 @@ class _ConvFn(torch.autograd.Function):
             dx = new_act(N, Cin, H, W, dev)
             mt = wino_tile(Cp, Cin, R, S, stride, pad, dil, H, W) if Cp == Cout else 0
             if mt:   # data gradient = the same convolution with rotated taps and swapped channel roles
-                _wino_conv(gy, ldg, weight_k, None, dx, N, H, W, Cin, Cout, dil, mt, True)
+                _wino_conv(gy, ldg, weight_k, None, dx, N, H, W, Cin, Cout, dil, mt, True)[0]
             else:
                 wT = torch.empty(Cin * R * S * Cp, dtype=torch.float32, device=dev)
                 call("u2pl_weight_transpose_f32", weight_k, wT, Cp, R * S, Cin)
@@ -214,7 +216,7 @@ class _ConvFn(torch.autograd.Function):
             stream_ctx.__enter__()
         if ctx.needs_input_grad[1]:
             sink = ctx.wsink
-            if col is not None:  # 3-channel stem: gradient of the padded [Cout][Kp] patch-matrix weights
+            if Cin % 32:  # 3-channel stem (col = im2col patches): gradient of the padded [Cout][Kp] patch-matrix weights
                 Kp = col.shape[1]
                 tmp = torch.empty((Cp, Kp), dtype=torch.float32, device=dev)
                 wsb = _ws(query("u2pl_conv2d_wgrad_workspace_bytes", N, Ho, Wo, Kp, Cp, 1, 1), dev)
@@ -229,8 +231,10 @@ class _ConvFn(torch.autograd.Function):
                 mt = wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W)
                 a2 = (mt + 2) ** 2
                 tiles = query("u2pl_wino_tiles", N, H, W, dil, mt)
-                V = torch.empty(a2 * tiles * Cin, dtype=torch.float32, device=dev)
-                call("u2pl_wino_input_f32", x, ldx, N, H, W, Cin, dil, mt, V)
+                V = col      # saved by the forward
+                if V is None:
+                    V = torch.empty(a2 * tiles * Cin, dtype=torch.float32, device=dev)
+                    call("u2pl_wino_input_f32", x, ldx, N, H, W, Cin, dil, mt, V)
                 Mg = torch.empty(a2 * tiles * Cout, dtype=torch.float32, device=dev)
                 call("u2pl_wino_gy_f32", gy, ldg, N, H, W, Cout, dil, mt, Mg)
                 ns = query("u2pl_wgrad_batched_splits", tiles, Cin, Cout, a2)

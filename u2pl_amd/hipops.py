@@ -68,6 +68,9 @@ def pseudo_label(logits_large):
     return conf, label
 
 
+REPLAY = None   # when a dict: the last arguments of the HBM-bound group's stages (bench.py roofline replay)
+
+
 def h2d(t, device):
     """small host table -> device through a PINNED staging buffer: a pageable `.to(device)` makes the host wait
     until the stream has drained (measured 17 ms per copy mid-step), a pinned one is a true async copy."""
@@ -289,6 +292,8 @@ class DeviceMemoryBank:
         if mx > 0:
             dd = h2d(torch.from_numpy(desc), self.buf[0].device)
             call("u2pl_bank_append_multi_f32", dd, len(entries), self.D, ld, mx)
+            if REPLAY is not None:
+                REPLAY["append"] = (dd, len(entries), self.D, ld, mx, [e[1] for e in entries], [e[3] for e in entries])
         self.head, self.length = head, length
         for c, n in per_class.items():
             self._book(c, n)
@@ -326,6 +331,8 @@ class ContraPhase1:
 def contra_phase1(rep_teacher_rows, ld, D, prob, prob_strides, lbits, low_mask, high_mask, num_labeled, C, h, w,
                   cfg):
     """classify + compaction + prototypes.  prob_strides = (sn, sc, sp)."""
+    if REPLAY is not None:
+        REPLAY["phase1"] = (rep_teacher_rows, ld, D, prob, prob_strides, lbits, low_mask, high_mask, num_labeled, C, h, w, cfg)
     dev = lbits.device
     N2 = lbits.shape[0]
     P = N2 * h * w
@@ -430,5 +437,8 @@ def infonce_loss(rep_rows, ph1, bank, valid_classes, counts_host, cfg, randint=N
         off += Q + Q * K
     assert query("u2pl_infonce_job_bytes") == 56
     jobs_dev = h2d(torch.from_numpy(jb), dev)
+    if REPLAY is not None:
+        REPLAY["infonce"] = (rep_rows.detach(), jobs_dev, len(jobs), Q, K, float(cfg["temperature"]), valid_seg,
+                             (idx_all, ph1, bank))
     return _InfoNCE.apply(rep_rows, jobs_dev, len(jobs), Q, K, float(cfg["temperature"]), valid_seg,
                           (idx_all, ph1))

@@ -66,6 +66,58 @@ def profile_step(step_fn):
     return agg
 
 
+def replay_hbm_group(reps=10):
+    """GPU time of the HBM-bound group (entropy + exact select + masks; classify / compaction / prototypes; bank
+    append; InfoNCE forward + gradient scatter) on the LAST step's own tensors: every stage is re-issued `reps`
+    times behind a spinning kernel, so the host has finished enqueueing before the first timed kernel starts and
+    ONE HIP-event pair brackets each stage's launches on the stream they run on (per-call event pairs would add
+    two marker packets, ~20 us, to kernels that take 5-30 us)."""
+    from . import hipops as H
+
+    R = H.REPLAY or {}
+    out = {}
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(60_000_000)      # ~30 ms of GPU spin: the host enqueues the whole replay meanwhile
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3    # us per repetition
+
+    saved, H.REPLAY = H.REPLAY, None
+    try:
+        if "rel" in R:
+            tl, hw, label_u, label_l, low_shape, specs, neg_high = R["rel"]
+
+            def rel():
+                ws = H.new_select_ws(tl.device, label_u.numel())
+                ent = H.entropy_map_up(tl, hw, label_u, ws)
+                thr = H.run_select(ent, ws, specs)
+                if neg_high is not None:
+                    H.reliability_apply(ent, thr, label_l, label_u, low_shape, negative_high_entropy=neg_high)
+            out["reliability_us"] = timed(rel)
+        if "phase1" in R:
+            out["phase1_us"] = timed(lambda: H.contra_phase1(*R["phase1"]))
+        if "append" in R:
+            dd, n, D, ld, mx = R["append"][:5]
+            out["bank_append_us"] = timed(lambda: _lib.call("u2pl_bank_append_multi_f32", dd, n, D, ld, mx))
+        if "infonce" in R:
+            rep_rows, jobs_dev, njobs, Q, K, temp, valid_seg, keep = R["infonce"]
+
+            def nce():
+                r = rep_rows.requires_grad_(True)
+                r.grad = None
+                H._InfoNCE.apply(r, jobs_dev, njobs, Q, K, temp, valid_seg, keep).backward()
+            out["infonce_fwd_bwd_us"] = timed(nce)
+    finally:
+        H.REPLAY = saved
+    return out
+
+
 def hbm_algorithmic_bytes(B, C, H, W, h, w, D, stats):
     """entropy+reliability 4C+24 B/pixel + low-res outputs; contrastive with
     the Q0 skip (only images {0,B} referenced) from the measured counts."""
@@ -80,14 +132,19 @@ def hbm_algorithmic_bytes(B, C, H, W, h, w, D, stats):
 def measure(trainer, batch, args, ms_per_step):
     from .utils import loss_helper as LH
 
+    from . import hipops as H
+
     il, ll, iu = batch
     # per-kernel HIP-event timing needs serial execution: run the profiled step without the side stream
     saved = getattr(trainer, "_side", None)
     trainer._side = torch.cuda.current_stream()
+    H.REPLAY = {}
     try:
         agg = profile_step(lambda: trainer.train_step(il, ll, iu, epoch=0))
+        replay = replay_hbm_group()
     finally:
         trainer._side = saved
+        H.REPLAY = None
     shapes = agg.pop("_shapes")
     out = {}
     if os.environ.get("U2PL_BENCH_SHAPES"):
@@ -124,13 +181,22 @@ def measure(trainer, batch, args, ms_per_step):
     rel_b, con_b = hbm_algorithmic_bytes(B, C, H, W, h, w, 256, LH.LAST_STATS)
     t_rel = sum(agg[n]["ms"] for n in rel_names if n in agg)
     t_con = sum(agg[n]["ms"] for n in con_names if n in agg)
+    per_call = {"reliability_us": round(t_rel * 1e3, 1), "contrastive_us": round(t_con * 1e3, 1)}
+    if "reliability_us" in replay and "phase1_us" in replay:   # back-to-back replay of the same launches (see replay_hbm_group)
+        t_rel = replay["reliability_us"] * 1e-3
+        t_con = (replay["phase1_us"] + replay.get("bank_append_us", 0.0) + replay.get("infonce_fwd_bwd_us", 0.0)) * 1e-3
     if t_rel > 0 and t_con > 0:
         ach = (rel_b + con_b) / ((t_rel + t_con) * 1e-3) / 1e9
         out["roofline_hbm"] = {"kernel": "entropy + exact select + masks + contrastive (classify/compact/proto/bank/InfoNCE)",
                                "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
                                "algorithmic_MB": round((rel_b + con_b) / 1e6, 1), "reliability_us": round(t_rel * 1e3, 1),
-                               "contrastive_us": round(t_con * 1e3, 1), "stats": dict(LH.LAST_STATS)}
+                               "contrastive_us": round(t_con * 1e3, 1), "stats": dict(LH.LAST_STATS),
+                               "stages_us": {k: round(v, 1) for k, v in replay.items()},
+                               "per_call_event_us": per_call,
+                               "method": "each stage re-issued 10x on the last step's tensors behind a spinning kernel, one "
+                                         "HIP-event pair per stage (per-call event pairs, kept in per_call_event_us, add "
+                                         "~20 us of marker packets to 5-30 us kernels)"}
     # HBM traffic per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
     # same command (profiles/r01_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), if present
     tj = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_traffic.json")

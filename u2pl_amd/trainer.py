@@ -208,6 +208,9 @@ class SemiTrainer:
                 if ccfg:
                     alpha_t = ccfg["low_entropy_threshold"] * (1 - epoch / self.epochs)
                     specs += [("pct", float(alpha_t)), ("pct", float(100 - alpha_t))]
+                if H.REPLAY is not None:
+                    H.REPLAY["rel"] = (pred_all_t[B:], (h, w), label_u_aug, label_l, tuple(pred_all.shape[2:]), specs,
+                                       bool(ccfg.get("negative_high_entropy", True)) if ccfg else None)
                 ws = H.new_select_ws(image_l.device, B * h * w)
                 ent = H.entropy_map_up(pred_all_t[B:], (h, w), label_u_aug, ws)
                 thr = H.run_select(ent, ws, specs)

@@ -1,5 +1,6 @@
 """Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md
-prescribes) of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline` into profiles/r01_traffic.json.
+prescribes) of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline` into profiles/r01_traffic.json
+(usage: parse_pmc_traffic.py <fetch_dir> <write_dir> <out.json> 5 10  -- 5 full steps, 10 replay repetitions).
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of a wide coalesced stream -> x2."""
 import collections
 import csv
@@ -20,7 +21,7 @@ def load(d, counter):
     return per
 
 
-def main(fetch_dir, write_dir, out, steps_profiled):
+def main(fetch_dir, write_dir, out, steps_profiled, hbm_reps=0):
     fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
     rows = {}
     for k in sorted(set(fe) | set(wr)):
@@ -33,7 +34,8 @@ def main(fetch_dir, write_dir, out, steps_profiled):
     ig_b = sum(v["bytes_per_launch"] * v["launches"] for v in ig) / max(ig_l, 1)
     hbm_names = ("k_entropy", "k_sel_", "k_reliability", "k_apply_drop", "k_contra", "k_compact", "k_proto", "k_bank",
                  "k_infonce", "k_scatter_add")
-    hb = sum(v["bytes_per_launch"] * v["launches"] for k, v in rows.items() if k.startswith(hbm_names)) / steps_profiled
+    # bench.py's roofline leg re-issues every stage of the HBM-bound group hbm_reps more times (replay_hbm_group)
+    hb = sum(v["bytes_per_launch"] * v["launches"] for k, v in rows.items() if k.startswith(hbm_names)) / (steps_profiled + hbm_reps)
     res = dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py; bytes = (2*FETCH_SIZE + "
                     "WRITE_SIZE) KiB (gfx950 FETCH_SIZE x2 correction, WRITE_SIZE uncalibrated); Infinity-Cache hits are counted",
                k_conv_igemm_bytes_per_launch=round(ig_b), k_conv_igemm_launches=ig_l,
@@ -43,4 +45,4 @@ def main(fetch_dir, write_dir, out, steps_profiled):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]))
+    main(sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]) if len(sys.argv) > 5 else 0)

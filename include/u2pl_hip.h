@@ -234,6 +234,12 @@ int u2pl_ema_update_f32(float* t, const float* s, long n, float decay, float one
 int u2pl_cutmix_f32(const float* img, const long long* label, const float* conf, const int* boxes_dev, int B, int C,
                     int H, int W, float* out_img, long long* out_label, float* out_conf, hipStream_t stream);
 
+/* sliding-window evaluation accumulators (eval.py:184-224): pred [C][H][W] += src [C][hc][wc] at (h0, w0), count += 1;
+   then pred /= count */
+int u2pl_window_accumulate_f32(float* pred, float* count, int C, int H, int W, const float* src, int h0, int w0,
+                               int hc, int wc, hipStream_t stream);
+int u2pl_window_normalize_f32(float* pred, const float* count, int C, int H, int W, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -387,6 +387,45 @@ def gen_model(ns, tag, arch, S, B, C, aux, seed=5):
     save(f"model_{tag}", **fx)
 
 
+def gen_eval_window(ns, tag, H, W, crop, seed):
+    """reference eval.py:184-224 scale_crop_process on a tiny R50 (formula weights, eval mode), fp32 and fp64."""
+    import copy
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("u2pl_ref_eval", os.path.join(ref_shim.REFERENCE_ROOT, "eval.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    C = 19
+    net = dict(
+        num_classes=C, sync_bn=False, ema_decay=0.99,
+        encoder=dict(type="u2pl.models.resnet.resnet50",
+                     kwargs=dict(multi_grid=True, zero_init_residual=True, fpn=True,
+                                 replace_stride_with_dilation=[False, True, True], pretrained=False)),
+        decoder=dict(type="u2pl.models.decoder.dec_deeplabv3_plus", kwargs=dict(inner_planes=256, dilations=[12, 24, 36])),
+        aux_loss=dict(aux_plane=1024, loss_weight=0.4),
+    )
+    model = ns.model_helper.ModelBuilder(copy.deepcopy(net))
+    model.load_state_dict(formula_state_dict(model))
+    model.eval()
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(1, 3, H, W, generator=gen)
+    out = ev.scale_crop_process(model, x, C, crop, crop, H, W)
+    m64 = ns.model_helper.ModelBuilder(copy.deepcopy(net))
+    m64.load_state_dict(formula_state_dict(m64))
+    m64 = m64.double().eval()
+    _zeros = torch.zeros
+
+    def zeros64(*a, **k):        # the reference allocates its accumulators as torch.float
+        k["dtype"] = torch.float64
+        return _zeros(*a, **k)
+    torch.zeros = zeros64
+    try:
+        out64 = ev.scale_crop_process(m64, x.double(), C, crop, crop, H, W)
+    finally:
+        torch.zeros = _zeros
+    save(f"evalwin_{tag}", x=x, out=out, out64=out64.float(), crop=np.int64(crop))
+
+
 def main():
     ns = ref_shim.load()
     which = set(sys.argv[1:])
@@ -417,6 +456,9 @@ def main():
         gen_pseudo(71, 65, 17, 19)
     if want("sgd"):
         gen_sgd_ema(ns, 81)
+    if want("evalwin"):
+        gen_eval_window(ns, "70x100", 70, 100, 65, 91)     # 2 x 2 overlapping windows, last ones pulled back
+        gen_eval_window(ns, "50x90", 50, 90, 65, 92)       # image shorter than the crop: symmetric zero padding
     if want("model"):
         gen_model(ns, "r50_65", "resnet50", 65, 2, 19, aux=True)
         gen_model(ns, "r101_33", "resnet101", 33, 2, 21, aux=False)

@@ -220,3 +220,31 @@ def validate_ref(model, batches, num_classes, ignore=255):
             union += ao + at - ai
     iou = inter / (union + 1e-10)
     return float(iou.mean()), iou
+
+
+def sliding_window_ref(model, image, classes, crop_h, crop_w, h, w, stride_rate=2 / 3):
+    """CPU restatement of scale_crop_process (reference eval.py:184-224) for one (1,3,H,W) image."""
+    ori_h, ori_w = image.shape[-2:]
+    pad_h, pad_w = max(crop_h - ori_h, 0), max(crop_w - ori_w, 0)
+    ph, pw = int(pad_h / 2), int(pad_w / 2)
+    if pad_h > 0 or pad_w > 0:
+        image = F.pad(image, (pw, pad_w - pw, ph, pad_h - ph), mode="constant", value=0.0)
+    new_h, new_w = image.shape[-2:]
+    stride_h, stride_w = int(np.ceil(crop_h * stride_rate)), int(np.ceil(crop_w * stride_rate))
+    grid_h = int(np.ceil(float(new_h - crop_h) / stride_h) + 1)
+    grid_w = int(np.ceil(float(new_w - crop_w) / stride_w) + 1)
+    pred = torch.zeros((1, classes, new_h, new_w))
+    cnt = torch.zeros((new_h, new_w))
+    model.eval()
+    with torch.no_grad():
+        for ih in range(grid_h):
+            for iw in range(grid_w):
+                e_h = min(ih * stride_h + crop_h, new_h)
+                e_w = min(iw * stride_w + crop_w, new_w)
+                s_h, s_w = e_h - crop_h, e_w - crop_w
+                cropped = image[:, :, s_h:e_h, s_w:e_w].contiguous()
+                cnt[s_h:e_h, s_w:e_w] += 1
+                pred[:, :, s_h:e_h, s_w:e_w] += _up(model(cropped)["pred"], (crop_h, crop_w))
+    pred /= cnt
+    pred = pred[:, :, ph:ph + ori_h, pw:pw + ori_w]
+    return _up(pred, (h, w))[0]

@@ -215,3 +215,29 @@ def test_model_ref_pinned_to_reference_golden(tag, arch, C, aux):
     for n in g["grad_names"]:
         gr = params[str(n)].grad.flatten()
         assert torch.equal(gr[:: max(1, gr.numel() // 4096)][:4096], torch.from_numpy(g["grad__" + str(n)])), n
+
+
+@pytest.mark.parametrize("tag", ["70x100", "50x90"])
+def test_sliding_window_restatement_pinned_to_reference(tag):
+    """oracle/step_ref.sliding_window_ref == the reference's eval.scale_crop_process (eval.py:184-224) on the
+    committed golden (window placement, pull-back of the last window, zero padding, count normalisation)."""
+    from model_utils import formula_state_dict
+    from oracle.model_ref import RefNet
+    from oracle.step_ref import sliding_window_ref
+    import torch
+
+    g = golden("evalwin_" + tag)
+    net = RefNet("resnet50", 19, True, p_drop=0.0)
+    net.load_state_dict(formula_state_dict(net))
+    x = torch.from_numpy(g["x"])
+    crop = int(g["crop"])
+    H, W = x.shape[2:]
+    out = sliding_window_ref(net, x, 19, crop, crop, H, W)
+    assert torch.equal(out, torch.from_numpy(g["out"]))      # same torch, same op order: bit-identical
+
+
+def test_window_grid_matches_reference_formula():
+    from u2pl_amd.evaluate import window_grid
+    # Cityscapes 1024x2048 at crop 769: stride ceil(769*2/3) = 513; 2 x 4 windows, last ones pulled back inside
+    assert window_grid(1024, 2048, 769, 769) == [(0, 0), (0, 513), (0, 1026), (0, 1279), (255, 0), (255, 513), (255, 1026), (255, 1279)]
+    assert window_grid(65, 65, 65, 65) == [(0, 0)]

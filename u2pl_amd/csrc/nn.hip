@@ -605,3 +605,41 @@ U2PL_API int u2pl_cutmix_f32(const float* img, const long long* label, const flo
     U2PL_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------
+// Sliding-window evaluation (reference eval.py:184-224, scale_crop_process): logits of one crop window are
+// added into the padded full-image accumulator, a per-pixel window count is kept, and the sum is divided by
+// the count at the end.  pred: [C][H][W] planar, count: [H][W], src: [C][hc][wc] planar (one window).
+// ---------------------------------------------------------------------------
+__global__ void k_window_acc(float* __restrict__ pred, float* __restrict__ count, int C, int H, int W,
+                             const float* __restrict__ src, int h0, int w0, int hc, int wc) {
+    const long total = (long)C * hc * wc;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % wc);
+        const long t = i / wc;
+        const int y = (int)(t % hc), c = (int)(t / hc);
+        pred[((long)c * H + h0 + y) * W + w0 + x] += src[i];
+        if (c == 0) count[(long)(h0 + y) * W + w0 + x] += 1.0f;
+    }
+}
+U2PL_API int u2pl_window_accumulate_f32(float* pred, float* count, int C, int H, int W, const float* src, int h0,
+                                        int w0, int hc, int wc, hipStream_t stream) {
+    if (h0 < 0 || w0 < 0 || h0 + hc > H || w0 + wc > W) return U2PL_EINVAL;
+    const long total = (long)C * hc * wc;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_window_acc, dim3(grid_for(total, 256)), dim3(256), 0, stream, pred, count, C, H, W, src, h0, w0, hc, wc);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void k_window_div(float* __restrict__ pred, const float* __restrict__ count, int C, long HW) {
+    const long total = (long)C * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        pred[i] = pred[i] / count[i % HW];
+}
+U2PL_API int u2pl_window_normalize_f32(float* pred, const float* count, int C, int H, int W, hipStream_t stream) {
+    const long total = (long)C * H * W;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_window_div, dim3(grid_for(total, 256)), dim3(256), 0, stream, pred, count, C, (long)H * W);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}

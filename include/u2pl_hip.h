@@ -240,6 +240,14 @@ int u2pl_window_accumulate_f32(float* pred, float* count, int C, int H, int W, c
                                int hc, int wc, hipStream_t stream);
 int u2pl_window_normalize_f32(float* pred, const float* count, int C, int H, int W, hipStream_t stream);
 
+/* device-side training data pipeline (augmentation.py:51-266 as composed by cityscapes.py:47-77): ToTensor, Normalize,
+   RandResize (bilinear align_corners=False / legacy nearest), flip, zero-padded crop fused into one gather from the
+   decoded uint8 sample.  img uint8 [B][H][W][3], lab uint8 [B][H][W], params int32 [B][8] = {rh, rw, flip, pad_top,
+   pad_left, crop_y, crop_x, 0} (device); mean3 / std3 are HOST pointers to three floats. */
+int u2pl_augment_u8_f32(const unsigned char* img, const unsigned char* lab, const int* params, int B, int H, int W,
+                        int Sh, int Sw, const float* mean3, const float* std3, float* out_img, long long* out_lab,
+                        hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

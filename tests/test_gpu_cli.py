@@ -54,3 +54,16 @@ def test_train_sup_cli(tmp_path):
     yaml.safe_dump(cfg, open(cfgp, "w"))
     out = _run("train_sup.py", cfgp)
     assert "mIoU" in out
+
+
+def test_train_semi_cli_with_device_side_data_pipeline(tmp_path):
+    """dataset.device_aug: uint8 batches + host-drawn geometry, transform chain fused on the GPU"""
+    import make_synth_dataset as M
+
+    d, s = M.make_cityscapes(str(tmp_path), H=110, W=150)
+    cfgp = M.write_city_config(str(tmp_path), d, s, crop=97, epochs=1)
+    cfg = yaml.load(open(cfgp), Loader=yaml.Loader)
+    cfg["dataset"]["device_aug"] = True
+    yaml.safe_dump(cfg, open(cfgp, "w"))
+    out = _run("train_semi.py", cfgp)
+    assert "mIoU" in out

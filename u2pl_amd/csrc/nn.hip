@@ -643,3 +643,85 @@ U2PL_API int u2pl_window_normalize_f32(float* pred, const float* count, int C, i
     U2PL_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------
+// Training-time data pipeline on the device (reference u2pl/dataset/augmentation.py:51-266 as
+// composed by cityscapes.py:47-77): ToTensor -> Normalize -> RandResize (bilinear align_corners=False for
+// the image, legacy nearest for the label) -> RandomHorizontalFlip -> Crop (zero padding of image AND label,
+// augmentation.py:241-245) fused into ONE gather per output pixel from the decoded uint8 sample.  The random
+// draws stay on the host (python `random`, reference order); per sample
+//   params = {rh, rw (resized size), flip, pad_top, pad_left, ho, wo (crop origin in the padded image), 0}.
+// img: uint8 [B][H][W][3] (decoder layout), lab: uint8 [B][H][W]; out_img fp32 [B][3][Sh][Sw], out_lab int64.
+// ---------------------------------------------------------------------------
+__global__ void k_augment(const unsigned char* __restrict__ img, const unsigned char* __restrict__ lab,
+                          const int* __restrict__ params, int B, int H, int W, int Sh, int Sw, float m0, float m1,
+                          float m2, float s0, float s1, float s2, float* __restrict__ out_img,
+                          long long* __restrict__ out_lab) {
+    const long total = (long)B * Sh * Sw;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Sw);
+        const long t = i / Sw;
+        const int y = (int)(t % Sh), b = (int)(t / Sh);
+        const int* p = params + b * 8;
+        const int rh = p[0], rw = p[1], flip = p[2];
+        const int ry = p[5] + y - p[3];
+        int rx = p[6] + x - p[4];
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        long long l = 0;
+        if (ry >= 0 && ry < rh && rx >= 0 && rx < rw) {
+            if (flip) rx = rw - 1 - rx;
+            const unsigned char* ib = img + (long)b * H * W * 3;
+            const unsigned char* lb = lab + (long)b * H * W;
+            // label: legacy nearest, src = min(floor(dst * float(in/out)), in-1)
+            const int ly = nearest_src(ry, (float)H / (float)rh, H), lx = nearest_src(rx, (float)W / (float)rw, W);
+            l = lb[(long)ly * W + lx];
+            if (rh == H && rw == W) {     // interpolate() with an unchanged size is the identity in torch too
+                const unsigned char* q = ib + ((long)ry * W + rx) * 3;
+                v0 = __fdiv_rn(__fsub_rn((float)q[0], m0), s0);
+                v1 = __fdiv_rn(__fsub_rn((float)q[1], m1), s1);
+                v2 = __fdiv_rn(__fsub_rn((float)q[2], m2), s2);
+            } else {
+                // image: bilinear, align_corners=False: src = scale*(dst+0.5)-0.5 clamped at 0 (ATen area_pixel_compute_source_index)
+                const float sy = (float)H / (float)rh, sx = (float)W / (float)rw;
+                // fused multiply-add like the AVX2/AVX-512 ATen kernel (one rounding): the fractional part of a source
+                // index near 150 otherwise differs by ~1e-5, i.e. ~5e-5 on the interpolated pixel
+                float fy = __fmaf_rn(sy, (float)ry + 0.5f, -0.5f), fx = __fmaf_rn(sx, (float)rx + 0.5f, -0.5f);
+                fy = fy < 0.f ? 0.f : fy;
+                fx = fx < 0.f ? 0.f : fx;
+                const int y0 = (int)fy, x0 = (int)fx;
+                const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+                const float ly1 = __fsub_rn(fy, (float)y0), lx1 = __fsub_rn(fx, (float)x0);
+                const float ly0 = __fsub_rn(1.f, ly1), lx0 = __fsub_rn(1.f, lx1);
+                const float mm[3] = {m0, m1, m2}, ss[3] = {s0, s1, s2};
+                float r[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float a00 = __fdiv_rn(__fsub_rn((float)ib[((long)y0 * W + x0) * 3 + c], mm[c]), ss[c]);
+                    const float a01 = __fdiv_rn(__fsub_rn((float)ib[((long)y0 * W + x1) * 3 + c], mm[c]), ss[c]);
+                    const float a10 = __fdiv_rn(__fsub_rn((float)ib[((long)y1 * W + x0) * 3 + c], mm[c]), ss[c]);
+                    const float a11 = __fdiv_rn(__fsub_rn((float)ib[((long)y1 * W + x1) * 3 + c], mm[c]), ss[c]);
+                    const float top = __fadd_rn(__fmul_rn(lx0, a00), __fmul_rn(lx1, a01));
+                    const float bot = __fadd_rn(__fmul_rn(lx0, a10), __fmul_rn(lx1, a11));
+                    r[c] = __fadd_rn(__fmul_rn(ly0, top), __fmul_rn(ly1, bot));
+                }
+                v0 = r[0]; v1 = r[1]; v2 = r[2];
+            }
+        }
+        const long plane = (long)Sh * Sw, o = (long)b * 3 * plane + (long)y * Sw + x;
+        out_img[o] = v0;
+        out_img[o + plane] = v1;
+        out_img[o + 2 * plane] = v2;
+        out_lab[i] = l;
+    }
+}
+U2PL_API int u2pl_augment_u8_f32(const unsigned char* img, const unsigned char* lab, const int* params, int B, int H,
+                                 int W, int Sh, int Sw, const float* mean3, const float* std3, float* out_img,
+                                 long long* out_lab, hipStream_t stream) {
+    const long total = (long)B * Sh * Sw;
+    if (total <= 0) return 0;
+    // mean / std are HOST pointers (three floats each): they travel as kernel arguments
+    hipLaunchKernelGGL(k_augment, dim3(grid_for(total, 256)), dim3(256), 0, stream, img, lab, params, B, H, W, Sh, Sw,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], out_img, out_lab);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}

@@ -122,4 +122,12 @@ def get_loader(cfg, seed=0):
     sup = SegDataset(tc["data_root"], tc["data_list"], Pipeline(tc), seed, n, "train")
     unsup = SegDataset(tc["data_root"], tc["data_list"].replace("labeled.txt", "unlabeled.txt"), Pipeline(tc), seed, n,
                        "train")
+    if d.get("device_aug", False):
+        # decoded uint8 samples + host-drawn geometry; the transform chain runs fused on the GPU (device_aug.py).
+        # Needs one image size per list (Cityscapes); engine.run finishes the batches with augment_batch.
+        from .device_aug import AugmentPlan, RawSegDataset
+        plan = AugmentPlan(tc)
+        ls, lu = _loader(RawSegDataset(sup, plan), tc, True), _loader(RawSegDataset(unsup, plan), tc, True)
+        ls.device_plan = lu.device_plan = plan
+        return ls, lu, _loader(val, vc, False)
     return _loader(sup, tc, True), _loader(unsup, tc, True), _loader(val, vc, False)

@@ -130,11 +130,22 @@ def run(cfg, args, semi):
                 ld.sampler.set_epoch(epoch)
         it_u = iter(loader_u) if loader_u is not None else None
         t0 = time.time()
-        for step, (image_l, label_l) in enumerate(loader_l):
-            image_l, label_l = image_l.to(device, non_blocking=True), label_l.to(device, non_blocking=True)
+        plan = getattr(loader_l, "device_plan", None)    # dataset.device_aug: raw uint8 batches, GPU transform chain
+        for step, batch_l in enumerate(loader_l):
+            if plan is not None:
+                from .dataset.device_aug import augment_batch
+                image_l, label_l = augment_batch(plan, batch_l[0].to(device, non_blocking=True),
+                                                 batch_l[1].to(device, non_blocking=True), batch_l[2])
+            else:
+                image_l, label_l = batch_l[0].to(device, non_blocking=True), batch_l[1].to(device, non_blocking=True)
             if semi:
-                image_u, _ = next(it_u)
-                meters = trainer.train_step(image_l, label_l, image_u.to(device, non_blocking=True), epoch)
+                batch_u = next(it_u)
+                if plan is not None:
+                    image_u, _ = augment_batch(plan, batch_u[0].to(device, non_blocking=True),
+                                               batch_u[1].to(device, non_blocking=True), batch_u[2])
+                else:
+                    image_u = batch_u[0].to(device, non_blocking=True)
+                meters = trainer.train_step(image_l, label_l, image_u, epoch)
             else:
                 meters = trainer.train_step(image_l, label_l, epoch)
             i_iter = epoch * len(loader_l) + step

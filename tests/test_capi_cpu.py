@@ -44,3 +44,25 @@ def test_product_never_imports_oracle():
                 if "import oracle" in s or "from oracle" in s or "/root/reference" in s:
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_winograd_layer_policy():
+    """nn.wino_tile: only stride-1 'same' 3x3 layers with MFMA-friendly channel counts, and only where tile
+    padding leaves a worthwhile multiply reduction (ASPP d=24 on a 97x97 map does not)."""
+    from u2pl_amd import nn as K
+    saved = dict(K.CONV_ALGO)
+    try:
+        K.CONV_ALGO.update(wino=4, min_gain=1.7)
+        assert K.wino_tile(256, 256, 3, 3, 1, 2, 2, 97, 97) == 4          # layer3
+        assert K.wino_tile(2048, 256, 3, 3, 1, 12, 12, 97, 97) == 4       # ASPP d=12
+        assert K.wino_tile(2048, 256, 3, 3, 1, 24, 24, 97, 97) == 0       # 5x5 sub-images: padding eats the gain
+        assert K.wino_tile(128, 128, 3, 3, 2, 1, 1, 193, 193) == 0        # strided
+        assert K.wino_tile(256, 1024, 1, 1, 1, 0, 1, 97, 97) == 0         # 1x1
+        assert K.wino_tile(3, 64, 3, 3, 1, 1, 1, 385, 385) == 0           # stem: Cin % 32
+        assert K.wino_tile(256, 19, 3, 3, 1, 1, 1, 97, 97) == 0           # narrow head
+        K.CONV_ALGO.update(wino=0)
+        assert K.wino_tile(256, 256, 3, 3, 1, 2, 2, 97, 97) == 0
+        K.CONV_ALGO.update(wino=2, min_gain=1.7)
+        assert K.wino_tile(256, 256, 3, 3, 1, 1, 1, 193, 193) == 2
+    finally:
+        K.CONV_ALGO.update(saved)

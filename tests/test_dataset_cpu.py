@@ -44,3 +44,36 @@ def test_voc_sup_loader(tmp_path):
     assert len(sup.dataset) == 8       # whole list is used (pascal_voc.py:85)
     img, lab = next(iter(sup))
     assert img.shape == (4, 3, 65, 65) and lab.shape == (4, 65, 65)
+
+
+def test_device_pipeline_plan_draws_like_the_cpu_pipeline():
+    """dataset/device_aug.AugmentPlan consumes python `random` exactly like builder.Pipeline (the reference's
+    augmentation order), and its geometry reproduces the Pipeline's output size / padding / crop origin."""
+    import random
+
+    import numpy as np
+    from PIL import Image
+
+    from u2pl_amd.dataset.builder import Pipeline
+    from u2pl_amd.dataset.device_aug import AugmentPlan
+
+    cfg = dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], rand_resize=[0.5, 2.0], flip=True,
+               crop=dict(type="rand", size=[97, 113]))
+    img = np.zeros((96, 150, 3), np.uint8)
+    # a coordinate image: label value encodes nothing, the image's red channel encodes x so the flip is visible
+    img[..., 0] = np.arange(150, dtype=np.uint8)[None, :]
+    lab = np.full((96, 150), 7, np.uint8)
+    for seed in range(12):
+        random.seed(seed)
+        out_img, out_lab = Pipeline(cfg)(Image.fromarray(img), Image.fromarray(lab))
+        after_cpu = random.random()
+        random.seed(seed)
+        p = AugmentPlan(cfg).draw(96, 150)
+        assert random.random() == after_cpu
+        rh, rw, flip, pt, pl, ho, wo, _ = [int(v) for v in p]
+        assert tuple(out_lab.shape) == (97, 113)
+        # rows / columns of the crop that fall on the zero padding carry label 0 (augmentation.py:241-245)
+        ys = np.arange(97) + ho - pt
+        xs = np.arange(113) + wo - pl
+        inside = ((ys >= 0) & (ys < rh))[:, None] & ((xs >= 0) & (xs < rw))[None, :]
+        assert np.array_equal(out_lab.numpy() == 7, inside), (seed, p)

@@ -337,3 +337,37 @@ def test_model_builder_vs_reference_golden(tag, arch, S, C, aux, conv_algo):
     chk(oe["rep"], "rep_eval", "rep_eval64", "rep_eval")
     print("\n".join(f"{k}: hip {v[0]:.3e} ref32 {v[1]:.3e}" for k, v in report.items()))
     assert not fails, "\n".join(fails)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,d", [(4, 256, 256, 97, 2), (4, 512, 256, 193, 1), (2, 2048, 256, 97, 12)])
+def test_full_size_winograd_agrees_with_direct_kernel(N, Cin, Cout, H, d):
+    """BASELINE-size layers (layer3 3x3 d=2, decoder 512->256 @193^2, ASPP d=12): the Winograd F(4x4) path and the
+    direct implicit-GEMM kernel agree on forward, data gradient and weight gradient, and the forward is linear
+    (size-independent properties; a CPU reference at these sizes would take minutes)."""
+    Kn = K()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(N, Cin, H, H, device=DEV, generator=g).contiguous(memory_format=CL)
+    x2 = torch.randn(N, Cin, H, H, device=DEV, generator=g).contiguous(memory_format=CL)
+    gy = torch.randn(N, Cout, H, H, device=DEV, generator=g).contiguous(memory_format=CL)
+    conv = Kn.Conv2d(Cin, Cout, 3, padding=d, dilation=d, bias=False).to(DEV)
+    saved = dict(Kn.CONV_ALGO)
+    res = {}
+    try:
+        for algo in (0, 4):
+            Kn.CONV_ALGO.update(wino=algo, min_gain=0.0)
+            xi = x.clone().requires_grad_(True)
+            conv.weight.grad = None
+            y = conv(xi)
+            y.backward(gy)
+            res[algo] = (y.detach(), xi.grad.detach(), conv.weight.grad.detach().clone())
+        Kn.CONV_ALGO.update(wino=4, min_gain=0.0)
+        with torch.no_grad():
+            lin = conv(2.0 * x - 0.5 * x2) - (2.0 * conv(x) - 0.5 * conv(x2))
+    finally:
+        Kn.CONV_ALGO.update(saved)
+    for name, a, b in zip(("fwd", "dgrad", "wgrad"), res[4], res[0]):
+        scale = b.abs().max().item()
+        err = (a - b).abs().max().item()
+        print(name, "max |wino - direct|", err, "scale", scale)
+        assert err <= 2e-4 * scale, (name, err, scale)
+    assert lin.abs().max().item() <= 2e-4 * res[0][0].abs().max().item()

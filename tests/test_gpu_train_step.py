@@ -30,8 +30,18 @@ def _gen_randint(seed):
     return (lambda high, n: torch.randint(high, size=(n,), generator=g)), g
 
 
+@pytest.fixture(params=[4, 0], ids=["winograd_default", "direct_conv"])
+def conv_mode(request):
+    """the production default (Winograd F(4x4) on the policy-selected 3x3 layers) and the all-direct kernel"""
+    from u2pl_amd import nn as Kn
+    saved = dict(Kn.CONV_ALGO)
+    Kn.CONV_ALGO.update(wino=request.param)
+    yield request.param
+    Kn.CONV_ALGO.update(saved)
+
+
 @pytest.mark.parametrize("arch,S", [("resnet50", 97)])
-def test_train_step_matches_cpu_port(arch, S):
+def test_train_step_matches_cpu_port(arch, S, conv_mode):
     from oracle.step_ref import CpuStepRef
     from u2pl_amd import configs
     from u2pl_amd.models.model_helper import ModelBuilder

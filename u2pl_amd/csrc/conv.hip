@@ -18,6 +18,7 @@
 // prefetch of the next K chunk overlaps the MFMAs of the current one.  K order
 // inside an 8-wide group is permuted (lane half h supplies k = 4h+j at step j) so
 // each lane fetches its four A / B operands with one ds_read_b128.
+#include <stdlib.h>
 #include "common.h"
 #include "u2pl_hip.h"
 
@@ -40,15 +41,17 @@ __device__ __forceinline__ bool gather_coord(int base, int tap, int step, int lo
     return ok;
 }
 
-template <int TM, int TN>
-__global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__ x, long ldx,
+// WM = wave rows of the block (2: 4 waves / 256 threads; 4: 8 waves / 512 threads with half the rows per wave)
+template <int TM, int TN, int WM = 2>
+__global__ __launch_bounds__(128 * WM, WM) void k_conv_igemm(const float* __restrict__ x, long ldx,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
                                                        long ldy, ConvGeom g, unsigned xbytes, unsigned wbytes,
                                                        long m_begin, long m_end, float* __restrict__ stats,
                                                        const float* __restrict__ pivot, long zx, long zw, long zy) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int RA = BM / 32, RB = BN / 32;  // rows per thread per chunk
+    constexpr int BM = 32 * TM * WM, BN = 64 * TN;
+    constexpr int NT = 128 * WM, RPP = NT / 8;          // threads, tile rows filled per pass (8 threads x float4 = BK)
+    constexpr int RA = BM / RPP, RB = BN / RPP;         // rows per thread per chunk
     // batched use (Winograd components): blockIdx.z selects an independent GEMM, element strides zx/zw/zy
     x += (long)blockIdx.z * zx;
     w += (long)blockIdx.z * zw;
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
     bool mv[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        long m = m0 + r0 + 32 * i;
+        long m = m0 + r0 + RPP * i;
         mv[i] = m < M;
         const unsigned mm = mv[i] ? (unsigned)m : 0u;   // pixel index < 2^31 (host check): 32-bit divisions
         const unsigned t = mm / (unsigned)g.Wout;
@@ -103,16 +106,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int co = n0 + r0 + 32 * i;
+            const int co = n0 + r0 + RPP * i;
             const int off = (co * K + kc * BK + kq * 4) * 4;
             rb[i] = buf_load4(rw, co < g.Cout ? off : OOB_OFF);
         }
     };
     auto store_chunk = [&](int buf, const float4 (&ra)[RA], const float4 (&rb)[RB]) {
 #pragma unroll
-        for (int i = 0; i < RA; ++i) *(float4*)(As + ((long)buf * BM + r0 + 32 * i) * LDP + kq * 4) = ra[i];
+        for (int i = 0; i < RA; ++i) *(float4*)(As + ((long)buf * BM + r0 + RPP * i) * LDP + kq * 4) = ra[i];
 #pragma unroll
-        for (int i = 0; i < RB; ++i) *(float4*)(Bs + ((long)buf * BN + r0 + 32 * i) * LDP + kq * 4) = rb[i];
+        for (int i = 0; i < RB; ++i) *(float4*)(Bs + ((long)buf * BN + r0 + RPP * i) * LDP + kq * 4) = rb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
     // S1 = sum(v - p), S2 = sum((v - p)^2) over the tile's valid rows, written in the two-stage column-reduce
     // partial format [tile][2][Cout]; the ordered double-precision finish is k_colreduce_final.
     if (stats) {
-        float* red = smem;   // [2 (wm)][2][BN]; the K loop's last barrier has passed, LDS is free
+        float* red = smem;   // [WM (wm)][2][BN]; the K loop's last barrier has passed, LDS is free
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int cl = wn * 32 * TN + b * 32 + li, co = n0 + cl;
@@ -237,26 +240,29 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const float* __restrict__
         }
         __syncthreads();
         float* out = stats + (long)blockIdx.x * 2 * g.Cout;
-        for (int c = tid; c < BN; c += 256) {
+        for (int c = tid; c < BN; c += NT) {
             const int co = n0 + c;
             if (co < g.Cout) {
-                out[co] = red[0 * BN + c] + red[2 * BN + c];
-                out[g.Cout + co] = red[1 * BN + c] + red[3 * BN + c];
+                float a1 = red[0 * BN + c], a2 = red[1 * BN + c];
+#pragma unroll
+                for (int r = 1; r < WM; ++r) { a1 += red[(2 * r) * BN + c]; a2 += red[(2 * r + 1) * BN + c]; }
+                out[co] = a1;
+                out[g.Cout + co] = a2;
             }
         }
     }
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int WM = 2>
 static int launch_igemm(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
                         const ConvGeom& g, long m_begin, long m_end, hipStream_t stream, float* stats = nullptr,
                         const float* pivot = nullptr, int batch = 1, long zx = 0, long zw = 0, long zy = 0) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int BM = 32 * TM * WM, BN = 64 * TN;
     if (m_end <= m_begin) return 0;
     const size_t lds = (size_t)2 * (BM + BN) * LDP * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_conv_igemm<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_conv_igemm<TM, TN, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     // byte extents of the gathered tensor and of the weight matrix (raw-buffer descriptors)
@@ -264,7 +270,7 @@ static int launch_igemm(const float* x, long ldx, const float* w, const float* b
     const long wb = (long)g.Cout * g.R * g.S * g.Cin * 4;
     if (xb >= (1L << 31) || wb >= (1L << 31)) return U2PL_EINVAL;
     dim3 grid((unsigned)cdiv(m_end - m_begin, BM), (unsigned)cdiv(g.Cout, BN), (unsigned)batch);
-    hipLaunchKernelGGL((k_conv_igemm<TM, TN>), grid, dim3(256), lds, stream, x, ldx, w, bias, y, ldy, g, (unsigned)xb,
+    hipLaunchKernelGGL((k_conv_igemm<TM, TN, WM>), grid, dim3(128 * WM), lds, stream, x, ldx, w, bias, y, ldy, g, (unsigned)xb,
                        (unsigned)wb, m_begin, m_end, stats, pivot, zx, zw, zy);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -314,7 +320,13 @@ static int run_igemm(const float* x, long ldx, const float* w, const float* bias
     const long M = (long)g.N * g.Hout * g.Wout;
     const IgemmPlan p = plan_igemm(g, batch);
     if (g.Cout <= 64) return launch_igemm<2, 1>(x, ldx, w, bias, y, ldy, g, 0, M, stream, stats, pivot, batch, zx, zw, zy);
-    int rc = launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, 0, p.m_body, stream, stats, pivot, batch, zx, zw, zy);
+    // 128x128 body tiles are computed by 8 waves (4x2, 32x64 outputs each; 4 waves per SIMD with two resident
+    // blocks): +6 % MFMA throughput over 4 waves of 64x64 (98.7 -> 104.6 TFLOP/s on the step's launch mix; more
+    // waves cover each other's LDS / barrier stalls).  U2PL_IGEMM_WAVES=4 selects the older shape.
+    static int waves = 0;
+    if (!waves) { const char* e = getenv("U2PL_IGEMM_WAVES"); waves = (e && atoi(e) == 4) ? 4 : 8; }
+    int rc = waves == 8 ? launch_igemm<1, 2, 4>(x, ldx, w, bias, y, ldy, g, 0, p.m_body, stream, stats, pivot, batch, zx, zw, zy)
+                        : launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, 0, p.m_body, stream, stats, pivot, batch, zx, zw, zy);
     if (rc || p.nblk_tail == 0) return rc;
     float* st = stats ? stats + (long)p.nblk_body * 2 * g.Cout : nullptr;
     if (p.tail_tm == 2) return launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy);

@@ -387,6 +387,19 @@ def gen_model(ns, tag, arch, S, B, C, aux, seed=5):
     save(f"model_{tag}", **fx)
 
 
+def gen_miou_hist(ns, seed):
+    """reference utils.intersectionAndUnion (utils.py:568-580) on argmax maps with ignored pixels."""
+    rng = np.random.default_rng(seed)
+    K = 19
+    out = rng.integers(0, K, (3, 37, 41)).astype(np.uint8)
+    tgt = rng.integers(0, K, (3, 37, 41)).astype(np.uint8)
+    tgt[rng.random(tgt.shape) < 0.1] = 255
+    tgt[0, :5] = 255
+    tgt[tgt == 7] = 3                       # a class that never occurs in the ground truth
+    i, u, t = ns.utils.intersectionAndUnion(out, tgt, K)
+    save("miou_hist", out=out, tgt=tgt, inter=np.asarray(i), union=np.asarray(u), target=np.asarray(t))
+
+
 def gen_eval_window(ns, tag, H, W, crop, seed):
     """reference eval.py:184-224 scale_crop_process on a tiny R50 (formula weights, eval mode), fp32 and fp64."""
     import copy
@@ -456,6 +469,8 @@ def main():
         gen_pseudo(71, 65, 17, 19)
     if want("sgd"):
         gen_sgd_ema(ns, 81)
+    if want("miou"):
+        gen_miou_hist(ns, 101)
     if want("evalwin"):
         gen_eval_window(ns, "70x100", 70, 100, 65, 91)     # 2 x 2 overlapping windows, last ones pulled back
         gen_eval_window(ns, "50x90", 50, 90, 65, 92)       # image shorter than the crop: symmetric zero padding

@@ -444,3 +444,16 @@ def ema_decay(i_iter, len_loader, sup_only_epoch, ema_decay_origin):
 
 def ema_update(t, s, d):
     return (f32(d) * t + f32(1 - d) * s).astype(np.float32)
+
+
+def intersection_and_union(output, target, K, ignore_index=255):
+    """utils.py:568-580 (intersectionAndUnion): per-class |pred == gt|, |pred| + |gt| - |pred == gt|, |gt| with the
+    ignored pixels removed from the prediction first.  Restated with bincount (integer-exact)."""
+    output = np.asarray(output).reshape(-1).astype(np.int64).copy()
+    target = np.asarray(target).reshape(-1).astype(np.int64)
+    output[target == ignore_index] = ignore_index
+    hit = output[output == target]
+    ai = np.bincount(hit[hit < K], minlength=K)[:K]
+    ao = np.bincount(output[output < K], minlength=K)[:K]
+    at = np.bincount(target[target < K], minlength=K)[:K]
+    return ai, ao + at - ai, at

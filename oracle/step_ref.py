@@ -210,14 +210,9 @@ def validate_ref(model, batches, num_classes, ignore=255):
     with torch.no_grad():
         for images, labels in batches:
             out = _up(model(images)["pred"], labels.shape[1:]).argmax(1).numpy()
-            tgt = labels.numpy()
-            out = np.where(tgt == ignore, ignore, out)
-            hit = out[out == tgt]
-            ai = np.bincount(hit[hit != ignore], minlength=num_classes)[:num_classes]
-            ao = np.bincount(out[out != ignore], minlength=num_classes)[:num_classes]
-            at = np.bincount(tgt[tgt != ignore], minlength=num_classes)[:num_classes]
+            ai, au, _ = R.intersection_and_union(out, labels.numpy(), num_classes, ignore)
             inter += ai
-            union += ao + at - ai
+            union += au
     iou = inter / (union + 1e-10)
     return float(iou.mean()), iou
 

@@ -241,3 +241,14 @@ def test_window_grid_matches_reference_formula():
     # Cityscapes 1024x2048 at crop 769: stride ceil(769*2/3) = 513; 2 x 4 windows, last ones pulled back inside
     assert window_grid(1024, 2048, 769, 769) == [(0, 0), (0, 513), (0, 1026), (0, 1279), (255, 0), (255, 513), (255, 1026), (255, 1279)]
     assert window_grid(65, 65, 65, 65) == [(0, 0)]
+
+
+def test_intersection_and_union_pinned_to_reference():
+    """oracle/restate.intersection_and_union == reference utils.intersectionAndUnion (utils.py:568-580) on the golden;
+    oracle/step_ref.validate_ref accumulates exactly these histograms."""
+    g = golden("miou_hist")
+    i, u, t = R.intersection_and_union(g["out"], g["tgt"], 19)
+    assert np.array_equal(i, g["inter"]) and np.array_equal(u, g["union"]) and np.array_equal(t, g["target"])
+    assert g["target"][7] == 0 and g["union"][7] > 0     # absent class: IoU 0 through the 1e-10 guard, not NaN
+    iou = g["inter"] / (g["union"] + 1e-10)
+    assert np.isfinite(iou).all()

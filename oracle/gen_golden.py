@@ -387,6 +387,40 @@ def gen_model(ns, tag, arch, S, B, C, aux, seed=5):
     save(f"model_{tag}", **fx)
 
 
+AUG_CFG = dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], ignore_label=255, flip=True,
+               rand_resize=[0.5, 2.0], crop=dict(type="rand", size=[49, 57]))
+
+
+def gen_augment(ns):
+    """reference transform chain exactly as cityscapes.build_transfrom composes it (cityscapes.py:47-77 ->
+    augmentation.py ToTensor / Normalize / RandResize / RandomHorizontalFlip / Crop) on one synthetic sample, for
+    several python-`random` seeds (covers up- and down-scaling, both flip outcomes, padding when the resized
+    image is smaller than the crop)."""
+    import importlib
+    import random
+
+    from PIL import Image
+    city = importlib.import_module("u2pl.dataset.cityscapes")
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (60, 84, 3), dtype=np.uint8)
+    lab = rng.integers(0, 19, (60, 84), dtype=np.uint8)
+    lab[:4] = 255
+    fx = dict(img=img, lab=lab)
+    seeds = [0, 1, 2, 3, 4, 5, 8, 13]
+    for sd in seeds:
+        random.seed(sd)
+        tf = city.build_transfrom(AUG_CFG)
+        oi, ol = tf(Image.fromarray(img), Image.fromarray(lab))
+        fx[f"img_{sd}"] = oi[0]
+        fx[f"lab_{sd}"] = ol[0, 0].long().to(torch.uint8)
+        fx[f"next_{sd}"] = np.float64(random.random())
+    fx["seeds"] = np.array(seeds)
+    cfgv = dict(AUG_CFG, flip=False, rand_resize=False, crop=dict(type="center", size=[49, 57]))
+    oi, ol = city.build_transfrom(cfgv)(Image.fromarray(img), Image.fromarray(lab))
+    fx["img_center"], fx["lab_center"] = oi[0], ol[0, 0].long().to(torch.uint8)
+    save("augment", **fx)
+
+
 def gen_miou_hist(ns, seed):
     """reference utils.intersectionAndUnion (utils.py:568-580) on argmax maps with ignored pixels."""
     rng = np.random.default_rng(seed)
@@ -469,6 +503,8 @@ def main():
         gen_pseudo(71, 65, 17, 19)
     if want("sgd"):
         gen_sgd_ema(ns, 81)
+    if want("augment"):
+        gen_augment(ns)
     if want("miou"):
         gen_miou_hist(ns, 101)
     if want("evalwin"):

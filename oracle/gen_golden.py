@@ -421,6 +421,25 @@ def gen_augment(ns):
     save("augment", **fx)
 
 
+def gen_resample(ns):
+    """reference city_dset.__init__ (cityscapes.py:18-33): the seeded random.sample of the (tiled) list, both
+    regimes (list longer / shorter than n_sup)."""
+    import importlib
+    import tempfile
+    city = importlib.import_module("u2pl.dataset.cityscapes")
+    lines = [f"leftImg8bit/train/synth/synth_{i:06d}_000019_leftImg8bit.png" for i in range(11)]
+    d = tempfile.mkdtemp(prefix="cityscapes_")
+    lp = os.path.join(d, "labeled.txt")
+    open(lp, "w").write("\n".join(lines) + "\n")
+    fx = dict(lines=np.array(lines))
+    for tag, seed, n_sup in (("short", 2, 7), ("tiled", 2, 30), ("seed5", 5, 11)):
+        ds = city.city_dset(d, lp, None, seed, n_sup, "train")
+        fx["order_" + tag] = np.array([a[0] for a in ds.list_sample_new])
+        fx["labels_" + tag] = np.array([a[1] for a in ds.list_sample_new])
+        fx["cfg_" + tag] = np.array([seed, n_sup])
+    save("resample", **fx)
+
+
 def gen_miou_hist(ns, seed):
     """reference utils.intersectionAndUnion (utils.py:568-580) on argmax maps with ignored pixels."""
     rng = np.random.default_rng(seed)
@@ -503,6 +522,8 @@ def main():
         gen_pseudo(71, 65, 17, 19)
     if want("sgd"):
         gen_sgd_ema(ns, 81)
+    if want("resample"):
+        gen_resample(ns)
     if want("augment"):
         gen_augment(ns)
     if want("miou"):

@@ -421,6 +421,130 @@ def gen_augment(ns):
     save("augment", **fx)
 
 
+def gen_train_steps(ns):
+    """The reference's OWN train() (train_semi.py:234-594) for three optimizer steps on fixed inputs: tiny R50 at
+    65x65, batch 2+2, OHEM + aux, CutMix, contrastive bank; fake loaders, plain BN, dropout off (same parity mode
+    as the step tests).  Records the per-step losses, the CutMix coin / RNG seeds and a few parameters afterwards:
+    pins oracle/step_ref.CpuStepRef (the composition of the individually pinned pieces) to the real loop."""
+    import copy
+    import importlib.util
+    import logging
+
+    spec = importlib.util.spec_from_file_location("u2pl_ref_train_semi", os.path.join(ref_shim.REFERENCE_ROOT, "train_semi.py"))
+    ts = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ts)
+    S, B, C, steps = 65, 2, 19, 3
+    cfg = dict(
+        dataset=dict(type="cityscapes_semi", n_sup=744, ignore_label=255),
+        trainer=dict(epochs=20, sup_only_epoch=0,
+                     optimizer=dict(type="SGD", kwargs=dict(lr=0.01, momentum=0.9, weight_decay=0.0005)),
+                     lr_scheduler=dict(mode="poly", kwargs=dict(power=0.9)),
+                     unsupervised=dict(TTA=False, drop_percent=80, apply_aug="cutmix"),
+                     contrastive=dict(negative_high_entropy=True, low_rank=3, high_rank=20, current_class_threshold=0.055,
+                                      current_class_negative_threshold=1, unsupervised_entropy_ignore=80,
+                                      low_entropy_threshold=20, num_negatives=50, num_queries=256, temperature=0.5)),
+        criterion=dict(type="ohem", kwargs=dict(thresh=0.7, min_kept=2000)),
+        net=dict(num_classes=C, sync_bn=False, ema_decay=0.99,
+                 encoder=dict(type="u2pl.models.resnet.resnet50",
+                              kwargs=dict(multi_grid=True, zero_init_residual=True, fpn=True,
+                                          replace_stride_with_dilation=[False, True, True], pretrained=False)),
+                 decoder=dict(type="u2pl.models.decoder.dec_deeplabv3_plus", kwargs=dict(inner_planes=256, dilations=[12, 24, 36])),
+                 aux_loss=dict(aux_plane=1024, loss_weight=0.4)),
+    )
+    ts.cfg = cfg
+    torch.manual_seed(0)
+    model = ns.model_helper.ModelBuilder(copy.deepcopy(cfg["net"]))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    teacher = ns.model_helper.ModelBuilder(copy.deepcopy(cfg["net"]))
+    teacher.load_state_dict(sd)
+    for m in list(model.modules()) + list(teacher.modules()):
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    for p_ in teacher.parameters():
+        p_.requires_grad = False
+    cfg_optim = cfg["trainer"]["optimizer"]
+    params_list = [dict(params=model.encoder.parameters(), lr=cfg_optim["kwargs"]["lr"]),
+                   dict(params=model.auxor.parameters(), lr=cfg_optim["kwargs"]["lr"]),
+                   dict(params=model.decoder.parameters(), lr=cfg_optim["kwargs"]["lr"])]
+    optimizer = ts.get_optimizer(params_list, cfg_optim)
+    sup_loss_fn = ts.get_criterion(cfg)
+    gen = torch.Generator().manual_seed(77)
+    data = []
+    for _ in range(steps):
+        il, iu = torch.randn(B, 3, S, S, generator=gen), torch.randn(B, 3, S, S, generator=gen)
+        data.append((il, block_labels(B, S, C, gen, ignore_rows=4), iu))
+
+    class _It:
+        def __init__(self, items):
+            self.items, self.i = items, 0
+
+        def next(self):                     # the reference calls the py2-style iterator.next()
+            self.i += 1
+            return self.items[self.i - 1]
+
+        __next__ = next
+
+        def __iter__(self):
+            return self
+
+    class _Loader:
+        class sampler:
+            @staticmethod
+            def set_epoch(e):
+                pass
+
+        def __init__(self, items):
+            self.items = items
+
+        def __len__(self):
+            return len(self.items)
+
+        def __iter__(self):
+            return _It(self.items)
+
+    loader_l = _Loader([(a, b) for a, b, _ in data])
+    loader_u = _Loader([(c, None) for _, _, c in data])
+    optimizer_start = ts.get_optimizer(params_list, cfg_optim)
+    lr_scheduler = ts.get_scheduler(cfg["trainer"], len(loader_l), optimizer_start, start_epoch=0)
+    memobank, queue_ptrlis, queue_size = [], [], []
+    for i in range(C):
+        memobank.append([torch.zeros(0, 256)])
+        queue_size.append(30000)
+        queue_ptrlis.append(torch.zeros(1, dtype=torch.long))
+    queue_size[0] = 50000
+    ts.prototype = torch.zeros((C, 256, 1, 256))
+    rec = []
+
+    class _Meter:
+        def __init__(self, *a, **k):
+            self.val = self.avg = 0.0
+
+        def update(self, v, *a):
+            self.val = self.avg = v
+            rec.append(float(v))
+    ts.AverageMeter = _Meter
+    np.random.seed(31)
+    torch.manual_seed(41)
+
+    class _Wrap(torch.nn.Module):          # train() only calls the models and iterates .parameters()
+        pass
+    ts.train(model, teacher, optimizer, lr_scheduler, sup_loss_fn, loader_l, loader_u, 0, ts.SummaryWriter(),
+             logging.getLogger("gen_golden"), memobank, queue_ptrlis, queue_size)
+    # meters are updated per step in the order data_time, lr, sup, uns, con, batch_time
+    per = len(rec) // steps
+    rec = np.array(rec).reshape(steps, per)
+    fx = dict(meters=rec, n_meters=np.int64(per), seeds=np.array([0, 77, 31, 41]), steps=np.int64(steps),
+              bank_len=np.array([m[0].shape[0] for m in memobank]), bank_ptr=np.array([int(q[0]) for q in queue_ptrlis]))
+    for k in ("encoder.conv1.0.weight", "decoder.classifier.8.weight", "decoder.representation.8.bias", "auxor.aux.4.bias",
+              "encoder.layer3.2.bn2.weight"):
+        fx["student__" + k] = dict(model.named_parameters())[k].detach().clone()
+        fx["teacher__" + k] = dict(teacher.named_parameters())[k].detach().clone()
+    fx["teacher_bn__encoder.bn1.running_mean"] = dict(teacher.named_buffers())["encoder.bn1.running_mean"].clone()
+    for i, (il, ll, iu) in enumerate(data):
+        fx[f"il_{i}"], fx[f"ll_{i}"], fx[f"iu_{i}"] = il, ll.to(torch.uint8), iu
+    save("train_steps", **fx)
+
+
 def gen_resample(ns):
     """reference city_dset.__init__ (cityscapes.py:18-33): the seeded random.sample of the (tiled) list, both
     regimes (list longer / shorter than n_sup)."""
@@ -522,6 +646,8 @@ def main():
         gen_pseudo(71, 65, 17, 19)
     if want("sgd"):
         gen_sgd_ema(ns, 81)
+    if want("trainsteps"):
+        gen_train_steps(ns)
     if want("resample"):
         gen_resample(ns)
     if want("augment"):

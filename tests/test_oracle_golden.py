@@ -252,3 +252,52 @@ def test_intersection_and_union_pinned_to_reference():
     assert g["target"][7] == 0 and g["union"][7] > 0     # absent class: IoU 0 through the 1e-10 guard, not NaN
     iou = g["inter"] / (g["union"] + 1e-10)
     assert np.isfinite(iou).all()
+
+
+def test_step_port_pinned_to_the_reference_train_loop():
+    """oracle/step_ref.CpuStepRef (the composition of the individually pinned pieces) reproduces the reference's
+    OWN train() (train_semi.py:234-594, run in this container by oracle/gen_golden.py:gen_train_steps) over three
+    optimizer steps: learning rates, sup / unsup / contrastive losses, bank bookkeeping, student and EMA-teacher
+    parameters, teacher BN buffers."""
+    import torch
+    from oracle.step_ref import CpuStepRef
+    from u2pl_amd import configs
+    from u2pl_amd.models.model_helper import ModelBuilder
+
+    g = golden("train_steps")
+    steps = int(g["steps"])
+    cfg = configs.cityscapes_semi(arch="resnet50", crop=65, batch_size=2, sync_bn=False, epochs=20)
+    torch.manual_seed(int(g["seeds"][0]))
+    sd = {k: v.detach().clone() for k, v in ModelBuilder(cfg["net"]).state_dict().items()}   # reference-identical init
+    contra = dict(cfg["trainer"]["contrastive"], current_class_threshold=0.055)
+    ref = CpuStepRef(arch="resnet50", num_classes=19, aux=True, epochs=20, steps_per_epoch=steps, ohem=(0.7, 2000),
+                     p_drop=0.0, contra=contra, state_dict=sd)
+    np.random.seed(int(g["seeds"][2]))
+    torch.manual_seed(int(g["seeds"][3]))
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    for i in range(steps):
+        il, ll, iu = torch.from_numpy(g[f"il_{i}"]), torch.from_numpy(g[f"ll_{i}"]).long(), torch.from_numpy(g[f"iu_{i}"])
+        o = ref.step(il, ll, iu, epoch=0)
+        lr, sup, uns, con = (float(g["meters"][i][k]) for k in (1, 2, 3, 4))
+        # train() logs get_lr() BEFORE lr_scheduler.step(): the logged value is the rate the previous step used
+        if i + 1 < steps:
+            assert abs(ref.opt.param_groups[0]["lr"] - float(g["meters"][i + 1][1])) <= 1e-12, i
+        else:
+            assert lr < 0.01
+        # step 0 starts from identical weights: exact up to summation order; later steps compare two fp32 weight
+        # trajectories whose conv reductions depend on the thread count (pixels near the percentile thresholds flip)
+        tol = 2e-6 if i == 0 else 2e-3
+        for name, a, b in (("sup", o["sup"], sup), ("unsup", o["unsup"], uns), ("contra", o["contra"], con)):
+            assert abs(a - b) <= tol * max(1.0, abs(b)), (i, name, a, b)
+    assert [b[0].shape[0] for b in ref.bank] == [int(x) for x in g["bank_len"]]
+    sref, tref = dict(ref.student.named_parameters()), dict(ref.teacher.named_parameters())
+    for k in g.files:
+        if k.startswith("student__"):
+            a, b = sref[k[9:]].detach(), torch.from_numpy(g[k])
+            # fp32 weight gradients of the first layers depend on the thread count's reduction order (~1e-4 of the update)
+            assert (a - b).abs().max().item() <= 1e-6 + 2e-2 * (b - sd[k[9:]]).abs().max().item(), k
+        elif k.startswith("teacher__"):
+            a, b = tref[k[9:]].detach(), torch.from_numpy(g[k])
+            assert (a - b).abs().max().item() <= 1e-6 + 2e-2 * (b - sd[k[9:]]).abs().max().item(), k
+    rm = dict(ref.teacher.named_buffers())["encoder.bn1.running_mean"]
+    assert torch.allclose(rm, torch.from_numpy(g["teacher_bn__encoder.bn1.running_mean"]), rtol=1e-3, atol=1e-5)

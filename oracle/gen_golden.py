@@ -421,7 +421,7 @@ def gen_augment(ns):
     save("augment", **fx)
 
 
-def gen_train_steps(ns):
+def gen_train_steps(ns, voc=False):
     """The reference's OWN train() (train_semi.py:234-594) for three optimizer steps on fixed inputs: tiny R50 at
     65x65, batch 2+2, OHEM + aux, CutMix, contrastive bank; fake loaders, plain BN, dropout off (same parity mode
     as the step tests).  Records the per-step losses, the CutMix coin / RNG seeds and a few parameters afterwards:
@@ -434,6 +434,9 @@ def gen_train_steps(ns):
     ts = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ts)
     S, B, C, steps = 65, 2, 19, 3
+    epochs_run = [0]
+    if voc:   # experiments/pascal/1464/ours flavour: C=21, no aux head, plain CE, head lr x10, sup_only_epoch = 1
+        C, steps, epochs_run = 21, 2, [0, 1]
     cfg = dict(
         dataset=dict(type="cityscapes_semi", n_sup=744, ignore_label=255),
         trainer=dict(epochs=20, sup_only_epoch=0,
@@ -451,6 +454,14 @@ def gen_train_steps(ns):
                  decoder=dict(type="u2pl.models.decoder.dec_deeplabv3_plus", kwargs=dict(inner_planes=256, dilations=[12, 24, 36])),
                  aux_loss=dict(aux_plane=1024, loss_weight=0.4)),
     )
+    if voc:
+        cfg["dataset"]["type"] = "pascal_semi"
+        cfg["trainer"].pop("sup_only_epoch")
+        cfg["trainer"]["optimizer"]["kwargs"].update(lr=0.001, weight_decay=0.0001)
+        cfg["trainer"]["contrastive"]["current_class_threshold"] = 0.05
+        cfg["criterion"] = dict(type="CELoss", kwargs=dict(use_weight=False))
+        cfg["net"]["num_classes"] = C
+        cfg["net"].pop("aux_loss")
     ts.cfg = cfg
     torch.manual_seed(0)
     model = ns.model_helper.ModelBuilder(copy.deepcopy(cfg["net"]))
@@ -463,14 +474,16 @@ def gen_train_steps(ns):
     for p_ in teacher.parameters():
         p_.requires_grad = False
     cfg_optim = cfg["trainer"]["optimizer"]
-    params_list = [dict(params=model.encoder.parameters(), lr=cfg_optim["kwargs"]["lr"]),
-                   dict(params=model.auxor.parameters(), lr=cfg_optim["kwargs"]["lr"]),
-                   dict(params=model.decoder.parameters(), lr=cfg_optim["kwargs"]["lr"])]
+    times = 10 if "pascal" in cfg["dataset"]["type"] else 1          # train_semi.py:100-110
+    params_list = [dict(params=model.encoder.parameters(), lr=cfg_optim["kwargs"]["lr"])]
+    if not voc:
+        params_list.append(dict(params=model.auxor.parameters(), lr=cfg_optim["kwargs"]["lr"] * times))
+    params_list.append(dict(params=model.decoder.parameters(), lr=cfg_optim["kwargs"]["lr"] * times))
     optimizer = ts.get_optimizer(params_list, cfg_optim)
     sup_loss_fn = ts.get_criterion(cfg)
     gen = torch.Generator().manual_seed(77)
     data = []
-    for _ in range(steps):
+    for _ in range(steps * len(epochs_run)):
         il, iu = torch.randn(B, 3, S, S, generator=gen), torch.randn(B, 3, S, S, generator=gen)
         data.append((il, block_labels(B, S, C, gen, ignore_rows=4), iu))
 
@@ -502,8 +515,8 @@ def gen_train_steps(ns):
         def __iter__(self):
             return _It(self.items)
 
-    loader_l = _Loader([(a, b) for a, b, _ in data])
-    loader_u = _Loader([(c, None) for _, _, c in data])
+    loader_l = _Loader([(a, b) for a, b, _ in data[:steps]])
+    loader_u = _Loader([(c, None) for _, _, c in data[:steps]])
     optimizer_start = ts.get_optimizer(params_list, cfg_optim)
     lr_scheduler = ts.get_scheduler(cfg["trainer"], len(loader_l), optimizer_start, start_epoch=0)
     memobank, queue_ptrlis, queue_size = [], [], []
@@ -528,21 +541,28 @@ def gen_train_steps(ns):
 
     class _Wrap(torch.nn.Module):          # train() only calls the models and iterates .parameters()
         pass
-    ts.train(model, teacher, optimizer, lr_scheduler, sup_loss_fn, loader_l, loader_u, 0, ts.SummaryWriter(),
-             logging.getLogger("gen_golden"), memobank, queue_ptrlis, queue_size)
+    for e in epochs_run:
+        loader_l.items = [(a, b) for a, b, _ in data[e * steps:(e + 1) * steps]]
+        loader_u.items = [(c, None) for _, _, c in data[e * steps:(e + 1) * steps]]
+        ts.train(model, teacher, optimizer, lr_scheduler, sup_loss_fn, loader_l, loader_u, e, ts.SummaryWriter(),
+                 logging.getLogger("gen_golden"), memobank, queue_ptrlis, queue_size)
     # meters are updated per step in the order data_time, lr, sup, uns, con, batch_time
-    per = len(rec) // steps
-    rec = np.array(rec).reshape(steps, per)
+    nst = steps * len(epochs_run)
+    per = len(rec) // nst
+    rec = np.array(rec).reshape(nst, per)
     fx = dict(meters=rec, n_meters=np.int64(per), seeds=np.array([0, 77, 31, 41]), steps=np.int64(steps),
+              epochs=np.array(epochs_run),
               bank_len=np.array([m[0].shape[0] for m in memobank]), bank_ptr=np.array([int(q[0]) for q in queue_ptrlis]))
     for k in ("encoder.conv1.0.weight", "decoder.classifier.8.weight", "decoder.representation.8.bias", "auxor.aux.4.bias",
               "encoder.layer3.2.bn2.weight"):
+        if voc and k.startswith("auxor"):
+            continue
         fx["student__" + k] = dict(model.named_parameters())[k].detach().clone()
         fx["teacher__" + k] = dict(teacher.named_parameters())[k].detach().clone()
     fx["teacher_bn__encoder.bn1.running_mean"] = dict(teacher.named_buffers())["encoder.bn1.running_mean"].clone()
     for i, (il, ll, iu) in enumerate(data):
         fx[f"il_{i}"], fx[f"ll_{i}"], fx[f"iu_{i}"] = il, ll.to(torch.uint8), iu
-    save("train_steps", **fx)
+    save("train_steps_voc" if voc else "train_steps", **fx)
 
 
 def gen_resample(ns):
@@ -648,6 +668,8 @@ def main():
         gen_sgd_ema(ns, 81)
     if want("trainsteps"):
         gen_train_steps(ns)
+    if want("trainsteps_voc"):
+        gen_train_steps(ns, voc=True)
     if want("resample"):
         gen_resample(ns)
     if want("augment"):

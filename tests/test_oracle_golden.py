@@ -301,3 +301,44 @@ def test_step_port_pinned_to_the_reference_train_loop():
             assert (a - b).abs().max().item() <= 1e-6 + 2e-2 * (b - sd[k[9:]]).abs().max().item(), k
     rm = dict(ref.teacher.named_buffers())["encoder.bn1.running_mean"]
     assert torch.allclose(rm, torch.from_numpy(g["teacher_bn__encoder.bn1.running_mean"]), rtol=1e-3, atol=1e-5)
+
+
+def test_step_port_pinned_to_the_reference_train_loop_voc_config():
+    """same pinning for the VOC-style configuration (experiments/pascal/1464/ours: C=21, no aux head, plain CE, head
+    learning rate x10, sup_only_epoch = 1): the reference's train() for one supervised-only epoch (teacher only
+    refreshes BN buffers) and the first semi-supervised epoch (teacher <- student, EMA decay 0), 2 steps each."""
+    import torch
+    from oracle.step_ref import CpuStepRef
+    from u2pl_amd import configs
+    from u2pl_amd.models.model_helper import ModelBuilder
+
+    g = golden("train_steps_voc")
+    spe = int(g["steps"])
+    cfg = configs.pascal_semi(arch="resnet50", crop=65, batch_size=2, sync_bn=False, epochs=20)
+    torch.manual_seed(int(g["seeds"][0]))
+    sd = {k: v.detach().clone() for k, v in ModelBuilder(cfg["net"]).state_dict().items()}
+    ok = cfg["trainer"]["optimizer"]["kwargs"]
+    contra = dict(cfg["trainer"]["contrastive"], current_class_threshold=0.05)
+    ref = CpuStepRef(arch="resnet50", num_classes=21, aux=False, epochs=20, steps_per_epoch=spe, lr=ok["lr"],
+                     weight_decay=ok["weight_decay"], lr_times=10, sup_only_epoch=1, ohem=None, p_drop=0.0, contra=contra,
+                     state_dict=sd)
+    np.random.seed(int(g["seeds"][2]))
+    torch.manual_seed(int(g["seeds"][3]))
+    n = spe * len(g["epochs"])
+    for i in range(n):
+        il, ll, iu = torch.from_numpy(g[f"il_{i}"]), torch.from_numpy(g[f"ll_{i}"]).long(), torch.from_numpy(g[f"iu_{i}"])
+        o = ref.step(il, ll, iu, epoch=i // spe)
+        if i + 1 < n:
+            assert abs(ref.opt.param_groups[0]["lr"] - float(g["meters"][i + 1][1])) <= 1e-12, i
+            assert abs(ref.opt.param_groups[-1]["lr"] - 10 * float(g["meters"][i + 1][1])) <= 1e-11, i
+        tol = 2e-6 if i == 0 else 2e-3
+        for name, a, b in (("sup", o["sup"], g["meters"][i][2]), ("unsup", o["unsup"], g["meters"][i][3]),
+                           ("contra", o["contra"], g["meters"][i][4])):
+            assert abs(a - float(b)) <= tol * max(1.0, abs(float(b))), (i, name, a, float(b))
+    assert [b[0].shape[0] for b in ref.bank] == [int(x) for x in g["bank_len"]]
+    sref, tref = dict(ref.student.named_parameters()), dict(ref.teacher.named_parameters())
+    for k in g.files:
+        if k.startswith("student__") or k.startswith("teacher__"):
+            src = sref if k.startswith("student__") else tref
+            a, b = src[k[9:]].detach(), torch.from_numpy(g[k])
+            assert (a - b).abs().max().item() <= 1e-6 + 2e-2 * (b - sd[k[9:]]).abs().max().item(), k

@@ -234,6 +234,14 @@ int u2pl_ema_update_f32(float* t, const float* s, long n, float decay, float one
 int u2pl_cutmix_f32(const float* img, const long long* label, const float* conf, const int* boxes_dev, int B, int C,
                     int H, int W, float* out_img, long long* out_label, float* out_conf, hipStream_t stream);
 
+/* generate_unsup_data(mode="cutout" -> mode 1, boxes) / (mode="classmix" -> mode 2, sel): augmentation.py:486-541.
+   sel_dev: uint64 [B], bit c set = class c of image i is in generate_class_mask's selected half */
+int u2pl_strong_aug_f32(const float* img, const long long* label, const float* conf, const int* boxes_dev,
+                        const unsigned long long* sel_dev, int mode, int B, int C, int H, int W, float* out_img,
+                        long long* out_label, float* out_conf, hipStream_t stream);
+/* torch.unique(pseudo_labels) (augmentation.py:488) as a per-image presence bitmask; bits [B] zeroed by the caller */
+int u2pl_label_presence_i64(const long long* label, int B, long HW, unsigned long long* bits, hipStream_t stream);
+
 /* sliding-window evaluation accumulators (eval.py:184-224): pred [C][H][W] += src [C][hc][wc] at (h0, w0), count += 1;
    then pred /= count */
 int u2pl_window_accumulate_f32(float* pred, float* count, int C, int H, int W, const float* src, int h0, int w0,

@@ -243,6 +243,41 @@ def gen_cutmix(ns, seed, B, S):
          new_data=nd, new_target=nt, new_logits=nl)
 
 
+def gen_strong_aug(ns, seed, B, S):
+    """reference generate_unsup_data for the two other modes (augmentation.py:486-541): "cutout" (boxes replayed from
+    np.random like gen_cutmix) and "classmix" (the per-image selected classes replayed from torch.randperm)."""
+    gen = torch.Generator().manual_seed(seed)
+    data = torch.randn(B, 3, S, S, generator=gen)
+    data[0, 0, :3, :3] = -0.0            # signed zero / x*0 behaviour is part of the contract
+    target = block_labels(B, S, 19, gen, ignore_rows=0, cell=16)
+    target[1][target[1] == 3] = 5        # images with different class sets
+    logits = torch.rand(B, S, S, generator=gen)
+    np.random.seed(seed)
+    state = np.random.get_state()
+    nd, nt, nl = ns.augmentation.generate_unsup_data(data, target.clone(), logits.clone(), mode="cutout")
+    np.random.set_state(state)
+    boxes = []
+    for _ in range(B):
+        area = S * S / 2
+        w = np.random.randint(S / 2 + 1, S)
+        h = np.round(area / w)
+        x0 = np.random.randint(0, S - w + 1)
+        y0 = np.random.randint(0, S - h + 1)
+        boxes.append((int(y0), int(y0 + h), int(x0), int(x0 + w)))
+    fx = dict(data=data, target=target.to(torch.uint8), logits=logits, seed=np.int64(seed), boxes=np.array(boxes),
+              cutout_data=nd, cutout_target=nt.to(torch.uint8), cutout_logits=nl)
+    torch.manual_seed(seed)
+    nd, nt, nl = ns.augmentation.generate_unsup_data(data, target.clone(), logits.clone(), mode="classmix")
+    torch.manual_seed(seed)
+    sel = np.zeros((B, 32), np.int64) - 1
+    for i in range(B):
+        labels = torch.unique(target[i])
+        ch = labels[torch.randperm(len(labels))][: len(labels) // 2].numpy()
+        sel[i, : len(ch)] = ch
+    fx.update(classmix_selected=sel, classmix_data=nd, classmix_target=nt.to(torch.uint8), classmix_logits=nl)
+    save("strong_aug", **fx)
+
+
 def gen_pseudo(seed, S, s, C):
     gen = torch.Generator().manual_seed(seed)
     low = torch.randn(2, C, s, s, generator=gen) * 3
@@ -421,56 +456,84 @@ def gen_augment(ns):
     save("augment", **fx)
 
 
-def gen_train_steps(ns, voc=False):
-    """The reference's OWN train() (train_semi.py:234-594) for three optimizer steps on fixed inputs: tiny R50 at
-    65x65, batch 2+2, OHEM + aux, CutMix, contrastive bank; fake loaders, plain BN, dropout off (same parity mode
-    as the step tests).  Records the per-step losses, the CutMix coin / RNG seeds and a few parameters afterwards:
-    pins oracle/step_ref.CpuStepRef (the composition of the individually pinned pieces) to the real loop."""
-    import copy
+def _load_ref_train_semi():
     import importlib.util
-    import logging
 
     spec = importlib.util.spec_from_file_location("u2pl_ref_train_semi", os.path.join(ref_shim.REFERENCE_ROOT, "train_semi.py"))
     ts = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ts)
-    S, B, C, steps = 65, 2, 19, 3
-    epochs_run = [0]
-    if voc:   # experiments/pascal/1464/ours flavour: C=21, no aux head, plain CE, head lr x10, sup_only_epoch = 1
-        C, steps, epochs_run = 21, 2, [0, 1]
+    return ts
+
+
+def _train_cfg(voc, arch, C, min_kept, class_thr, epochs=20):
     cfg = dict(
         dataset=dict(type="cityscapes_semi", n_sup=744, ignore_label=255),
-        trainer=dict(epochs=20, sup_only_epoch=0,
+        trainer=dict(epochs=epochs, sup_only_epoch=0,
                      optimizer=dict(type="SGD", kwargs=dict(lr=0.01, momentum=0.9, weight_decay=0.0005)),
                      lr_scheduler=dict(mode="poly", kwargs=dict(power=0.9)),
                      unsupervised=dict(TTA=False, drop_percent=80, apply_aug="cutmix"),
-                     contrastive=dict(negative_high_entropy=True, low_rank=3, high_rank=20, current_class_threshold=0.055,
+                     contrastive=dict(negative_high_entropy=True, low_rank=3, high_rank=20, current_class_threshold=class_thr,
                                       current_class_negative_threshold=1, unsupervised_entropy_ignore=80,
                                       low_entropy_threshold=20, num_negatives=50, num_queries=256, temperature=0.5)),
-        criterion=dict(type="ohem", kwargs=dict(thresh=0.7, min_kept=2000)),
+        criterion=dict(type="ohem", kwargs=dict(thresh=0.7, min_kept=min_kept)),
         net=dict(num_classes=C, sync_bn=False, ema_decay=0.99,
-                 encoder=dict(type="u2pl.models.resnet.resnet50",
+                 encoder=dict(type=f"u2pl.models.resnet.{arch}",
                               kwargs=dict(multi_grid=True, zero_init_residual=True, fpn=True,
                                           replace_stride_with_dilation=[False, True, True], pretrained=False)),
                  decoder=dict(type="u2pl.models.decoder.dec_deeplabv3_plus", kwargs=dict(inner_planes=256, dilations=[12, 24, 36])),
                  aux_loss=dict(aux_plane=1024, loss_weight=0.4)),
     )
-    if voc:
+    if voc:   # experiments/pascal/1464/ours flavour: C=21, no aux head, plain CE, head lr x10, sup_only_epoch = 1
         cfg["dataset"]["type"] = "pascal_semi"
         cfg["trainer"].pop("sup_only_epoch")
         cfg["trainer"]["optimizer"]["kwargs"].update(lr=0.001, weight_decay=0.0001)
-        cfg["trainer"]["contrastive"]["current_class_threshold"] = 0.05
         cfg["criterion"] = dict(type="CELoss", kwargs=dict(use_weight=False))
-        cfg["net"]["num_classes"] = C
         cfg["net"].pop("aux_loss")
+    return cfg
+
+
+def _pack_classbits(onehot):
+    """(N,C,h,w) {0,1} -> (N,h,w) int32 bit c = class c (the product's lbits layout)."""
+    oh = onehot.detach().cpu().numpy().astype(np.int64)
+    bits = np.zeros((oh.shape[0],) + oh.shape[2:], np.int64)
+    for c in range(oh.shape[1]):
+        bits |= oh[:, c] << c
+    return bits.astype(np.int32)
+
+
+def _run_reference_train(ns, cfg, data, steps, epochs_run, voc, init_seed=0, np_seed=31, torch_seed=41, p_drop=0.0,
+                         dropout_seed=None, sharpen=None, capture=None, threads=None, ddp=False):
+    """Drive the reference's OWN train() (train_semi.py:234-594) over `data` (list of (il, ll, iu), `steps` per epoch
+    in `epochs_run`) with fake loaders, plain BN and a gloo world of 1.  Dropout: p_drop = 0, or p = 0.1 with the
+    keep-masks of oracle/parity_dropout.KeyedMasks(dropout_seed) (nn.Dropout2d.forward patched at run time; no
+    reference file is modified).  capture: list that receives one dict per semi-supervised step with the arguments /
+    side effects of compute_unsupervised_loss and compute_contra_memobank_loss (the mask tensors the product must
+    reproduce)."""
+    import contextlib
+    import copy
+    import logging
+
+    import parity_dropout as PD
+
+    ts = _load_ref_train_semi()
+    C = cfg["net"]["num_classes"]
     ts.cfg = cfg
-    torch.manual_seed(0)
+    torch.manual_seed(init_seed)
     model = ns.model_helper.ModelBuilder(copy.deepcopy(cfg["net"]))
+    if sharpen:
+        with torch.no_grad():
+            model.decoder.classifier[8].weight.mul_(sharpen)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     teacher = ns.model_helper.ModelBuilder(copy.deepcopy(cfg["net"]))
     teacher.load_state_dict(sd)
     for m in list(model.modules()) + list(teacher.modules()):
         if isinstance(m, torch.nn.Dropout2d):
-            m.p = 0.0
+            m.p = p_drop
+    masks = None
+    if dropout_seed is not None:
+        PD.tag_model(model, "student")
+        PD.tag_model(teacher, "teacher")
+        masks = PD.KeyedMasks(dropout_seed)
     for p_ in teacher.parameters():
         p_.requires_grad = False
     cfg_optim = cfg["trainer"]["optimizer"]
@@ -481,11 +544,9 @@ def gen_train_steps(ns, voc=False):
     params_list.append(dict(params=model.decoder.parameters(), lr=cfg_optim["kwargs"]["lr"] * times))
     optimizer = ts.get_optimizer(params_list, cfg_optim)
     sup_loss_fn = ts.get_criterion(cfg)
-    gen = torch.Generator().manual_seed(77)
-    data = []
-    for _ in range(steps * len(epochs_run)):
-        il, iu = torch.randn(B, 3, S, S, generator=gen), torch.randn(B, 3, S, S, generator=gen)
-        data.append((il, block_labels(B, S, C, gen, ignore_rows=4), iu))
+    raw_model = model
+    if ddp:   # train_semi.py:114-120 (CPU / gloo flavour of the same wrapper)
+        model = torch.nn.parallel.DistributedDataParallel(model)
 
     class _It:
         def __init__(self, items):
@@ -536,21 +597,61 @@ def gen_train_steps(ns, voc=False):
             self.val = self.avg = v
             rec.append(float(v))
     ts.AverageMeter = _Meter
-    np.random.seed(31)
-    torch.manual_seed(41)
+    if capture is not None:
+        f_unsup, f_contra = ts.compute_unsupervised_loss, ts.compute_contra_memobank_loss
 
-    class _Wrap(torch.nn.Module):          # train() only calls the models and iterates .parameters()
-        pass
-    for e in epochs_run:
-        loader_l.items = [(a, b) for a, b, _ in data[e * steps:(e + 1) * steps]]
-        loader_u.items = [(c, None) for _, _, c in data[e * steps:(e + 1) * steps]]
-        ts.train(model, teacher, optimizer, lr_scheduler, sup_loss_fn, loader_l, loader_u, e, ts.SummaryWriter(),
-                 logging.getLogger("gen_golden"), memobank, queue_ptrlis, queue_size)
+        def unsup(predict, target, percent, pred_teacher):
+            d = dict(label_u_aug=target.clone(), percent=float(percent))
+            out = f_unsup(predict, target, percent, pred_teacher)
+            d["target_u"] = target.clone()                      # mutated in place (loss_helper.py:41-43)
+            capture.append(d)
+            return out
+
+        def contra(rep, label_l, label_u, prob_l, prob_u, low_mask, high_mask, *a, **k):
+            d = capture[-1]
+            d.update(low_mask=low_mask.clone(), high_mask=high_mask.clone(),
+                     lbits=np.concatenate([_pack_classbits(label_l), _pack_classbits(label_u)]))
+            out = f_contra(rep, label_l, label_u, prob_l, prob_u, low_mask, high_mask, *a, **k)
+            d["bank_len"] = np.array([m[0].shape[0] for m in memobank])
+            return out
+        ts.compute_unsupervised_loss, ts.compute_contra_memobank_loss = unsup, contra
+    if threads:
+        torch.set_num_threads(threads)
+    np.random.seed(np_seed)
+    torch.manual_seed(torch_seed)
+    ctx = PD.patched_torch_dropout2d(masks) if masks is not None else contextlib.nullcontext()
+    with ctx:
+        for e in epochs_run:
+            k = epochs_run.index(e)
+            loader_l.items = [(a, b) for a, b, _ in data[k * steps:(k + 1) * steps]]
+            loader_u.items = [(c, None) for _, _, c in data[k * steps:(k + 1) * steps]]
+            ts.train(model, teacher, optimizer, lr_scheduler, sup_loss_fn, loader_l, loader_u, e, ts.SummaryWriter(),
+                     logging.getLogger("gen_golden"), memobank, queue_ptrlis, queue_size)
     # meters are updated per step in the order data_time, lr, sup, uns, con, batch_time
     nst = steps * len(epochs_run)
     per = len(rec) // nst
-    rec = np.array(rec).reshape(nst, per)
-    fx = dict(meters=rec, n_meters=np.int64(per), seeds=np.array([0, 77, 31, 41]), steps=np.int64(steps),
+    return dict(meters=np.array(rec).reshape(nst, per), per=per, model=raw_model, teacher=teacher, memobank=memobank,
+                queue_ptrlis=queue_ptrlis, sd=sd, masks=masks)
+
+
+def gen_train_steps(ns, voc=False):
+    """The reference's OWN train() (train_semi.py:234-594) for three optimizer steps on fixed inputs: tiny R50 at
+    65x65, batch 2+2, OHEM + aux, CutMix, contrastive bank; fake loaders, plain BN, dropout off.  Records the per-step
+    losses, the CutMix coin / RNG seeds and a few parameters afterwards: pins oracle/step_ref.CpuStepRef (the
+    composition of the individually pinned pieces) to the real loop."""
+    S, B, C, steps = 65, 2, 19, 3
+    epochs_run = [0]
+    if voc:
+        C, steps, epochs_run = 21, 2, [0, 1]
+    cfg = _train_cfg(voc, "resnet50", C, min_kept=2000, class_thr=0.05 if voc else 0.055)
+    gen = torch.Generator().manual_seed(77)
+    data = []
+    for _ in range(steps * len(epochs_run)):
+        il, iu = torch.randn(B, 3, S, S, generator=gen), torch.randn(B, 3, S, S, generator=gen)
+        data.append((il, block_labels(B, S, C, gen, ignore_rows=4), iu))
+    r = _run_reference_train(ns, cfg, data, steps, epochs_run, voc)
+    model, teacher, memobank, queue_ptrlis = r["model"], r["teacher"], r["memobank"], r["queue_ptrlis"]
+    fx = dict(meters=r["meters"], n_meters=np.int64(r["per"]), seeds=np.array([0, 77, 31, 41]), steps=np.int64(steps),
               epochs=np.array(epochs_run),
               bank_len=np.array([m[0].shape[0] for m in memobank]), bank_ptr=np.array([int(q[0]) for q in queue_ptrlis]))
     for k in ("encoder.conv1.0.weight", "decoder.classifier.8.weight", "decoder.representation.8.bias", "auxor.aux.4.bias",
@@ -563,6 +664,117 @@ def gen_train_steps(ns, voc=False):
     for i, (il, ll, iu) in enumerate(data):
         fx[f"il_{i}"], fx[f"ll_{i}"], fx[f"iu_{i}"] = il, ll.to(torch.uint8), iu
     save("train_steps_voc" if voc else "train_steps", **fx)
+
+
+WORLD2 = dict(S=65, B=2, C=19, steps=2, arch="resnet50", sharpen=4.0, data_seed=500)
+
+
+def _world2_worker(rank, port, ret):
+    """one rank of the reference's train() under a gloo world of 2 (DDP on CPU, plain per-rank BN): different data
+    per rank, identical seeds / weights -- pins the cross-rank conventions: contrastive value = cross-rank mean with
+    gradient local/world (Q5, train_semi.py:514-519), DDP gradient mean, meters = cross-rank SUMS (train_semi.py:551-561),
+    rank-major bank gather (utils.py:16-24)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    ns = ref_shim.load()
+    w = WORLD2
+    cfg = _train_cfg(False, w["arch"], w["C"], min_kept=2000, class_thr=0.3)
+    data = survey_step_inputs(w["data_seed"] + rank, w["B"], w["S"], w["C"], w["steps"])
+    cap = []
+    r = _run_reference_train(ns, cfg, data, w["steps"], [0], False, sharpen=w["sharpen"], capture=cap, ddp=True, threads=4)
+    out = dict(meters=r["meters"], bank_len=np.array([m[0].shape[0] for m in r["memobank"]]),
+               bank_sum=np.array([float(m[0].double().sum()) for m in r["memobank"]]))
+    for k in ("encoder.conv1.0.weight", "decoder.classifier.8.weight", "decoder.representation.8.bias", "auxor.aux.4.bias",
+              "encoder.layer3.2.bn2.weight"):
+        out["student__" + k] = dict(r["model"].named_parameters())[k].detach().numpy().copy()
+        out["teacher__" + k] = dict(r["teacher"].named_parameters())[k].detach().numpy().copy()
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def gen_train_world2():
+    import socket
+    import torch.multiprocessing as mp
+    sck = socket.socket()
+    sck.bind(("127.0.0.1", 0))
+    port = sck.getsockname()[1]
+    sck.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_world2_worker, args=(port, ret), nprocs=2, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert np.array_equal(r0["bank_len"], r1["bank_len"]) and np.array_equal(r0["bank_sum"], r1["bank_sum"])
+    fx = dict(meters_rank0=r0["meters"], meters_rank1=r1["meters"], bank_len=r0["bank_len"], bank_sum=r0["bank_sum"],
+              cfg=np.array([WORLD2["S"], WORLD2["B"], WORLD2["C"], WORLD2["steps"], WORLD2["data_seed"]]),
+              sharpen=np.float64(WORLD2["sharpen"]), seeds=np.array([0, 31, 41]))
+    for k, v in r0.items():
+        if k.startswith("student__") or k.startswith("teacher__"):
+            assert np.array_equal(v, r1[k]), k          # DDP keeps the replicas identical
+            fx[k] = v
+    save("train_world2", **fx)
+
+
+def survey_step_inputs(seed, B, S, C, n):
+    """SURVEY 8(d) synthetic step inputs, regenerated from the seed wherever they are needed (never stored: 28 MB per
+    step at 769^2): images N(0,1); labels randint(0,C) on an (S//16+1)^2 grid, nearest-up-sampled, first 8 rows 255.
+    tests/full_size.py holds the same function for the GPU box (kept identical by test_oracle_golden)."""
+    gen = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        il, iu = torch.randn(B, 3, S, S, generator=gen), torch.randn(B, 3, S, S, generator=gen)
+        gsz = S // 16 + 1
+        coarse = torch.randint(0, C, (B, gsz, gsz), generator=gen)
+        iy = (torch.arange(S) * gsz // S).clamp(max=gsz - 1)
+        ll = coarse[:, iy][:, :, iy].contiguous()
+        ll[:, :8] = 255
+        out.append((il, ll, iu))
+    return out
+
+
+FULL_SIZE = {   # tag: (voc, arch, S, B, C, steps, epochs_run, sharpen, dropout_seed, input seed)
+    # BASELINE configs[2]/[3]: Cityscapes, R101, 769^2, 2+2 per GPU, OHEM(0.7, 100000) + aux 0.4, CutMix, contrastive
+    "city769": (False, "resnet101", 769, 2, 19, 1, [0], 4.0, 1234, 2),
+    # BASELINE configs[1]: VOC, R101, 513^2, 4+4, plain CE, no aux, sup_only_epoch 1 -> one sup-only step + one semi step
+    "voc513": (True, "resnet101", 513, 4, 21, 1, [0, 1], 4.0, 1234, 2),
+    # cheap variants of the same two harness paths for the CPU suite (port <-> reference with dropout ON)
+    "city97": (False, "resnet50", 97, 2, 19, 2, [0], 4.0, 1234, 2),
+}
+
+
+def gen_train_full(ns, tag):
+    """BASELINE-size step-0 golden from the reference's OWN train(): default configuration values (class threshold
+    0.3, OHEM min_kept 100000), dropout ON with keyed keep-masks, classifier last layer x4 (as bench.py: random-init
+    logits are near-uniform otherwise).  Inputs are regenerated from the seed; the fixture stores the meters, the
+    packed reliability masks / targets and bank bookkeeping."""
+    voc, arch, S, B, C, steps, epochs_run, sharpen, dseed, iseed = FULL_SIZE[tag]
+    cfg = _train_cfg(voc, arch, C, min_kept=100000 if S > 200 else 4000, class_thr=0.3, epochs=200 if S > 200 else 20)
+    data = survey_step_inputs(iseed, B, S, C, steps * len(epochs_run))
+    cap = []
+    import time
+    t0 = time.time()
+    r = _run_reference_train(ns, cfg, data, steps, epochs_run, voc, p_drop=0.1, dropout_seed=dseed, sharpen=sharpen,
+                             capture=cap)
+    print(tag, "reference train():", round(time.time() - t0, 1), "s; meters", r["meters"][:, 1:5])
+    fx = dict(meters=r["meters"], seeds=np.array([0, iseed, 31, 41, dseed]), steps=np.int64(steps), epochs=np.array(epochs_run),
+              sharpen=np.float64(sharpen), geom=np.array([S, B, C]),
+              bank_len=np.array([m[0].shape[0] for m in r["memobank"]]),
+              bank_ptr=np.array([int(q[0]) for q in r["queue_ptrlis"]]),
+              dropout_log=np.array([f"{t}|{k}|{n}|{c}|{s}" for t, k, n, c, s in r["masks"].log]))
+    for i, d in enumerate(cap):
+        lab, tgt = d["label_u_aug"].numpy(), d["target_u"].numpy()
+        fx[f"s{i}_label_u"] = lab.astype(np.uint8)
+        fx[f"s{i}_dropped"] = np.packbits((tgt == 255) & (lab != 255))
+        fx[f"s{i}_percent"] = np.float64(d["percent"])
+        if "low_mask" in d:
+            fx[f"s{i}_low"] = np.packbits(d["low_mask"].numpy() != 0)
+            fx[f"s{i}_high"] = np.packbits(d["high_mask"].numpy() != 0)
+            fx[f"s{i}_lbits"] = d["lbits"]
+            fx[f"s{i}_bank_len"] = d["bank_len"]
+    for k in ("encoder.conv1.0.weight", "decoder.classifier.8.weight", "decoder.representation.8.bias",
+              "encoder.layer3.2.bn2.weight"):
+        fx["student__" + k] = dict(r["model"].named_parameters())[k].detach().clone()
+    save("train_full_" + tag, **fx)
 
 
 def gen_resample(ns):
@@ -637,8 +849,11 @@ def gen_eval_window(ns, tag, H, W, crop, seed):
 
 
 def main():
-    ns = ref_shim.load()
     which = set(sys.argv[1:])
+    if "world2" in which:       # two gloo ranks: each worker installs the shim inside ITS process group
+        gen_train_world2()
+        return
+    ns = ref_shim.load()
 
     def want(k):
         return not which or k in which
@@ -662,6 +877,8 @@ def main():
         gen_bank_seq(ns, 51)
     if want("cutmix"):
         gen_cutmix(ns, 61, 2, 65)
+    if want("strongaug"):
+        gen_strong_aug(ns, 62, 3, 65)
     if want("pseudo"):
         gen_pseudo(71, 65, 17, 19)
     if want("sgd"):
@@ -670,6 +887,9 @@ def main():
         gen_train_steps(ns)
     if want("trainsteps_voc"):
         gen_train_steps(ns, voc=True)
+    for tag in FULL_SIZE:
+        if ("full_" + tag) in which or "full" in which:     # minutes of CPU each: only on request
+            gen_train_full(ns, tag)
     if want("resample"):
         gen_resample(ns)
     if want("augment"):

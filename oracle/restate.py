@@ -424,6 +424,38 @@ def cutmix_apply(data, target, logits, boxes):
     return nd, nt, nl
 
 
+def cutout_apply(data, target, logits, boxes):
+    """generate_unsup_data(mode="cutout") (augmentation.py:506-513): inside box_i the image and the confidence
+    are MULTIPLIED by 0 (so -x -> -0.0, like the reference) and the label becomes 255."""
+    nd, nt, nl = data.copy(), target.copy(), logits.copy()
+    for i, (y0, y1, x0, x1) in enumerate(boxes):
+        nd[i, :, y0:y1, x0:x1] = data[i, :, y0:y1, x0:x1] * f32(0)
+        nl[i, y0:y1, x0:x1] = logits[i, y0:y1, x0:x1] * f32(0)
+        nt[i, y0:y1, x0:x1] = 255
+    return nd, nt, nl
+
+
+def classmix_select(target_i, randperm):
+    """generate_class_mask (augmentation.py:487-495): sorted unique labels, a random half (first len//2 of a
+    permutation drawn by `randperm(n)` -- torch.randperm on the global CPU generator upstream)."""
+    labels = np.unique(target_i)
+    return labels[np.asarray(randperm(len(labels)))][: len(labels) // 2]
+
+
+def classmix_apply(data, target, logits, selected):
+    """generate_unsup_data(mode="classmix") (augmentation.py:517-535): m = [target_i in selected_i];
+    out = x_i * m + x_{(i+1)%B} * (1 - m) in float32 (labels go through float and back to int64)."""
+    B = data.shape[0]
+    nd, nt, nl = np.empty_like(data), np.empty_like(target), np.empty_like(logits)
+    for i in range(B):
+        j = (i + 1) % B
+        m = np.isin(target[i], selected[i]).astype(np.float32)
+        nd[i] = data[i] * m + data[j] * (f32(1) - m)
+        nt[i] = (target[i].astype(np.float32) * m + target[j].astype(np.float32) * (f32(1) - m)).astype(np.int64)
+        nl[i] = logits[i] * m + logits[j] * (f32(1) - m)
+    return nd, nt, nl
+
+
 # ----------------------------------------------------------------------------
 # a18/a19  SGD (torch.optim.SGD semantics), poly LR, EMA
 #          (lr_helper.py:12-27,78-113; train_semi.py:531-548)

@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 from . import restate as R
 from .model_ref import RefNet
+from .parity_dropout import patched_torch_dropout2d, tag_model
 
 CONTRA = dict(negative_high_entropy=True, low_rank=3, high_rank=20, current_class_threshold=0.3,
               current_class_negative_threshold=1, low_entropy_threshold=20, num_negatives=50, num_queries=256,
@@ -32,9 +33,14 @@ class CpuStepRef:
     def __init__(self, arch="resnet101", num_classes=19, aux=True, epochs=200, steps_per_epoch=163, lr=0.01,
                  momentum=0.9, weight_decay=0.0005, ema_decay=0.99, sup_only_epoch=0, drop_percent=80,
                  ohem=(0.7, 100000), contra=CONTRA, p_drop=0.0, lr_times=1, queue=(50000, 30000), state_dict=None,
-                 apply_aug="cutmix"):
+                 apply_aug="cutmix", dropout_masks=None):
         self.student = RefNet(arch, num_classes, aux, p_drop)
         self.teacher = RefNet(arch, num_classes, aux, p_drop)
+        # parity mode with dropout ON: both sides take their keep-masks from oracle/parity_dropout.KeyedMasks
+        self.dropout_masks = dropout_masks
+        if dropout_masks is not None:
+            tag_model(self.student, "student")
+            tag_model(self.teacher, "teacher")
         if state_dict is not None:
             self.student.load_state_dict(state_dict)
             self.teacher.load_state_dict(state_dict)
@@ -102,6 +108,12 @@ class CpuStepRef:
 
     # ---- the step -----------------------------------------------------------------------
     def step(self, image_l, label_l, image_u, epoch, cutmix_boxes="draw", randint=None):
+        if self.dropout_masks is not None:
+            with patched_torch_dropout2d(self.dropout_masks):
+                return self._step(image_l, label_l, image_u, epoch, cutmix_boxes, randint)
+        return self._step(image_l, label_l, image_u, epoch, cutmix_boxes, randint)
+
+    def _step(self, image_l, label_l, image_u, epoch, cutmix_boxes="draw", randint=None):
         if randint is None:
             def randint(high, n):
                 return torch.randint(high, size=(n,)).numpy()

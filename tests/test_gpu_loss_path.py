@@ -328,3 +328,79 @@ def test_full_size_reliability_properties():
     lb = lbits.cpu().numpy()
     assert (lb[1] == 0).all() and (lb[3] == 0).all() and (lb[2] != 0).all()
     assert (lb[0][8 // 4 + 1:] != 0).all() and (lb[0][0] == 0).all()
+
+
+# ------------------------------------------------------------------ strong augmentations (a9)
+def test_cutmix_kernel_bitexact_vs_reference_golden():
+    """u2pl_cutmix_f32 against the reference's generate_unsup_data(mode="cutmix") output (augmentation.py:498-541)"""
+    from u2pl_amd import trainer as TR
+    g = golden("cutmix")
+    B, _, S, _ = g["data"].shape
+    np.random.seed(int(g["seed"]))
+    boxes = TR.generate_cutmix_boxes(B, S, S)            # the product's own host draws, reference call order
+    assert np.array_equal(np.array(boxes), g["boxes"])
+    oi, ol, oc = TR.cutmix(T(g["data"]), T(g["target"], torch.int64), T(g["logits"]), boxes)
+    assert np.array_equal(oi.cpu().numpy(), g["new_data"]) and np.array_equal(ol.cpu().numpy(), g["new_target"])
+    assert np.array_equal(oc.cpu().numpy(), g["new_logits"])
+
+
+def test_cutout_and_classmix_kernels_bitexact_vs_reference_golden():
+    """u2pl_strong_aug_f32 (modes cutout / classmix) + u2pl_label_presence_i64 against generate_unsup_data
+    (augmentation.py:486-541), bit patterns included (x * 0 keeps the sign of x like the reference)."""
+    from u2pl_amd import trainer as TR
+    g = golden("strong_aug")
+    B, _, S, _ = g["data"].shape
+    data, tgt, conf = T(g["data"]), T(g["target"], torch.int64), T(g["logits"])
+    np.random.seed(int(g["seed"]))
+    boxes = TR.generate_cutmix_boxes(B, S, S)
+    assert np.array_equal(np.array(boxes), g["boxes"])
+    oi, ol, oc = TR.cutout(data, tgt, conf, boxes)
+    assert np.array_equal(oi.cpu().numpy().view(np.uint32), g["cutout_data"].view(np.uint32))
+    assert np.array_equal(ol.cpu().numpy(), g["cutout_target"])
+    assert np.array_equal(oc.cpu().numpy().view(np.uint32), g["cutout_logits"].view(np.uint32))
+    assert np.array_equal(tgt.cpu().numpy(), g["target"])          # the caller's tensor is not modified
+    torch.manual_seed(int(g["seed"]))
+    sel = TR.classmix_select(tgt)                                    # torch.randperm on the global CPU generator
+    for i in range(B):
+        want = g["classmix_selected"][i]
+        got = [c for c in range(64) if (int(sel[i]) >> c) & 1]
+        assert sorted(got) == sorted(int(c) for c in want[want >= 0]), i
+    oi, ol, oc = TR.classmix(data, tgt, conf, sel)
+    assert np.array_equal(oi.cpu().numpy(), g["classmix_data"]) and np.array_equal(ol.cpu().numpy(), g["classmix_target"])
+    assert np.array_equal(oc.cpu().numpy(), g["classmix_logits"])
+
+
+@pytest.mark.parametrize("aug", ["cutout", "classmix"])
+def test_train_step_runs_with_cutout_and_classmix(aug):
+    """the two modes through SemiTrainer.train_step: cutout creates label 255 -> NaN entropy / n_valid path, the
+    unsupervised weight B*H*W / #valid, masks exclude the cut-out pixels."""
+    from u2pl_amd import configs
+    from u2pl_amd.models.model_helper import ModelBuilder
+    from u2pl_amd.trainer import SemiTrainer
+    from u2pl_amd.utils.loss_helper import get_criterion
+
+    S, B = 65, 2
+    cfg = configs.cityscapes_semi(arch="resnet50", crop=S, batch_size=B, sync_bn=False, epochs=20)
+    cfg["criterion"]["kwargs"]["min_kept"] = 2000
+    cfg["trainer"]["unsupervised"]["apply_aug"] = aug
+    torch.manual_seed(3)
+    model, teacher = ModelBuilder(cfg["net"]).to(DEV), ModelBuilder(cfg["net"]).to(DEV)
+    tr = SemiTrainer(cfg, model, teacher, get_criterion(cfg), steps_per_epoch=4)
+    g = torch.Generator().manual_seed(9)
+    il, iu = torch.randn(B, 3, S, S, generator=g).to(DEV), torch.randn(B, 3, S, S, generator=g).to(DEV)
+    ll = torch.randint(0, 19, (B, S, S), generator=g).to(DEV)
+    np.random.seed(1)           # first uniform draw 0.417 < 0.5: the augmentation is applied
+    dbg = {}
+    m = tr.train_step(il, ll, iu, epoch=0, debug=dbg)
+    assert torch.isfinite(m).all(), m
+    lab, tgt, ent = dbg["label_u"].cpu().numpy(), dbg["target_u"].cpu().numpy(), dbg["entropy"].cpu().numpy()
+    if aug == "cutout":
+        cut = lab == 255
+        assert 0.3 < cut.mean() < 0.7                       # ~half of every image
+        assert np.isnan(ent[cut]).all() and not np.isnan(ent[~cut]).any()
+        assert (tgt[cut] == 255).all()
+        low = dbg["low_mask"].cpu().numpy()[B:]
+        sy = np.minimum(np.floor(np.arange(17) * np.float32(S / 17)), S - 1).astype(int)
+        assert (low[:, 0][cut[:, sy][:, :, sy]] == 0).all()
+    else:
+        assert (lab != 255).all() and not np.isnan(ent).any()

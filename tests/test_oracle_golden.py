@@ -342,3 +342,61 @@ def test_step_port_pinned_to_the_reference_train_loop_voc_config():
             src = sref if k.startswith("student__") else tref
             a, b = src[k[9:]].detach(), torch.from_numpy(g[k])
             assert (a - b).abs().max().item() <= 1e-6 + 2e-2 * (b - sd[k[9:]]).abs().max().item(), k
+
+
+def test_step_port_with_dropout_on_pinned_to_the_reference_train_loop():
+    """Dropout ON (p = 0.1 in the student and the train-mode teacher, decoder.py:79-136): the port fed with the keyed
+    keep-masks reproduces two steps of the reference's own train() run with the SAME masks (fixture train_full_city97,
+    default configuration values, classifier x4): losses, the reliability masks / dropped targets BIT-EXACT at step 0,
+    bank bookkeeping, which (layer, call) pairs drew a mask."""
+    import torch
+    from full_size import FULL, golden_step, port_for_full, survey_step_inputs
+
+    g = golden("train_full_city97")
+    voc, arch, S, B, C, steps, epochs_run = FULL["city97"]
+    ref, cfg, sd = port_for_full("city97", g)
+    data = survey_step_inputs(int(g["seeds"][1]), B, S, C, steps)
+    np.random.seed(int(g["seeds"][2]))
+    torch.manual_seed(int(g["seeds"][3]))
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    s = (S - 1) // 4 + 1
+    for i in range(steps):
+        o = ref.step(*data[i], epoch=0)
+        gs = golden_step(g, i, S, B, s)
+        tol = 2e-6 if i == 0 else 2e-3
+        for name, a, b in (("sup", o["sup"], g["meters"][i][2]), ("unsup", o["unsup"], g["meters"][i][3]),
+                           ("contra", o["contra"], g["meters"][i][4])):
+            assert abs(a - float(b)) <= tol * max(1.0, abs(float(b))), (i, name, a, float(b))
+        assert np.array_equal(o["label_u"], gs["label_u"]), i
+        if i == 0:
+            assert np.array_equal(o["new_target"], gs["target_u"])
+            assert np.array_equal(o["low_mask"] != 0, gs["low"]) and np.array_equal(o["high_mask"] != 0, gs["high"])
+            assert [b[0].shape[0] for b in ref.bank] == [int(x) for x in gs["bank_len"]]
+    # the same (layer, call, shape, #kept) sequence was drawn on both sides, up to the order of the passes
+    mine = sorted(f"{t}|{k}|{n}|{c}|{kept}" for t, k, n, c, kept in ref.dropout_masks.log)
+    theirs = sorted(str(x) for x in g["dropout_log"] if "teacher:auxor" not in str(x) or True)
+    assert mine == theirs
+    assert any(x.startswith("teacher:decoder.classifier.7|1|") for x in mine)   # teacher dropout is live in train mode
+
+
+def test_cutout_and_classmix():
+    """the two other strong augmentations (augmentation.py:486-541) against the reference's generate_unsup_data"""
+    import torch
+    g = golden("strong_aug")
+    B, _, S, _ = g["data"].shape
+    tgt = g["target"].astype(np.int64)
+    np.random.seed(int(g["seed"]))
+    boxes = [R.cutmix_box(S, S, np.random.randint) for _ in range(B)]
+    assert np.array_equal(np.array(boxes), g["boxes"])
+    nd, nt, nl = R.cutout_apply(g["data"], tgt, g["logits"], boxes)
+    assert np.array_equal(nd.view(np.uint32), g["cutout_data"].view(np.uint32))        # incl. the sign of x*0
+    assert np.array_equal(nt, g["cutout_target"]) and np.array_equal(nl.view(np.uint32), g["cutout_logits"].view(np.uint32))
+    assert (nt == 255).any()
+    torch.manual_seed(int(g["seed"]))
+    sel = [R.classmix_select(tgt[i], lambda n: torch.randperm(n).numpy()) for i in range(B)]
+    for i in range(B):
+        want = g["classmix_selected"][i]
+        assert np.array_equal(sel[i], want[want >= 0])
+    nd, nt, nl = R.classmix_apply(g["data"], tgt, g["logits"], sel)
+    assert np.array_equal(nd, g["classmix_data"]) and np.array_equal(nt, g["classmix_target"])
+    assert np.array_equal(nl, g["classmix_logits"])

@@ -607,6 +607,71 @@ U2PL_API int u2pl_cutmix_f32(const float* img, const long long* label, const flo
 }
 
 // ---------------------------------------------------------------------------
+// The other two strong augmentations of generate_unsup_data (augmentation.py:486-541), same arithmetic as the
+// reference (`a * m + b * (1 - m)` in fp32, so signed zeros / non-finite inputs behave identically):
+//   mode 1 "cutout":   m = 0 inside box_i, 1 outside;  img*m, conf*m, label = 255 inside (augmentation.py:506-513)
+//   mode 2 "classmix": m = [label_i(y,x) in selected_i];  out = x_i*m + x_{(i+1)%B}*(1-m)  (augmentation.py:517-535)
+// boxes: int32 [B][4] = y0,y1,x0,x1;  sel: uint64 [B], bit c = class c of image i selected (generate_class_mask)
+// ---------------------------------------------------------------------------
+__global__ void k_strong_aug(const float* __restrict__ img, const long long* __restrict__ lab, const float* __restrict__ conf,
+                             const int* __restrict__ boxes, const unsigned long long* __restrict__ sel, int mode, int B,
+                             int C, int H, int W, float* __restrict__ oimg, long long* __restrict__ olab,
+                             float* __restrict__ oconf) {
+    const long HW = (long)H * W, total = (long)B * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const long q = i % HW;
+        const long long l = lab[i];
+        if (mode == 1) {
+            const int yy = (int)(q / W), xx = (int)(q % W);
+            const int* bx = boxes + 4 * b;
+            const bool in = yy >= bx[0] && yy < bx[1] && xx >= bx[2] && xx < bx[3];
+            const float m = in ? 0.f : 1.f;
+            for (int c = 0; c < C; ++c) oimg[((long)b * C + c) * HW + q] = img[((long)b * C + c) * HW + q] * m;
+            olab[i] = in ? 255 : l;
+            oconf[i] = conf[i] * m;
+        } else {
+            const int nb = (b + 1) % B;
+            const float m = (l >= 0 && l < 64 && ((sel[b] >> l) & 1ull)) ? 1.f : 0.f, m1 = 1.f - m;
+            for (int c = 0; c < C; ++c)
+                oimg[((long)b * C + c) * HW + q] = img[((long)b * C + c) * HW + q] * m + img[((long)nb * C + c) * HW + q] * m1;
+            olab[i] = (long long)((float)l * m + (float)lab[(long)nb * HW + q] * m1);
+            oconf[i] = conf[i] * m + conf[(long)nb * HW + q] * m1;
+        }
+    }
+}
+U2PL_API int u2pl_strong_aug_f32(const float* img, const long long* label, const float* conf, const int* boxes_dev,
+                                 const unsigned long long* sel_dev, int mode, int B, int C, int H, int W, float* out_img,
+                                 long long* out_label, float* out_conf, hipStream_t stream) {
+    if (mode != 1 && mode != 2) return 1;
+    if ((mode == 1 && !boxes_dev) || (mode == 2 && !sel_dev)) return 1;
+    hipLaunchKernelGGL(k_strong_aug, dim3(grid_for((long)B * H * W, 256)), dim3(256), 0, stream, img, label, conf, boxes_dev,
+                       sel_dev, mode, B, C, H, W, out_img, out_label, out_conf);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+// torch.unique(pseudo_labels) of generate_class_mask (augmentation.py:488) as a presence bitmask per image:
+// bits[b] |= 1 << label for every pixel (labels outside [0,64) are ignored).  bits must be zeroed by the caller.
+__global__ void k_label_presence(const long long* __restrict__ lab, long HW, unsigned long long* __restrict__ bits) {
+    const int b = blockIdx.y;
+    unsigned long long acc = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) {
+        const long long l = lab[(long)b * HW + i];
+        if (l >= 0 && l < 64) acc |= 1ull << l;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc |= __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicOr(bits + b, acc);
+}
+U2PL_API int u2pl_label_presence_i64(const long long* label, int B, long HW, unsigned long long* bits, hipStream_t stream) {
+    long nb = (HW + 255) / 256;
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(k_label_presence, dim3((unsigned)nb, B), dim3(256), 0, stream, label, HW, bits);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // Sliding-window evaluation (reference eval.py:184-224, scale_crop_process): logits of one crop window are
 // added into the padded full-image accumulator, a per-pixel window count is kept, and the sum is divided by
 // the count at the end.  pred: [C][H][W] planar, count: [H][W], src: [C][hc][wc] planar (one window).

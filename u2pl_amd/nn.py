@@ -415,15 +415,25 @@ class SyncBatchNorm(BatchNorm2d):
         super().__init__(num_features, eps, momentum, sync=True)
 
 
-def dropout2d_scale(p, N, C, device, training):
+# Parity runs feed explicit keep-masks to every Dropout2d (hard part 10): a callable
+# hook(module, N, C) -> (N, C) float32 CPU tensor holding 0 or 1/(1-p), or None to let the layer draw.
+DROPOUT_HOOK = None
+
+
+def dropout2d_scale(mod, N, C, device):
     """nn.Dropout2d(p) keep-mask as a per-(n,c) scale (0 or 1/(1-p)); None in eval mode."""
-    if not training or p <= 0:
+    p = mod.p
+    if not mod.training or p <= 0:
         return None
+    if DROPOUT_HOOK is not None:
+        s = DROPOUT_HOOK(mod, N, C)
+        if s is not None:
+            return s.to(torch.float32).contiguous().pin_memory().to(device, non_blocking=True)
     keep = (torch.rand((N, C), device=device) >= p).to(torch.float32)
     return keep.mul_(1.0 / (1.0 - p))
 
 
-def run_seq(seq, x, drop_override=None):
+def run_seq(seq, x):
     """Execute an nn.Sequential of {Conv2d, BatchNorm2d, ReLU, Dropout2d} fusing
     BN + ReLU + Dropout2d into one kernel (indices/names unchanged)."""
     mods = list(seq)
@@ -440,10 +450,7 @@ def run_seq(seq, x, drop_override=None):
             if j < len(mods) and isinstance(mods[j], nn.ReLU):
                 relu, j = True, j + 1
             if j < len(mods) and isinstance(mods[j], nn.Dropout2d):
-                if drop_override is not None and id(mods[j]) in drop_override:
-                    drop = drop_override[id(mods[j])]
-                else:
-                    drop = dropout2d_scale(mods[j].p, x.shape[0], x.shape[1], x.device, mods[j].training)
+                drop = dropout2d_scale(mods[j], x.shape[0], m.num_features, x.device)
                 j += 1
             if pending_conv is not None:
                 x = conv_bn(pending_conv, m, x, relu=relu, drop=drop)

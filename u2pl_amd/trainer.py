@@ -55,6 +55,46 @@ def cutmix(image, label, conf, boxes):
     return oi, ol, oc
 
 
+def cutout(image, label, conf, boxes):
+    """generate_unsup_data(mode='cutout') (augmentation.py:506-513): zero the box in image / confidence, label 255
+    inside -- the only producer of ignored unlabeled pixels."""
+    B, C, Hh, Ww = image.shape
+    image = image.contiguous()
+    bx = H.h2d(torch.tensor(boxes, dtype=torch.int32), image.device)
+    oi, ol, oc = torch.empty_like(image), torch.empty_like(label), torch.empty_like(conf)
+    K.call("u2pl_strong_aug_f32", image, label, conf, bx, None, 1, B, C, Hh, Ww, oi, ol, oc)
+    return oi, ol, oc
+
+
+def classmix_select(label, randperm=None):
+    """generate_class_mask (augmentation.py:487-495) per image, in the reference's order: the sorted unique labels
+    come back from the device as one presence bitmask per image (the one host sync of this mode), the random half
+    is drawn with torch.randperm on the global CPU generator like upstream.  -> uint64 selection bitmasks (host)."""
+    B = label.shape[0]
+    bits = torch.zeros(B, dtype=torch.int64, device=label.device)
+    K.call("u2pl_label_presence_i64", label.contiguous(), B, label[0].numel(), bits)
+    present = bits.cpu().numpy().view(np.uint64)
+    if randperm is None:
+        randperm = torch.randperm
+    sel = np.zeros(B, dtype=np.uint64)
+    for i in range(B):
+        labels = np.array([c for c in range(64) if (int(present[i]) >> c) & 1], dtype=np.int64)
+        chosen = labels[randperm(len(labels)).numpy()][: len(labels) // 2]
+        for c in chosen:
+            sel[i] |= np.uint64(1) << np.uint64(c)
+    return sel
+
+
+def classmix(image, label, conf, sel):
+    """generate_unsup_data(mode='classmix') (augmentation.py:517-535) given the selection bitmasks."""
+    B, C, Hh, Ww = image.shape
+    image = image.contiguous()
+    sd = H.h2d(torch.from_numpy(sel.view(np.int64).copy()), image.device)
+    oi, ol, oc = torch.empty_like(image), torch.empty_like(label), torch.empty_like(conf)
+    K.call("u2pl_strong_aug_f32", image, label, conf, None, sd, 2, B, C, Hh, Ww, oi, ol, oc)
+    return oi, ol, oc
+
+
 class SemiTrainer:
     def __init__(self, cfg, model, model_teacher, sup_loss_fn, steps_per_epoch, memobank=None):
         self.cfg = cfg
@@ -157,12 +197,30 @@ class SemiTrainer:
             # strong augmentation (train_semi.py:326-337): host coin flip + host rectangle draws.  The IMAGE mix
             # needs only the boxes, so it is issued on the main stream right away; labels are mixed on the side.
             image_u_aug = image_u
-            if np.random.uniform(0, 1) < 0.5 and unsup_cfg.get("apply_aug", False):
-                assert unsup_cfg["apply_aug"] == "cutmix", "only cutmix is wired to a HIP kernel"
-                boxes = cutmix_boxes if cutmix_boxes is not None else generate_cutmix_boxes(B, h, w)
-                with torch.cuda.stream(side):
-                    image_u_aug, label_u_aug, conf_u = cutmix(image_u, label_u_aug, conf_u, boxes)
-                    image_all = torch.cat((image_l, image_u_aug))
+            aug = unsup_cfg.get("apply_aug", False)
+            mixed_on_main = None
+            if np.random.uniform(0, 1) < 0.5 and aug:
+                if aug not in ("cutmix", "cutout", "classmix"):
+                    raise ValueError(f"trainer.unsupervised.apply_aug: {aug!r} (cutout | cutmix | classmix)")
+                if aug == "classmix":
+                    # the mask depends on the pseudo labels: the student's input has to wait for the side stream
+                    with torch.cuda.stream(side):
+                        sel = classmix_select(label_u_aug)
+                        image_u_aug, label_u_aug, conf_u = classmix(image_u, label_u_aug, conf_u, sel)
+                        image_all = torch.cat((image_l, image_u_aug))
+                    main.wait_stream(side)
+                    if side is not main:
+                        image_u_aug.record_stream(main)
+                    mixed_on_main = image_u_aug
+                else:
+                    fn = cutmix if aug == "cutmix" else cutout
+                    boxes = cutmix_boxes if cutmix_boxes is not None else generate_cutmix_boxes(B, h, w)
+                    with torch.cuda.stream(side):
+                        image_u_aug, label_u_aug, conf_u = fn(image_u, label_u_aug, conf_u, boxes)
+                        image_all = torch.cat((image_l, image_u_aug))
+                    # the student's input is rebuilt on the main stream from the same boxes (no cross-stream wait)
+                    mixed_on_main = fn(image_u, label_u_aug.new_zeros(label_u_aug.shape), conf_u.new_zeros(conf_u.shape),
+                                       boxes)[0]
             else:
                 with torch.cuda.stream(side):
                     image_all = torch.cat((image_l, image_u_aug))
@@ -175,12 +233,7 @@ class SemiTrainer:
                 pt, ldp = K.as_rows(pred_all_t)
                 Cn = pred_all_t.shape[1]
                 K.call("u2pl_softmax_rows_f32", pt, ldp, prob_all_t, Cn, pt.shape[0] * pt.shape[2] * pt.shape[3], Cn)
-            # the student's input is rebuilt on the main stream from the same boxes (no cross-stream wait needed)
-            if image_u_aug is not image_u:
-                image_u_main, _, _ = cutmix(image_u, label_u_aug.new_zeros(label_u_aug.shape), conf_u.new_zeros(conf_u.shape), boxes)
-                image_all_s = torch.cat((image_l, image_u_main))
-            else:
-                image_all_s = torch.cat((image_l, image_u))
+            image_all_s = torch.cat((image_l, mixed_on_main if mixed_on_main is not None else image_u))
             # student forward (train_semi.py:339-358)
             outs = model(image_all_s)
             pred_all, rep_all = outs["pred"], outs["rep"]

@@ -344,6 +344,9 @@ def formula_state_dict(model, seed=1234):
     return out
 
 
+DROPOUT_SEED_MODEL = 2024
+
+
 def gen_model(ns, tag, arch, S, B, C, aux, seed=5):
     import copy
 
@@ -358,13 +361,14 @@ def gen_model(ns, tag, arch, S, B, C, aux, seed=5):
         net["aux_loss"] = dict(aux_plane=1024, loss_weight=0.4)
     model = ns.model_helper.ModelBuilder(copy.deepcopy(net))
     model.load_state_dict(formula_state_dict(model))
-    for m in model.modules():
-        if isinstance(m, torch.nn.Dropout2d):
-            m.p = 0.0  # CPU mt19937 vs device RNG cannot match: parity mode runs without dropout
+    # dropout ON (p = 0.1) with explicit keyed keep-masks (parity_dropout): CPU mt19937 vs device RNG cannot match
+    import parity_dropout as PD
+    PD.tag_model(model, "student")
     gen = torch.Generator().manual_seed(seed)
     x = torch.randn(B, 3, S, S, generator=gen)
     model.train()
-    out = model(x)
+    with PD.patched_torch_dropout2d(PD.KeyedMasks(DROPOUT_SEED_MODEL)):
+        out = model(x)
     gp = torch.randn(out["pred"].shape, generator=gen)
     gr = torch.randn(out["rep"].shape, generator=gen)
     loss = (out["pred"] * gp).sum() + (out["rep"] * gr).sum()
@@ -399,11 +403,10 @@ def gen_model(ns, tag, arch, S, B, C, aux, seed=5):
     # reference's OWN fp32 rounding error (|ref32 - ref64|) instead of an arbitrary tolerance
     m64 = ns.model_helper.ModelBuilder(copy.deepcopy(net))
     m64.load_state_dict(formula_state_dict(m64))
-    for m in m64.modules():
-        if isinstance(m, torch.nn.Dropout2d):
-            m.p = 0.0
+    PD.tag_model(m64, "student")
     m64 = m64.double().train()
-    o64 = m64(x.double())
+    with PD.patched_torch_dropout2d(PD.KeyedMasks(DROPOUT_SEED_MODEL)):
+        o64 = m64(x.double())
     l64 = (o64["pred"] * gp.double()).sum() + (o64["rep"] * gr.double()).sum()
     if aux:
         l64 = l64 + (o64["aux"] * ga.double()).sum()
@@ -419,6 +422,7 @@ def gen_model(ns, tag, arch, S, B, C, aux, seed=5):
     with torch.no_grad():
         oe64 = m64(x.double())
     fx.update(pred_eval64=oe64["pred"].float(), rep_eval64=oe64["rep"].float())
+    fx["dropout_seed"] = np.int64(DROPOUT_SEED_MODEL)
     save(f"model_{tag}", **fx)
 
 
@@ -666,7 +670,7 @@ def gen_train_steps(ns, voc=False):
     save("train_steps_voc" if voc else "train_steps", **fx)
 
 
-WORLD2 = dict(S=65, B=2, C=19, steps=2, arch="resnet50", sharpen=4.0, data_seed=500)
+WORLD2 = dict(S=65, B=2, C=19, steps=2, arch="resnet50", sharpen=4.0, data_seed=500, dropout_seed=4321)
 
 
 def _world2_worker(rank, port, ret):
@@ -682,7 +686,8 @@ def _world2_worker(rank, port, ret):
     cfg = _train_cfg(False, w["arch"], w["C"], min_kept=2000, class_thr=0.3)
     data = survey_step_inputs(w["data_seed"] + rank, w["B"], w["S"], w["C"], w["steps"])
     cap = []
-    r = _run_reference_train(ns, cfg, data, w["steps"], [0], False, sharpen=w["sharpen"], capture=cap, ddp=True, threads=4)
+    r = _run_reference_train(ns, cfg, data, w["steps"], [0], False, sharpen=w["sharpen"], capture=cap, ddp=True, threads=4,
+                             p_drop=0.1, dropout_seed=w["dropout_seed"])
     out = dict(meters=r["meters"], bank_len=np.array([m[0].shape[0] for m in r["memobank"]]),
                bank_sum=np.array([float(m[0].double().sum()) for m in r["memobank"]]))
     for k in ("encoder.conv1.0.weight", "decoder.classifier.8.weight", "decoder.representation.8.bias", "auxor.aux.4.bias",
@@ -707,7 +712,7 @@ def gen_train_world2():
     assert np.array_equal(r0["bank_len"], r1["bank_len"]) and np.array_equal(r0["bank_sum"], r1["bank_sum"])
     fx = dict(meters_rank0=r0["meters"], meters_rank1=r1["meters"], bank_len=r0["bank_len"], bank_sum=r0["bank_sum"],
               cfg=np.array([WORLD2["S"], WORLD2["B"], WORLD2["C"], WORLD2["steps"], WORLD2["data_seed"]]),
-              sharpen=np.float64(WORLD2["sharpen"]), seeds=np.array([0, 31, 41]))
+              sharpen=np.float64(WORLD2["sharpen"]), seeds=np.array([0, 31, 41, WORLD2["dropout_seed"]]))
     for k, v in r0.items():
         if k.startswith("student__") or k.startswith("teacher__"):
             assert np.array_equal(v, r1[k]), k          # DDP keeps the replicas identical

@@ -284,7 +284,7 @@ def _as_accurate(mine, ref32, ref64, what, slack=4.0, floor=1e-6, outlier_frac=0
 @pytest.mark.parametrize("tag,arch,S,C,aux", [("r50_65", "resnet50", 65, 19, True), ("r101_33", "resnet101", 33, 21, False)])
 def test_model_builder_vs_reference_golden(tag, arch, S, C, aux, conv_algo):
     """Whole ModelBuilder (train-mode fwd, bwd, buffers, eval fwd) vs the reference model
-    (formula weights, dropout disabled on both sides).  Tolerance = the reference's own fp32
+    (formula weights, dropout ON with the keyed keep-masks the golden was written with).  Tolerance = the reference's own fp32
     error against its float64 twin, x4 -- for the direct kernel AND with every 3x3 layer forced onto Winograd
     F(2x2).  The F(4x4) run is a stress case: EVERY stride-1 3x3 layer (also the dilations the production
     policy keeps direct) on 9x9 / 5x5 maps of this deliberately ill-conditioned formula-weight network; its
@@ -296,13 +296,18 @@ def test_model_builder_vs_reference_golden(tag, arch, S, C, aux, conv_algo):
     g = golden("model_" + tag)
     model = ModelBuilder(net_cfg(arch, C, aux))
     model.load_state_dict(formula_state_dict(model))
+    from oracle.parity_dropout import KeyedMasks, tag_model
+    from u2pl_amd import nn as Kn
+    tag_model(model, "student")
+    assert all(m.p == 0.1 for m in model.modules() if isinstance(m, nn.Dropout2d))
     model = model.to(DEV)
-    for m in model.modules():
-        if isinstance(m, nn.Dropout2d):
-            m.p = 0.0
     model.train()
     x = torch.from_numpy(g["x"]).to(DEV)
-    out = model(x)
+    Kn.DROPOUT_HOOK = KeyedMasks(int(g["dropout_seed"])).hook
+    try:
+        out = model(x)
+    finally:
+        Kn.DROPOUT_HOOK = None
     report = {}
     fails = []
 

@@ -146,9 +146,12 @@ def _world2_reference_case(rank, world):
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     teacher = ModelBuilder(cfg["net"])
     teacher.load_state_dict(sd)
-    for m in list(model.modules()) + list(teacher.modules()):
-        if isinstance(m, nn.Dropout2d):
-            m.p = 0.0                       # the world-2 golden was written with dropout off
+    # dropout ON: both ranks take the keyed keep-masks the golden was written with
+    from oracle.parity_dropout import KeyedMasks, tag_model
+    from u2pl_amd import nn as Kn
+    tag_model(model, "student"), tag_model(teacher, "teacher")
+    Kn.DROPOUT_HOOK = KeyedMasks(int(g["seeds"][3])).hook
+    assert all(m.p == 0.1 for m in model.modules() if isinstance(m, nn.Dropout2d))
     dev = torch.device("cuda", 0)
     model, teacher = model.to(dev), teacher.to(dev)
     tr = SemiTrainer(cfg, model, teacher, get_criterion(cfg), steps_per_epoch=steps)

@@ -2,7 +2,7 @@
 semi-supervised training must be within +-0.3 points of the CPU reference (here: the CPU port of the
 reference step, oracle/step_ref.py) on a deterministic synthetic Cityscapes-layout dataset; both sides
 start from the same initial weights and see the same batches, CutMix boxes and sampling indices
-(dropout disabled: device and CPU RNG streams cannot match)."""
+(dropout ON, p = 0.1: both sides take the keyed keep-masks of oracle/parity_dropout)."""
 import copy
 import os
 import sys
@@ -41,20 +41,24 @@ def test_miou_after_one_epoch_matches_cpu_reference(tmp_path):
     model, teacher = ModelBuilder(copy.deepcopy(cfg["net"])), ModelBuilder(copy.deepcopy(cfg["net"]))
     sd = {k: v.detach().clone().contiguous() for k, v in model.state_dict().items()}
     teacher.load_state_dict(sd)
+    from oracle.parity_dropout import KeyedMasks, tag_model
+    from u2pl_amd import nn as Kn
+    tag_model(model, "student"), tag_model(teacher, "teacher")
+    assert all(m.p == 0.1 for m in model.modules() if isinstance(m, nn.Dropout2d))
     model, teacher = model.to(DEV), teacher.to(DEV)
-    for m in list(model.modules()) + list(teacher.modules()):
-        if isinstance(m, nn.Dropout2d):
-            m.p = 0.0
+    Kn.DROPOUT_HOOK = KeyedMasks(77).hook
     tr = SemiTrainer(cfg, model, teacher, get_criterion(cfg), steps_per_epoch=len(batches))
     ref = CpuStepRef(arch="resnet50", num_classes=19, aux=True, epochs=1, steps_per_epoch=len(batches),
-                     ohem=(0.7, cfg["criterion"]["kwargs"]["min_kept"]), p_drop=0.0,
-                     contra=copy.deepcopy(cfg["trainer"]["contrastive"]), state_dict={k: v.clone() for k, v in sd.items()})
+                     ohem=(0.7, cfg["criterion"]["kwargs"]["min_kept"]), p_drop=0.1,
+                     contra=copy.deepcopy(cfg["trainer"]["contrastive"]), state_dict={k: v.clone() for k, v in sd.items()},
+                     dropout_masks=KeyedMasks(77))
     for step, ((il, ll), (iu, _)) in enumerate(batches):
         g1, g2 = torch.Generator().manual_seed(90 + step), torch.Generator().manual_seed(90 + step)
         np.random.seed(40 + step)
         ref.step(il, ll, iu, 0, randint=lambda hi, n, g=g1: torch.randint(hi, size=(n,), generator=g).numpy())
         np.random.seed(40 + step)
         tr.train_step(il.to(DEV), ll.to(DEV), iu.to(DEV), 0, randint=lambda hi, n, g=g2: torch.randint(hi, size=(n,), generator=g))
+    Kn.DROPOUT_HOOK = None
     miou_ref, iou_ref = validate_ref(ref.teacher, val_batches, 19)
     miou_gpu, iou_gpu = validate(teacher, val_batches, cfg, torch.device(DEV))
     print("mIoU cpu-reference %.4f  hip %.4f" % (miou_ref * 100, miou_gpu * 100))

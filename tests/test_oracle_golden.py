@@ -199,11 +199,15 @@ def test_model_ref_pinned_to_reference_golden(tag, arch, C, aux):
     from model_utils import formula_state_dict
     from oracle.model_ref import RefNet
 
+    from oracle.parity_dropout import KeyedMasks, patched_torch_dropout2d, tag_model
+
     g = golden("model_" + tag)
-    net = RefNet(arch, C, aux, p_drop=0.0)
+    net = RefNet(arch, C, aux, p_drop=0.1)         # dropout ON: the golden's keyed keep-masks
     net.load_state_dict(formula_state_dict(net))   # strict: key sets must match the reference's
+    tag_model(net, "student")
     net.train()
-    out = net(torch.from_numpy(g["x"]))
+    with patched_torch_dropout2d(KeyedMasks(int(g["dropout_seed"]))):
+        out = net(torch.from_numpy(g["x"]))
     assert torch.equal(out["pred"], torch.from_numpy(g["pred"]))
     assert torch.equal(out["rep"], torch.from_numpy(g["rep"]))
     loss = (out["pred"] * torch.from_numpy(g["gp"])).sum() + (out["rep"] * torch.from_numpy(g["gr"])).sum()

@@ -234,6 +234,10 @@ int u2pl_ema_update_f32(float* t, const float* s, long n, float decay, float one
 int u2pl_cutmix_f32(const float* img, const long long* label, const float* conf, const int* boxes_dev, int B, int C,
                     int H, int W, float* out_img, long long* out_label, float* out_conf, hipStream_t stream);
 
+/* nn.Conv2d(kernel_size=1) on a 1x1 map (ASPP image-pooling branch, base.py:24-28): y[m][o] = x[m][:] . w[o][:] + bias[o]
+   for M <= 16 rows, accumulated in float64 (the 2-sample BatchNorm behind it amplifies y's relative error ~50x) */
+int u2pl_dense_small_f32(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, int M, int K,
+                         int Cout, hipStream_t stream);
 /* generate_unsup_data(mode="cutout" -> mode 1, boxes) / (mode="classmix" -> mode 2, sel): augmentation.py:486-541.
    sel_dev: uint64 [B], bit c set = class c of image i is in generate_class_mask's selected half */
 int u2pl_strong_aug_f32(const float* img, const long long* label, const float* conf, const int* boxes_dev,

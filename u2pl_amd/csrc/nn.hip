@@ -152,8 +152,29 @@ U2PL_API int u2pl_colreduce_finish_f32(const float* partial, int nblk, int C, do
 
 // nn.SyncBatchNorm / nn.BatchNorm2d training statistics (base.py:6-8): local
 // shifted sums  S1 = sum(x - pivot), S2 = sum((x - pivot)^2)  -> out double [2][C]
+// Few rows (M <= 64: the BatchNorm behind the ASPP image-pooling branch normalises over the N pooled vectors, which
+// differ by ~1 %): S2 - S1^2/M cancels ~1e4..1e5 : 1 there, so fp32 squares would leave only 2-3 correct digits of
+// the variance.  Two passes in float64 (mean, then centred squares), re-expressed in the shifted-sum protocol.
+__global__ void k_bn_stats_small(const float* __restrict__ x, long ld, int M, int C, const float* __restrict__ pivot,
+                                 double* __restrict__ sums) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int m = 0; m < M; ++m) s += (double)x[m * ld + c];
+    const double mean = s / M;
+    double q = 0.0;
+    for (int m = 0; m < M; ++m) { const double d = (double)x[m * ld + c] - mean; q += d * d; }
+    const double dm = mean - (pivot ? (double)pivot[c] : 0.0);
+    sums[c] = M * dm;
+    sums[C + c] = q + M * dm * dm;
+}
 U2PL_API int u2pl_bn_stats_f32(const float* x, long ld, long M, int C, const float* pivot, void* workspace,
                                double* sums, hipStream_t stream) {
+    if (M <= 64) {
+        hipLaunchKernelGGL(k_bn_stats_small, dim3(cdiv(C, 64)), dim3(64), 0, stream, x, ld, (int)M, C, pivot, sums);
+        U2PL_LAUNCH_CHECK();
+        return 0;
+    }
     StatOp op = {x, ld, pivot};
     return run_colreduce(op, M, 1, C, workspace, sums, stream);
 }
@@ -572,6 +593,48 @@ U2PL_API int u2pl_ema_update_f32(float* t, const float* s, long n, float decay, 
                                  hipStream_t stream) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_ema, dim3(grid_for(n, 256)), dim3(256), 0, stream, t, s, n, decay, one_minus_decay);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// 1x1 convolution on a 1x1 map = dense layer on M <= 16 rows (ASPP image-pooling branch, base.py:24-28): the rows
+// are the global averages of the batch, which differ from each other by ~1 %, and the BatchNorm that follows
+// normalises over just those M values, i.e. it amplifies the relative error of y by |y| / |y_m - y_m'| ~ 50x.
+// The products are therefore accumulated in float64 (one wave per output channel, lanes stride K): y is the
+// correctly rounded dot product, at a cost of M * K * Cout = 2 MFLOP.
+// ---------------------------------------------------------------------------
+#define DENSE_MAXM 16
+__global__ __launch_bounds__(256) void k_dense_small(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ y, long ldy,
+                                                     int M, int K, int Cout) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (o >= Cout) return;
+    double acc[DENSE_MAXM];
+#pragma unroll
+    for (int m = 0; m < DENSE_MAXM; ++m) acc[m] = 0.0;
+    const float* wr = w + (long)o * K;
+    for (int k = lane * 4; k < K; k += 256) {
+        const float4 wv = *(const float4*)(wr + k);
+#pragma unroll
+        for (int m = 0; m < DENSE_MAXM; ++m)
+            if (m < M) {
+                const float4 xv = *(const float4*)(x + m * ldx + k);
+                acc[m] += (double)xv.x * (double)wv.x + (double)xv.y * (double)wv.y + (double)xv.z * (double)wv.z +
+                          (double)xv.w * (double)wv.w;
+            }
+    }
+#pragma unroll
+    for (int m = 0; m < DENSE_MAXM; ++m)
+        if (m < M) {
+            const double t = wave_sum_d(acc[m]);
+            if (lane == 0) y[m * ldy + o] = (float)(t + (bias ? (double)bias[o] : 0.0));
+        }
+}
+U2PL_API int u2pl_dense_small_f32(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, int M,
+                                  int K, int Cout, hipStream_t stream) {
+    if (M < 1 || M > DENSE_MAXM || K % 4) return U2PL_EINVAL;
+    hipLaunchKernelGGL(k_dense_small, dim3(cdiv(Cout, 4)), dim3(256), 0, stream, x, ldx, w, bias, y, ldy, M, K, Cout);
     U2PL_LAUNCH_CHECK();
     return 0;
 }

@@ -142,7 +142,11 @@ class _ConvFn(torch.autograd.Function):
             raise HipError("conv weight must be stored channels_last ([Cout][R][S][Cin])")
         y = new_act(N, Cout, Ho, Wo, x.device)
         col = None
-        if Cin % 32:
+        if H * W == 1 and R == 1 and S == 1 and stride == 1 and pad == 0 and N <= 16 and Cin % 4 == 0:
+            # image-pooling branch of the ASPP: float64-accumulated dense layer (see csrc/nn.hip:k_dense_small)
+            call("u2pl_dense_small_f32", x, ldx, weight, bias, y, Cout, N, Cin, Cout)
+            pivot = None if pivot is None else False   # statistics by the stand-alone pass
+        elif Cin % 32:
             Kp = ((R * S * Cin + 31) // 32) * 32
             col = torch.empty((N * Ho * Wo, Kp), dtype=torch.float32, device=x.device)
             call("u2pl_im2col_f32", x, ldx, col, Kp, N, H, W, Cin, Ho, Wo, R, S, stride, pad, dil)
@@ -157,7 +161,7 @@ class _ConvFn(torch.autograd.Function):
             if pivot is not None:
                 sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=x.device)
                 call("u2pl_colreduce_finish_f32", part, part.shape[0], Cout, sums)
-        elif pivot is not None:
+        elif pivot is not None and pivot is not False:
             nblk = query("u2pl_conv2d_fwd_stat_blocks", N, Ho, Wo, Cout)
             part = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=x.device)
             call("u2pl_conv2d_fwd_bnstats_f32", x, ldx, weight, bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S, stride,
@@ -171,7 +175,7 @@ class _ConvFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.wsink, ctx.bsink = wsink, bsink
         if pivot is not None:
-            if Cin % 32:   # stem (im2col path): statistics by the stand-alone pass
+            if Cin % 32 or pivot is False:   # stem (im2col path) / pooled dense layer: statistics by the stand-alone pass
                 return y, None
             ctx.mark_non_differentiable(sums)
             return y, sums

@@ -230,6 +230,20 @@ int u2pl_softmax_rows_f32(const float* x, long ldx, float* y, long ldy, long M, 
 int u2pl_sgd_step_f32(float* p, const float* g, float* buf, long n, long b1, long b2, float lr0, float lr1, float lr2,
                       float momentum, float weight_decay, int first, float grad_scale, hipStream_t stream);
 int u2pl_ema_update_f32(float* t, const float* s, long n, float decay, float one_minus_decay, hipStream_t stream);
+/* The whole reliability split in ONE persistent launch (csrc/relfused.hip): bilinear up-sampling + entropy of the
+ * train-mode teacher logits (train_semi.py:371-374,402), exact np.percentile thresholds (loss_helper.py:38-40,
+ * train_semi.py:405-415), unsup target overwrite (loss_helper.py:41-43), low / high masks + nearest down-sampling +
+ * label_onehot class bits (train_semi.py:408-465, utils.py:50-59).  nspec = 1 (target only) or 3; q32_host = HOST
+ * array of percentiles/100 in float32.  workspace (u2pl_reliability_fused_workspace_bytes(G) bytes) is zeroed ONCE and
+ * reused; epoch = number of earlier launches on it (barrier counters grow monotonically, totals alternate by parity);
+ * thresholds are left in workspace words 16..18 (float bits), #kept in word 2.  G = power of two <= #CUs, <= 256.
+ * Returns 1001 when the shape is not covered (fall back to entropy_up + select + reliability_apply). */
+size_t u2pl_reliability_fused_workspace_bytes(int G);
+int u2pl_reliability_fused(const float* logits_low, long sn, long sc, long sh, long sw, int B, int C, int h, int w,
+                           int H, int W, const long long* label_u, const long long* label_l, int ignore, int nspec,
+                           const float* q32_host, int negative_high_entropy, int hm, int wm, float* entropy,
+                           long long* target_u, float* low_mask, float* high_mask, unsigned* lbits,
+                           unsigned* workspace, float* cand, int G, unsigned epoch, hipStream_t stream);
 /* generate_unsup_data(mode="cutmix"): augmentation.py:498-541 */
 int u2pl_cutmix_f32(const float* img, const long long* label, const float* conf, const int* boxes_dev, int B, int C,
                     int H, int W, float* out_img, long long* out_label, float* out_conf, hipStream_t stream);

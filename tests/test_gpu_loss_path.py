@@ -404,3 +404,125 @@ def test_train_step_runs_with_cutout_and_classmix(aug):
         assert (low[:, 0][cut[:, sy][:, :, sy]] == 0).all()
     else:
         assert (lab != 255).all() and not np.isnan(ent).any()
+
+
+# ------------------------------------------------------------------ fused (persistent) reliability split
+def _split_equal(a, b, nspec):
+    """a: fused, b: five-launch path.  Entropies agree to rounding (the fused kernel shifts the logits by the cell's
+    corner maximum instead of the per-pixel maximum: same value mathematically, last bits differ), thresholds / masks
+    of BOTH are exact functions of their own entropies (checked by _self_consistent); label-only outputs are identical."""
+    ea, eb = a["entropy"], b["entropy"]
+    assert torch.equal(torch.isnan(ea), torch.isnan(eb))
+    assert float((torch.nan_to_num(ea) - torch.nan_to_num(eb)).abs().max()) <= 2e-6
+    assert float((a["thr"][:nspec] - b["thr"][:nspec]).abs().max()) <= 2e-6 or bool(torch.isnan(a["thr"][:nspec]).all())
+    assert float((a["target_u"] != b["target_u"]).float().mean()) <= 1e-4
+    if nspec == 3:
+        assert torch.equal(a["lbits"], b["lbits"])
+        B = a["low_mask"].shape[0] // 2
+        assert torch.equal(a["low_mask"][:B], b["low_mask"][:B]) and torch.equal(a["high_mask"][:B], b["high_mask"][:B])
+        assert float((a["low_mask"] != b["low_mask"]).float().mean()) <= 1e-4
+
+
+def _self_consistent(f, lab_u, pcts, out_hw, neg_high=True):
+    """every output of the split re-derived on the host from the kernel's OWN entropy map must match bit for bit:
+    np.percentile thresholds (scalar q: float32 lerp), target overwrite, low / high masks at the nearest-sampled pixels"""
+    ent = f["entropy"].cpu().numpy()
+    lab = lab_u.cpu().numpy()
+    valid = lab != 255
+    assert np.array_equal(np.isnan(ent), ~valid)
+    thr = f["thr"].cpu().numpy()[: len(pcts)]
+    if valid.any():
+        assert np.array_equal(thr, np.array([np.percentile(ent[valid], q) for q in pcts], np.float32)), thr
+    tgt = lab.copy()
+    with np.errstate(invalid="ignore"):
+        tgt[(ent >= thr[0]) & valid] = 255
+        assert np.array_equal(f["target_u"].cpu().numpy(), tgt)
+        if len(pcts) == 3:
+            B, S = lab.shape[0], lab.shape[1]
+            h, w = out_hw
+            # legacy nearest (Q8): src = min(floor(float32(dst) * float32(in / out)), in - 1), all in float32
+            iy = np.minimum(np.floor(np.arange(h, dtype=np.float32) * np.float32(S / h)).astype(np.int64), S - 1)
+            ix = np.minimum(np.floor(np.arange(w, dtype=np.float32) * np.float32(lab.shape[2] / w)).astype(np.int64), lab.shape[2] - 1)
+            es = ent[:, iy][:, :, ix]
+            low = (es <= thr[1]).astype(np.float32)
+            high = (es >= thr[2]).astype(np.float32) if neg_high else np.ones_like(low)
+            assert np.array_equal(f["low_mask"].cpu().numpy()[B:, 0], low)
+            assert np.array_equal(f["high_mask"].cpu().numpy()[B:, 0], high)
+    if "nkept" in f:
+        assert int(f["nkept"]) == int((tgt != 255).sum())
+
+
+@pytest.mark.parametrize("tag", ["65_a20", "97_a13", "65_cutout", "65_b3"])
+def test_fused_reliability_split_vs_reference_golden_and_unfused_path(tag):
+    """u2pl_reliability_fused (one persistent launch) on the reference-generated fixtures: thresholds, masks and class
+    bits vs train_semi.py:397-465 within Tier B (entropy recomputed from logits), and BIT-IDENTICAL to the five-launch
+    path (same arithmetic, different schedule), for NCHW and NHWC logits; the workspace is reused across launches."""
+    H = hip()
+    g = golden("relsplit_" + tag)
+    B = g["label_l"].shape[0]
+    C, s, S = g["low_t_train"].shape[1], g["low_t_train"].shape[-1], int(g["size"])
+    lab_u, lab_l = T(g["label_u_aug"], torch.int64), T(g["label_l"], torch.int64)
+    a = float(g["alpha_t"])
+    for rep, fmt in enumerate((torch.contiguous_format, torch.channels_last, torch.channels_last)):
+        low = T(g["low_t_train"]).contiguous(memory_format=fmt)
+        pcts = [80.0 + rep, a, 100 - a]
+        f = H.reliability_split(low[B:], (S, S), lab_l, lab_u, (s, s), pcts, fused=True)
+        assert "nkept" in f, "the fused kernel was not used"
+        u = H.reliability_split(low[B:], (S, S), lab_l, lab_u, (s, s), pcts, fused=False)
+        _split_equal(f, u, 3)
+        _self_consistent(f, lab_u, pcts, (s, s))
+        _self_consistent(u, lab_u, pcts, (s, s))
+        tn = f["thr"].cpu().numpy()
+        assert abs(tn[1] - g["low_thresh"]) <= 2e-6 and abs(tn[2] - g["high_thresh"]) <= 2e-6
+        assert (f["low_mask"].cpu().numpy().astype(np.uint8) != g["low_mask_all"]).sum() <= 1
+        assert (f["high_mask"].cpu().numpy().astype(np.uint8) != g["high_mask_all"]).sum() <= 1
+        oh = H.unpack_class_bits(f["lbits"], C).cpu().numpy()
+        assert np.array_equal(oh[:B].astype(np.uint8), g["label_l_small"]) and np.array_equal(oh[B:].astype(np.uint8), g["label_u_small"])
+    one = H.reliability_split(low[B:], (S, S), lab_l, lab_u, (s, s), [73.0], fused=True)
+    _split_equal(one, H.reliability_split(low[B:], (S, S), lab_l, lab_u, (s, s), [73.0], fused=False), 1)
+    _self_consistent(one, lab_u, [73.0], (s, s))
+
+
+@pytest.mark.parametrize("case", ["random", "confident", "constant", "ties", "cutout", "two_values", "voc513"])
+def test_fused_reliability_split_full_size_equals_unfused(case):
+    """BASELINE sizes (769^2, B=2, C=19; 513^2, B=4, C=21) and adversarial entropy distributions: near-zero entropies of
+    a confident model (log-linear bins), ALL pixels identical (one candidate list of 1.18 M values: the out-of-LDS
+    selection), heavy ties, cut-out (ignored) regions, an all-ignored image.  Every output bit-identical to the
+    un-fused path, thresholds equal to np.percentile of the device entropies."""
+    H = hip()
+    B, C, S = (4, 21, 513) if case == "voc513" else (2, 19, 769)
+    s = (S - 1) // 4 + 1
+    g = torch.Generator(device=DEV).manual_seed(len(case))
+    low = torch.randn(B, C, s, s, device=DEV, generator=g) * 3
+    lab_u = torch.randint(0, C, (B, S, S), device=DEV, generator=g)
+    lab_l = torch.randint(0, C, (B, S, S), device=DEV, generator=g)
+    lab_l[:, :8] = 255
+    if case == "confident":
+        low = low * 12                                      # arg-max probability ~1: entropies 1e-30 .. 1e-2
+    elif case == "constant":
+        low = torch.zeros_like(low) + torch.arange(C, device=DEV).view(1, C, 1, 1) * 0.1
+    elif case == "ties":
+        low = torch.round(low)                              # a few thousand distinct entropy values
+    elif case == "cutout":
+        lab_u[0, 100:500, 50:600] = 255
+        lab_u[1] = 255                                      # one image entirely ignored
+    elif case == "two_values":
+        low = torch.zeros_like(low)
+        low[:, 0, : s // 2] = 5.0
+    low = low.contiguous(memory_format=torch.channels_last)
+    pcts = [80.0, 20.0, 80.0] if case != "cutout" else [83.7, 11.0, 89.0]
+    f = H.reliability_split(low, (S, S), lab_l, lab_u, (s, s), pcts, fused=True)
+    assert "nkept" in f
+    torch.cuda.synchronize()
+    u = H.reliability_split(low, (S, S), lab_l, lab_u, (s, s), pcts, fused=False)
+    if case != "constant":       # (all-equal entropies: one rounding step moves every pixel across the threshold)
+        _split_equal(f, u, 3)
+    _self_consistent(f, lab_u, pcts, (s, s))
+    ws = H._rf_workspace(torch.device(DEV, 0), B * S * S)[1]
+    assert int(ws[3]) == 0          # no barrier time-out
+    # further launches on the same workspace (epoch counters, alternating totals) give the same answer bit for bit
+    for _ in range(3):
+        f2 = H.reliability_split(low, (S, S), lab_l, lab_u, (s, s), pcts, fused=True)
+        assert torch.equal(f2["entropy"].view(torch.int32), f["entropy"].view(torch.int32))
+        assert torch.equal(f2["target_u"], f["target_u"]) and torch.equal(f2["low_mask"], f["low_mask"])
+        assert torch.equal(f2["high_mask"], f["high_mask"]) and torch.equal(f2["lbits"], f["lbits"])

@@ -59,6 +59,8 @@ def main():
         return H.reliability_apply(ent, thr, label_l, label_u, (s, s))
 
     res["reliability_fused_total_us"] = timeit(rel_fused)
+    res["reliability_persistent_us"] = timeit(
+        lambda: H.reliability_split(low[B:], (S, S), label_l, label_u, (s, s), [80.0, 20.0, 80.0], fused=True), n=20)
     wsf = H.new_select_ws(DEV, B * S * S)
     res["entropy_up_us"] = timeit(lambda: H.entropy_map_up(low[B:], (S, S), label_u, wsf))
     ws = H.new_select_ws(DEV, B * S * S)

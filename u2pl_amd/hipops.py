@@ -156,6 +156,76 @@ def reliability_apply(entropy, thr3, label_l, label_u_aug, out_hw, negative_high
     return target, nk, low, high, lbits
 
 
+_RF_WS = {}
+
+
+def _rf_workspace(device, n_px):
+    """persistent (zeroed once, self re-arming) workspace + candidate scratch of the fused split, one per stream"""
+    import torch.cuda as tc
+    key = (str(device), tc.current_stream().cuda_stream)
+    ent = _RF_WS.get(key)
+    if ent is None or ent[2].numel() < n_px:
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
+        G = 256
+        while G > cus:
+            G //= 2
+        ws = torch.zeros(query("u2pl_reliability_fused_workspace_bytes", G) // 4, dtype=torch.int32, device=device)
+        cand = torch.empty(n_px, dtype=torch.float32, device=device)
+        ent = _RF_WS[key] = [G, ws, cand, 0]
+    return ent
+
+
+def reliability_split(logits_low, size, label_l, label_u_aug, out_hw, percents, negative_high_entropy=True, ignore=255,
+                      fused=None):
+    """train_semi.py:371-465 + loss_helper.py:35-44 for the unlabeled half: entropy of the bilinearly up-sampled
+    teacher logits, np.percentile thresholds at `percents` ([drop] or [drop, alpha_t, 100 - alpha_t]), unsup target,
+    low / high masks and class bits.  One persistent launch (csrc/relfused.hip) when the shape allows, otherwise
+    entropy_up + select + apply.  -> dict(entropy, thr (float32 view, valid until the next call), target_u,
+    low_mask, high_mask, lbits)."""
+    import os
+    B, C, h, w = logits_low.shape
+    H, W = int(size[0]), int(size[1])
+    hm, wm = int(out_hw[0]), int(out_hw[1])
+    dev = logits_low.device
+    nspec = len(percents)
+    if fused is None:
+        fused = os.environ.get("U2PL_NO_FUSED_SPLIT") is None
+    ok = (fused and C in (19, 21) and nspec in (1, 3) and h >= 2 and w >= 2 and H - 1 == 4 * (h - 1) and W - 1 == 4 * (w - 1)
+          and H <= 1024 and W <= 1024 and hm <= H and wm <= W and 0 <= ignore <= 255)
+    if ok:
+        slot = _rf_workspace(dev, B * H * W)
+        G, ws, cand = slot[0], slot[1], slot[2]
+        per = -(-(B * h * w) // G)
+        ok = G >= 128 and per // 256 + (1 if per % 256 > 64 else 0) <= 2
+    if not ok:
+        ws = new_select_ws(dev, B * H * W)
+        ent = entropy_map_up(logits_low, (H, W), label_u_aug, ws, ignore)
+        thr = run_select(ent, ws, [("pct", float(p)) for p in percents])
+        if nspec == 3:
+            target, _, low, high, lbits = reliability_apply(ent, thr, label_l, label_u_aug, (hm, wm),
+                                                            negative_high_entropy=negative_high_entropy, ignore=ignore)
+        else:
+            target = label_u_aug.clone()
+            drop_high_entropy_(target, ent, thr[0:1], ignore)
+            low = high = lbits = None
+        return dict(entropy=ent, thr=thr, target_u=target, low_mask=low, high_mask=high, lbits=lbits)
+    _chk_cuda(logits_low, label_l, label_u_aug)
+    q32 = np.array([percentile_q32(p) for p in percents], dtype=np.float32)
+    ent = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    target = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+    low = high = lbits = None
+    if nspec == 3:
+        low = torch.empty((2 * B, 1, hm, wm), dtype=torch.float32, device=dev)
+        high = torch.empty((2 * B, 1, hm, wm), dtype=torch.float32, device=dev)
+        lbits = torch.empty((2 * B, hm, wm), dtype=torch.int32, device=dev)
+    call("u2pl_reliability_fused", _f32c(logits_low), *_strides_nchw(logits_low), B, C, h, w, H, W, label_u_aug.contiguous(),
+         label_l.contiguous(), int(ignore), nspec, q32.ctypes.data, int(bool(negative_high_entropy)), hm, wm, ent, target,
+         low, high, lbits, ws, cand, G, slot[3] & 0x3FFFFFF)
+    slot[3] += 1
+    return dict(entropy=ent, thr=ws[16:16 + nspec].view(torch.float32), target_u=target, low_mask=low, high_mask=high,
+                lbits=lbits, nkept=ws[2:3])
+
+
 # --------------------------------------------------------------------------- cross entropy
 class _CrossEntropy(torch.autograd.Function):
     @staticmethod

@@ -257,23 +257,19 @@ class SemiTrainer:
                 percent_unreliable = (100 - drop_percent) * (1 - epoch / self.epochs)
                 drop_percent = 100 - percent_unreliable
                 ccfg = cfg["trainer"].get("contrastive", False)
-                specs = [("pct", float(drop_percent))]
+                percents = [float(drop_percent)]
                 if ccfg:
                     alpha_t = ccfg["low_entropy_threshold"] * (1 - epoch / self.epochs)
-                    specs += [("pct", float(alpha_t)), ("pct", float(100 - alpha_t))]
+                    percents += [float(alpha_t), float(100 - alpha_t)]
+                neg_high = bool(ccfg.get("negative_high_entropy", True)) if ccfg else True
                 if H.REPLAY is not None:
-                    H.REPLAY["rel"] = (pred_all_t[B:], (h, w), label_u_aug, label_l, tuple(pred_all.shape[2:]), specs,
-                                       bool(ccfg.get("negative_high_entropy", True)) if ccfg else None)
-                ws = H.new_select_ws(image_l.device, B * h * w)
-                ent = H.entropy_map_up(pred_all_t[B:], (h, w), label_u_aug, ws)
-                thr = H.run_select(ent, ws, specs)
-                if ccfg:
-                    target_u, _, low_mask, high_mask, lbits = H.reliability_apply(
-                        ent, thr, label_l, label_u_aug, pred_all.shape[2:],
-                        negative_high_entropy=ccfg.get("negative_high_entropy", True))
-                else:
-                    target_u = label_u_aug.clone()
-                    H.drop_high_entropy_(target_u, ent, thr[0:1])
+                    H.REPLAY["rel"] = (pred_all_t[B:], (h, w), label_l, label_u_aug, tuple(pred_all.shape[2:]), percents, neg_high)
+                # ONE persistent launch: fused bilinear up-sampling + entropy, exact selection of all three
+                # percentiles (drop_percent, alpha_t, 100 - alpha_t), target overwrite, masks, class bits
+                rs = H.reliability_split(pred_all_t[B:], (h, w), label_l, label_u_aug, tuple(pred_all.shape[2:]), percents,
+                                         negative_high_entropy=neg_high)
+                ent, thr, target_u = rs["entropy"], rs["thr"], rs["target_u"]
+                low_mask, high_mask, lbits = rs["low_mask"], rs["high_mask"], rs["lbits"]
             unsup_loss = H.cross_entropy(pred_u_large, target_u, 255, unsup_weight=True,
                                          scale=float(unsup_cfg.get("loss_weight", 1)))
             if ccfg:

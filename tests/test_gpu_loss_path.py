@@ -526,3 +526,53 @@ def test_fused_reliability_split_full_size_equals_unfused(case):
         assert torch.equal(f2["entropy"].view(torch.int32), f["entropy"].view(torch.int32))
         assert torch.equal(f2["target_u"], f["target_u"]) and torch.equal(f2["low_mask"], f["low_mask"])
         assert torch.equal(f2["high_mask"], f["high_mask"]) and torch.equal(f2["lbits"], f["lbits"])
+
+
+# ------------------------------------------------------------------ row-sparse ordered InfoNCE gradient
+@pytest.mark.parametrize("n_pix", [3000, 40, 2])
+def test_infonce_gradient_scatter_is_row_sparse_ordered_and_reproducible(n_pix):
+    """u2pl_scatter_rows_ordered_f32 + u2pl_zero_rows_f32 (the backward of the anchor gather, loss_helper.py:205-230):
+    rows of the persistent gradient buffer = scale * g * (sum of the entries that sampled the pixel, ASCENDING entry
+    order) -- bit-identical to a sequential host sum, bit-identical run to run, zero everywhere else, also when a pixel
+    is sampled hundreds of times (chains >= 64: the O(len^2) branch) and after the lazy re-zero of the previous call."""
+    from u2pl_amd._lib import call
+    P, D, n = 5000, 256, 19 * 256
+    g = torch.Generator().manual_seed(n_pix)
+    grad = torch.zeros((P, D), device=DEV)
+    head = torch.full((P,), -1, dtype=torch.int32, device=DEV)
+    gout = torch.tensor(0.37, device=DEV)
+    results = []
+    prev = None
+    for trial in range(3):
+        gsrc = torch.Generator().manual_seed(100 + (trial if trial < 2 else 0))       # trial 2 repeats trial 0's data
+        pix = torch.randint(0, n_pix, (n,), generator=gsrc).to(torch.int32) * (P // n_pix) + (0 if trial != 1 else 1)
+        src = torch.randn(n, D, generator=gsrc)
+        pd, sd = pix.to(DEV), src.to(DEV)
+        nxt = torch.empty(n, dtype=torch.int32, device=DEV)
+        # build the chains like k_infonce does (atomic exchange; order of arrival is arbitrary)
+        order = torch.randperm(n, generator=g)
+        hh = head.cpu().numpy().copy()
+        nn_ = np.zeros(n, np.int32)
+        for e in order.numpy():
+            nn_[e] = hh[pix[e]]
+            hh[pix[e]] = e
+        head.copy_(torch.from_numpy(hh))
+        nxt.copy_(torch.from_numpy(nn_))
+        if prev is not None:
+            call("u2pl_zero_rows_f32", grad, D, D, prev, prev.numel())
+        call("u2pl_scatter_rows_ordered_f32", grad, D, D, pd, nxt, head, sd, n, gout, 0.25)
+        prev = pd
+        torch.cuda.synchronize()
+        assert int((head != -1).sum()) == 0                         # chain heads re-armed
+        out = grad.cpu().numpy()
+        ref = np.zeros((P, D), np.float32)
+        acc = {}
+        for e in range(n):                                           # ascending entry order, float32 adds
+            p = int(pix[e])
+            acc[p] = src[e].numpy() if p not in acc else (acc[p] + src[e].numpy()).astype(np.float32)
+        sc = np.float32(np.float32(0.25) * np.float32(0.37))
+        for p, v in acc.items():
+            ref[p] = sc * v
+        assert np.array_equal(out, ref), trial
+        results.append(out.copy())
+    assert np.array_equal(results[0], results[2])                   # same data, different chain order: same bits

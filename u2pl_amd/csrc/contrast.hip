@@ -504,7 +504,8 @@ struct NceJob {
 template <int VPL>  // floats per lane = D / 64
 __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restrict__ rep, long ld, int D,
                           int Q, int K, float inv_temp, float* __restrict__ loss_q,
-                          float* __restrict__ ganchor, int* __restrict__ anchor_pix) {
+                          float* __restrict__ ganchor, int* __restrict__ anchor_pix, int* __restrict__ head,
+                          int* __restrict__ next) {
     const int job = blockIdx.y;
     const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -599,8 +600,13 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
     }
     const float lse = m + logf(s);
     if (lane == 0) {
-        loss_q[(long)job * Q + q] = lse - l0;
-        anchor_pix[(long)job * Q + q] = pix;
+        const int e = job * Q + q;
+        loss_q[e] = lse - l0;
+        anchor_pix[e] = pix;
+        // entries that sampled the same pixel (anchors are drawn with replacement; a pixel can also sit in several
+        // class lists) are chained through an integer exchange: the backward pass sums each chain in ascending
+        // entry order, so the gradient needs no floating-point atomics and is reproducible bit for bit
+        if (head) next[e] = atomicExch(head + pix, e);
     }
     // d loss/d cos_j = (softmax_j - [j==0]) * inv_temp ; d cos_j/d a = (fhat_j - cos_j*ahat)/|a|
     const float inv_s = 1.0f / s;
@@ -612,17 +618,17 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
 }
 
 U2PL_API int u2pl_infonce_f32(const void* jobs_dev, int njobs, const float* rep, long ld, int D, int Q, int K,
-                              float temp, float* loss_q, float* ganchor, int* anchor_pix,
+                              float temp, float* loss_q, float* ganchor, int* anchor_pix, int* head, int* next,
                               hipStream_t stream) {
     if (njobs <= 0) return 0;
     dim3 grid(cdiv(Q, 4), njobs), block(256);
     const NceJob* jobs = (const NceJob*)jobs_dev;
     float it = 1.0f / temp;
     switch (D) {
-        case 64: hipLaunchKernelGGL(k_infonce<1>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix); break;
-        case 128: hipLaunchKernelGGL(k_infonce<2>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix); break;
-        case 256: hipLaunchKernelGGL(k_infonce<4>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix); break;
-        case 512: hipLaunchKernelGGL(k_infonce<8>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix); break;
+        case 64: hipLaunchKernelGGL(k_infonce<1>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next); break;
+        case 128: hipLaunchKernelGGL(k_infonce<2>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next); break;
+        case 256: hipLaunchKernelGGL(k_infonce<4>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next); break;
+        case 512: hipLaunchKernelGGL(k_infonce<8>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next); break;
         default: return U2PL_EINVAL;
     }
     U2PL_LAUNCH_CHECK();
@@ -670,6 +676,83 @@ U2PL_API int u2pl_scatter_add_rows_f32(float* dst, long ld, int D, const int* pi
                                        const float* gout_dev, float scale, hipStream_t stream) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_scatter_add_rows, dim3(grid_for(n * D, 256)), dim3(256), 0, stream, dst, ld, D, pix, src, n, gout_dev, scale);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Row-sparse, ordered gradient of the anchors (replaces zero-filling the dense (P, D) gradient -- 152 MB at 769^2 --
+// and the float atomicAdd scatter): dst is a PERSISTENT all-zero buffer; the wave of the entry that heads a pixel's
+// chain (head[pix] == e) collects the chain (entries that sampled that pixel), sorts the entry ids ascending and
+// writes  dst[pix] = scale * gout * sum_{e ascending} src[e]  with a plain store; head[pix] is re-armed to -1.
+// The rows written here are cleared again by u2pl_zero_rows_f32 before the next backward pass reuses the buffer.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scatter_rows_ordered(float* __restrict__ dst, long ld, int D,
+                                                              const int* __restrict__ pix, const int* __restrict__ next,
+                                                              int* __restrict__ head, const float* __restrict__ src, int n,
+                                                              const float* __restrict__ gout, float scale) {
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= n) return;
+    const int p = pix[e];
+    if (head[p] != e) return;                      // not the chain head: the head's wave does the work
+    const float sc = scale * (gout ? *gout : 1.0f);
+    int myid = 0x7fffffff, cnt = 0;
+    for (int cur = e; cur >= 0; cur = next[cur]) {   // wave-uniform walk (chains are 1-3 entries long in practice)
+        if (lane == (cnt & 63)) myid = cur;
+        if (++cnt == 64) break;
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool act = lane * 4 < D;
+    if (cnt < 64) {
+        // rank of my id among the chain (ids are distinct) -> add the rows in ascending id order
+        int rank = 0;
+        for (int j = 0; j < cnt; ++j) rank += __shfl(myid, j, 64) < myid;
+        for (int r = 0; r < cnt; ++r) {
+            const unsigned long long m = __ballot(lane < cnt && rank == r);
+            const int id = __shfl(myid, __ffsll((long long)m) - 1, 64);
+            if (act) {
+                const float4 v = *(const float4*)(src + (long)id * D + lane * 4);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+    } else {
+        // a pixel sampled >= 64 times (tiny candidate lists): repeated minimum search over the chain, O(len^2) hops
+        int last = -1;
+        while (true) {
+            int best = 0x7fffffff;
+            for (int cur = e; cur >= 0; cur = next[cur])
+                if (cur > last && cur < best) best = cur;
+            if (best == 0x7fffffff) break;
+            if (act) {
+                const float4 v = *(const float4*)(src + (long)best * D + lane * 4);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            last = best;
+        }
+    }
+    if (act) *(float4*)(dst + (long)p * ld + lane * 4) = make_float4(sc * acc.x, sc * acc.y, sc * acc.z, sc * acc.w);
+    if (lane == 0) head[p] = -1;
+}
+U2PL_API int u2pl_scatter_rows_ordered_f32(float* dst, long ld, int D, const int* pix, const int* next, int* head,
+                                           const float* src, long n, const float* gout_dev, float scale,
+                                           hipStream_t stream) {
+    if (n <= 0) return 0;
+    if (D % 4 || D > 256) return U2PL_EINVAL;
+    hipLaunchKernelGGL(k_scatter_rows_ordered, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, ld, D, pix, next, head, src, (int)n,
+                       gout_dev, scale);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void k_zero_rows(float* __restrict__ dst, long ld, int D, const int* __restrict__ pix, long n) {
+    const int D4 = D >> 2;
+    const long total = n * D4;
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x)
+        *(float4*)(dst + (long)pix[t / D4] * ld + 4 * (t % D4)) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+U2PL_API int u2pl_zero_rows_f32(float* dst, long ld, int D, const int* pix, long n, hipStream_t stream) {
+    if (n <= 0) return 0;
+    if (D % 4) return U2PL_EINVAL;
+    hipLaunchKernelGGL(k_zero_rows, dim3(grid_for(n * (D / 4), 256)), dim3(256), 0, stream, dst, ld, D, pix, n);
     U2PL_LAUNCH_CHECK();
     return 0;
 }

@@ -425,6 +425,20 @@ def contra_phase1(rep_teacher_rows, ld, D, prob, prob_strides, lbits, low_mask, 
     return out
 
 
+_NCE_STATE = {}
+
+
+def _nce_state(device, P, D):
+    """persistent buffers of the row-sparse InfoNCE gradient: an all-zero (P, D) gradient, the per-pixel chain heads
+    (-1), and the pixel list whose rows the previous backward pass wrote (cleared lazily before the next write)"""
+    key = (str(device), P, D)
+    st = _NCE_STATE.get(key)
+    if st is None:
+        st = _NCE_STATE[key] = dict(grad=torch.zeros((P, D), dtype=torch.float32, device=device),
+                                    head=torch.full((P,), -1, dtype=torch.int32, device=device), dirty=None)
+    return st
+
+
 class _InfoNCE(torch.autograd.Function):
     """rep_rows: (P, D) contiguous view of the student features (requires grad)."""
 
@@ -432,23 +446,29 @@ class _InfoNCE(torch.autograd.Function):
     def forward(ctx, rep_rows, jobs_dev, njobs, Q, K, temp, valid_seg, keepalive):
         P, D = rep_rows.shape
         dev = rep_rows.device
+        st = _nce_state(dev, P, D)
         loss_q = torch.empty((njobs, Q), dtype=torch.float32, device=dev)
         ganchor = torch.empty((njobs, Q, D), dtype=torch.float32, device=dev)
         apix = torch.empty((njobs, Q), dtype=torch.int32, device=dev)
-        call("u2pl_infonce_f32", jobs_dev, njobs, rep_rows, D, D, Q, K, float(temp), loss_q, ganchor, apix)
+        nxt = torch.empty((njobs, Q), dtype=torch.int32, device=dev)
+        call("u2pl_infonce_f32", jobs_dev, njobs, rep_rows, D, D, Q, K, float(temp), loss_q, ganchor, apix, st["head"], nxt)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         call("u2pl_infonce_reduce_f32", loss_q, njobs, Q, 1.0 / valid_seg, loss)
-        ctx.save_for_backward(ganchor, apix)
+        ctx.save_for_backward(ganchor, apix, nxt)
         ctx.meta = (P, D, njobs * Q, 1.0 / (Q * valid_seg))
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        ganchor, apix = ctx.saved_tensors
+        ganchor, apix, nxt = ctx.saved_tensors
         P, D, n, scale = ctx.meta
-        grad = torch.zeros((P, D), dtype=torch.float32, device=g.device)
-        call("u2pl_scatter_add_rows_f32", grad, D, D, apix, ganchor, n, g.contiguous(), float(scale))
-        return grad, None, None, None, None, None, None, None
+        st = _nce_state(g.device, P, D)
+        if st["dirty"] is not None:      # rows written by the previous step's backward (their consumer has long run)
+            call("u2pl_zero_rows_f32", st["grad"], D, D, st["dirty"], st["dirty"].numel())
+        call("u2pl_scatter_rows_ordered_f32", st["grad"], D, D, apix, nxt, st["head"], ganchor, n, g.contiguous(),
+             float(scale))
+        st["dirty"] = apix
+        return st["grad"], None, None, None, None, None, None, None
 
 
 class _ZeroTimesSum(torch.autograd.Function):

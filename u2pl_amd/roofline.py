@@ -91,15 +91,9 @@ def replay_hbm_group(reps=10):
     saved, H.REPLAY = H.REPLAY, None
     try:
         if "rel" in R:
-            tl, hw, label_u, label_l, low_shape, specs, neg_high = R["rel"]
-
-            def rel():
-                ws = H.new_select_ws(tl.device, label_u.numel())
-                ent = H.entropy_map_up(tl, hw, label_u, ws)
-                thr = H.run_select(ent, ws, specs)
-                if neg_high is not None:
-                    H.reliability_apply(ent, thr, label_l, label_u, low_shape, negative_high_entropy=neg_high)
-            out["reliability_us"] = timed(rel)
+            tl, hw, label_l, label_u, low_shape, percents, neg_high = R["rel"]
+            out["reliability_us"] = timed(lambda: H.reliability_split(tl, hw, label_l, label_u, low_shape, percents,
+                                                                      negative_high_entropy=neg_high))
         if "phase1" in R:
             out["phase1_us"] = timed(lambda: H.contra_phase1(*R["phase1"]))
         if "append" in R:
@@ -175,9 +169,10 @@ def measure(trainer, batch, args, ms_per_step):
     C = trainer.num_classes
     h, w = (H - 1) // 4 + 1, (W - 1) // 4 + 1
     rel_names = ["u2pl_entropy_f32", "u2pl_entropy_up_f32", "u2pl_select_f32", "u2pl_apply_drop_i64",
-                 "u2pl_reliability_masks", "u2pl_reliability_apply"]
+                 "u2pl_reliability_masks", "u2pl_reliability_apply", "u2pl_reliability_fused"]
     con_names = ["u2pl_contra_classify", "u2pl_compact_lists", "u2pl_class_prototypes", "u2pl_bank_append_f32", "u2pl_bank_append_multi_f32",
-                 "u2pl_infonce_f32", "u2pl_infonce_reduce_f32", "u2pl_scatter_add_rows_f32"]
+                 "u2pl_infonce_f32", "u2pl_infonce_reduce_f32", "u2pl_scatter_add_rows_f32", "u2pl_scatter_rows_ordered_f32",
+                 "u2pl_zero_rows_f32"]
     rel_b, con_b = hbm_algorithmic_bytes(B, C, H, W, h, w, 256, LH.LAST_STATS)
     t_rel = sum(agg[n]["ms"] for n in rel_names if n in agg)
     t_con = sum(agg[n]["ms"] for n in con_names if n in agg)

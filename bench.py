@@ -36,8 +36,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharpen", type=float, default=4.0,
-                    help="scale of the random-init classifier's last layer (student+teacher): random-init logits are "
+                    help="std of the calibrated teacher/student logits (see calibrate()): random-init logits are "
                          "near-uniform, which would leave the contrastive path (anchors need p>0.3) idle")
+    ap.add_argument("--no-calibrate", action="store_true", help="round-1 workload: classifier last layer x sharpen only")
     ap.add_argument("--no-bank-prefill", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     return ap.parse_args()
@@ -54,6 +55,44 @@ def synth_batch(B, S, C, device, gen):
     lab = coarse[:, iy][:, :, iy].contiguous()
     lab[:, :8] = 255
     return img_l, lab, img_u
+
+
+def calibrate(model, teacher, calib, batches, sharpen):
+    """Put the random-init networks into a TRAINED-LIKE state so that the loss path sees realistic inputs (there are no
+    checkpoints or datasets offline): (1) BatchNorm running statistics = cumulative average over the synthetic batches
+    (a fresh network's running stats are 0 / 1, which makes the eval-mode pseudo-label pass collapse onto 1-2 classes);
+    (2) the classifier's last layer is standardised per class on the teacher's eval-mode logits (every class wins about
+    1/19 of the pixels, logit std = `sharpen`: confident, class-balanced predictions); (3) student = teacher (as after EMA
+    convergence); (4) the labeled targets are the teacher's own arg-max (predictions agree with the labels, like a trained
+    model).  The conv / BN workload is unchanged; all 19 classes now yield anchors, prototypes and negative keys."""
+    from u2pl_amd import nn as KN
+    bns = [m for m in teacher.modules() if isinstance(m, KN.BatchNorm2d)]
+    saved = [m.momentum for m in bns]
+    teacher.train()
+    with torch.no_grad():
+        for k in range(4):
+            for m in bns:
+                m.momentum = 1.0 / (k + 1)
+            il, _, iu = calib[k % len(calib)]
+            teacher(torch.cat((il, iu)), need_aux=True)
+        for m, mo in zip(bns, saved):
+            m.momentum = mo
+        teacher.eval()
+        il, _, iu = calib[0]
+        pred = teacher(torch.cat((il, iu)), need_aux=False, need_rep=False)["pred"].float()
+        mu = pred.mean(dim=(0, 2, 3))
+        sd = pred.std(dim=(0, 2, 3)).clamp_min(1e-6)
+        last = teacher.decoder.classifier[8]
+        last.weight.mul_((sharpen / sd).view(-1, 1, 1, 1))
+        last.bias.copy_((last.bias - mu) * (sharpen / sd))
+        model.load_state_dict(teacher.state_dict())
+        from u2pl_amd import hipops as H
+        out = []
+        for il, ll, iu in batches:
+            lab = H.pseudo_label(H.bilinear_up(teacher(il, need_aux=False, need_rep=False)["pred"], ll.shape[1:]))[1]
+            lab[:, :8] = 255
+            out.append((il, lab, iu))
+    return out
 
 
 def main():
@@ -89,9 +128,10 @@ def main():
     C = cfg["net"]["num_classes"]
     model = ModelBuilder(cfg["net"]).to(dev)
     teacher = ModelBuilder(cfg["net"]).to(dev)
-    with torch.no_grad():   # confident (trained-like) predictions so anchors / negatives exist at realistic counts
-        for m in (model, teacher):
-            m.decoder.classifier[8].weight.mul_(args.sharpen)
+    if args.no_calibrate:
+        with torch.no_grad():
+            for m in (model, teacher):
+                m.decoder.classifier[8].weight.mul_(args.sharpen)
     trainer = SemiTrainer(cfg, model, teacher, get_criterion(cfg), steps_per_epoch=163)
     if not args.no_bank_prefill:   # steady state of BASELINE configs[3]: queues at capacity (30000 x 256; class 0: 50000)
         gb = torch.Generator(device=dev).manual_seed(7)
@@ -99,6 +139,12 @@ def main():
             trainer.memobank.load_logical(c, torch.randn(trainer.memobank.cap[c], 256, device=dev, generator=gb))
     gen = torch.Generator(device=dev).manual_seed(2 + rank)
     batches = [synth_batch(args.batch, args.crop, C, dev, gen) for _ in range(2)]
+    if not args.no_calibrate:
+        # weights are calibrated on batches that are IDENTICAL on every rank (replicas must stay bit-identical);
+        # each rank's own batches only get their labeled targets from the calibrated teacher
+        gc = torch.Generator(device=dev).manual_seed(1234)
+        calib = [synth_batch(args.batch, args.crop, C, dev, gc) for _ in range(2)]
+        batches = calibrate(model, teacher, calib, batches, args.sharpen)
 
     def step(i):
         il, ll, iu = batches[i % len(batches)]
@@ -143,7 +189,11 @@ def main():
             "metric": "train images/sec at 769x769 (R101-DeepLabv3+)", "value": round(value, 4), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic (N(0,1) images, block labels; random-init weights, classifier last layer x%g)" % args.sharpen,
+            "data": ("synthetic (N(0,1) images; random-init weights put into a trained-like state: BN running statistics and "
+                     "the classifier's last layer calibrated on the synthetic batches to confident, class-balanced "
+                     "predictions with logit std %g, student = teacher, labeled targets = teacher arg-max)" % args.sharpen)
+                    if not args.no_calibrate else
+                    "synthetic (N(0,1) images, block labels; random-init weights, classifier last layer x%g)" % args.sharpen,
             "config": {"workload": f"U2PL semi {args.arch}-DeepLabv3+ Cityscapes-shaped {args.crop}x{args.crop}, per-GPU "
                                    f"batch {args.batch} labeled + {args.batch} unlabeled, C=19, OHEM+aux, cutmix, "
                                    "contrastive bank 30000x256 pre-filled (BASELINE configs[2]/[3])",
@@ -151,8 +201,16 @@ def main():
             "losses_last_step": [round(float(x), 5) for x in meters.cpu()],
         }
         out.update(roof)
-        if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N=1 only
-            out["cpu_baseline"] = RL.cpu_baseline(args)
+        if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N=1 only (the checker's port, never the product)
+            from oracle import step_ref
+            out["cpu_baseline"] = step_ref.timed_cpu_baseline(crop=args.crop, arch=args.arch, batch=args.batch)
+            ref_t = os.path.join(ROOT, "profiles", "r02_cpu_reference_timing.json")
+            if os.path.exists(ref_t):
+                rt = json.load(open(ref_t))
+                out["cpu_baseline"]["reference_train_in_build_container"] = {
+                    "images_per_s": round(rt["reference_images_per_s"], 5), "cores": rt["cores"],
+                    "note": "the reference's own train_semi.train() through oracle/ref_shim.py, 1 warm-up + 2 timed steps, "
+                            "same configuration; /root/reference does not exist on the GPU box"}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -188,29 +188,40 @@ class CpuStepRef:
         return out
 
 
-def timed_cpu_baseline(crop=769, arch="resnet101", batch=1):
-    """bench.py cpu_baseline leg: ONE reference-equivalent CPU step on a bounded sample
-    (batch labeled + batch unlabeled images at the full crop)."""
-    # torch-CPU conv scaling collapses when oversubscribed (256 threads: 650 s for this sample on
-    # the MI355X host; 8 threads: ~35 s) -> use a bounded thread pool and report it as `cores`
+def timed_cpu_baseline(crop=769, arch="resnet101", batch=2, warmup=1, steps=2):
+    """bench.py cpu_baseline leg (SURVEY 8d "CPU reference timing"): `warmup` un-timed + `steps`
+    timed reference-equivalent CPU training steps at the FULL per-GPU batch (batch labeled + batch unlabeled crops),
+    dropout on.  The port is pinned to the reference's own train() (tests/test_oracle_golden.py, incl. a 769^2 step);
+    the reference itself cannot travel to the GPU box, so `kind` is "port" and profiles/r02_cpu_reference_timing.json
+    holds the reference's own timing next to the port's in the build container."""
+    # torch-CPU conv scaling collapses when oversubscribed (256 threads: 650 s per step on the MI355X host; 32: ~20 s)
     ncores = min(os.cpu_count() or 1, int(os.environ.get("U2PL_CPU_BASELINE_THREADS", "32")))
     torch.set_num_threads(ncores)
     torch.manual_seed(2)
     np.random.seed(2)
     ref = CpuStepRef(arch=arch, p_drop=0.1)
-    il, iu = torch.randn(batch, 3, crop, crop), torch.randn(batch, 3, crop, crop)
-    gsz = crop // 16 + 1
-    coarse = torch.randint(0, 19, (batch, gsz, gsz))
-    iy = (torch.arange(crop) * gsz // crop).clamp(max=gsz - 1)
-    ll = coarse[:, iy][:, :, iy].contiguous()
-    ll[:, :8] = 255
-    t0 = time.perf_counter()
-    ref.step(il, ll, iu, epoch=0)
-    dt = time.perf_counter() - t0
+    gen = torch.Generator().manual_seed(2)
+    data = []
+    for _ in range(warmup + steps):
+        il, iu = torch.randn(batch, 3, crop, crop, generator=gen), torch.randn(batch, 3, crop, crop, generator=gen)
+        gsz = crop // 16 + 1
+        coarse = torch.randint(0, 19, (batch, gsz, gsz), generator=gen)
+        iy = (torch.arange(crop) * gsz // crop).clamp(max=gsz - 1)
+        ll = coarse[:, iy][:, :, iy].contiguous()
+        ll[:, :8] = 255
+        data.append((il, ll, iu))
+    times = []
+    for i, (il, ll, iu) in enumerate(data):
+        t0 = time.perf_counter()
+        ref.step(il, ll, iu, epoch=0)
+        times.append(time.perf_counter() - t0)
+    dt = float(np.mean(times[warmup:]))
     return {"value": round(2 * batch / dt, 5), "unit": "images/s", "cores": ncores, "kind": "port",
-            "sample": f"1 full U2PL step (teacher eval fwd, student fwd+bwd, teacher train fwd, OHEM+unsup+contrastive "
-                      f"losses, SGD, EMA) of oracle/step_ref.py on {batch} labeled + {batch} unlabeled {crop}x{crop} "
-                      f"crops ({arch}), torch-CPU fp32 with {ncores} threads + numpy; {dt:.1f} s"}
+            "s_per_step": [round(t, 2) for t in times],
+            "sample": f"{warmup} warm-up + {steps} timed full U2PL steps (teacher eval fwd, student fwd+bwd, teacher train fwd, "
+                      f"OHEM+unsup+contrastive losses, SGD, EMA) of oracle/step_ref.py (pinned to the reference's train()) on "
+                      f"{batch} labeled + {batch} unlabeled {crop}x{crop} crops ({arch}), torch-CPU fp32 with {ncores} threads "
+                      f"+ numpy; {dt:.1f} s per timed step"}
 
 
 def validate_ref(model, batches, num_classes, ignore=255):

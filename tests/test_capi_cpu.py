@@ -41,7 +41,8 @@ def test_product_never_imports_oracle():
         for f in files:
             if f.endswith(".py"):
                 s = open(os.path.join(d, f)).read()
-                if "import oracle" in s or "from oracle" in s or "/root/reference" in s:
+                # any mention at all: also catches importlib.import_module("oracle...") / __import__ / sys.path games
+                if "oracle" in s or "/root/reference" in s or "ref_shim" in s:
                     bad.append(os.path.join(d, f))
     assert not bad, bad
 

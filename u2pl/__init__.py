@@ -7,7 +7,8 @@ import sys
 import u2pl_amd
 
 for _name in ["models", "models.base", "models.resnet", "models.decoder", "models.model_helper", "utils",
-              "utils.loss_helper", "utils.utils"]:
+              "utils.loss_helper", "utils.utils", "utils.lr_helper", "utils.dist_helper", "dataset", "dataset.builder",
+              "dataset.augmentation"]:
     try:
         sys.modules["u2pl." + _name] = importlib.import_module("u2pl_amd." + _name)
     except ImportError:

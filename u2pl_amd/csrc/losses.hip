@@ -189,8 +189,12 @@ __global__ void k_confusion(const float* __restrict__ z, const long long* __rest
             if (v > m) { m = v; am = c; }
         }
         atomicAdd(&sh_h[C + am], 1u);
-        atomicAdd(&sh_h[2 * C + (int)t], 1u);
-        if (am == (int)t) atomicAdd(&sh_h[am], 1u);
+        // a label outside [0, C) that is not the ignore value (wrong label map): np.histogram(range=(0, K-1)) drops it
+        // from area_target / area_intersection (utils.py:576-579); the prediction still counts in area_output
+        if (t >= 0 && t < C) {
+            atomicAdd(&sh_h[2 * C + (int)t], 1u);
+            if (am == (int)t) atomicAdd(&sh_h[am], 1u);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 3 * C; i += blockDim.x)

@@ -95,8 +95,11 @@ class SegDataset(Dataset):
 
 
 def _loader(dset, cfg, train):
-    sampler = DistributedSampler(dset) if torch.distributed.is_available() and torch.distributed.is_initialized() \
-        else None
+    # the reference always samples through DistributedSampler (shuffle=True, re-seeded by set_epoch: cityscapes.py:143-163);
+    # with explicit num_replicas / rank it needs no process group, so single-GPU runs shuffle per epoch too
+    ddp = torch.distributed.is_available() and torch.distributed.is_initialized()
+    world, rank = (torch.distributed.get_world_size(), torch.distributed.get_rank()) if ddp else (1, 0)
+    sampler = DistributedSampler(dset, num_replicas=world, rank=rank, shuffle=train)
     return DataLoader(dset, batch_size=cfg.get("batch_size", 1), num_workers=cfg.get("workers", 2), sampler=sampler,
                       shuffle=False, pin_memory=True, drop_last=train)
 

@@ -74,15 +74,69 @@ def state_dict_ddp(model):
     return {"module." + k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}
 
 
-def load_state(path, model, key="model_state"):
-    """utils.py:583-636 semantics: strips 'module.', drops size-mismatched keys, strict=False."""
-    ckpt = torch.load(path, map_location="cpu")
+def load_state(path, model, optimizer=None, key="model_state"):
+    """utils.py:583-636 semantics: strips 'module.', drops size-mismatched keys, strict=False; with `optimizer`
+    (anything exposing load_state_dict / load_optimizer_state_dict) also restores `optimizer_state` and returns
+    (best_miou, epoch) like the reference."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
     sd = ckpt[key] if key in ckpt else ckpt
     sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
     own = model.state_dict()
     sd = {k: v for k, v in sd.items() if k in own and own[k].shape == v.shape}
     model.load_state_dict(sd, strict=False)
+    if optimizer is not None:
+        load = getattr(optimizer, "load_optimizer_state_dict", None) or optimizer.load_state_dict
+        load(ckpt["optimizer_state"])
+        return ckpt["best_miou"], ckpt["epoch"]
     return ckpt
+
+
+def checkpoint_state(epoch, best, model, teacher, trainer):
+    """train_semi.py:210-224 wire format (`module.`-prefixed model_state / teacher_state, torch-SGD optimizer_state,
+    best_miou, epoch) + what upstream forgets and a bit-faithful resume needs: the memory bank, the iteration counter
+    and the RNG streams (extra keys, ignored by the reference's load_state)."""
+    state = {"epoch": epoch, "model_state": state_dict_ddp(model), "optimizer_state": trainer.optimizer_state_dict(),
+             "best_miou": best, "cur_iter": trainer.cur_iter,
+             "rng_state": {"torch": torch.get_rng_state(), "cuda": torch.cuda.get_rng_state(), "numpy": np.random.get_state(),
+                           "python": random.getstate()}}
+    if teacher is not None:
+        state["teacher_state"] = state_dict_ddp(teacher)
+        bank = trainer.memobank
+        state["memobank"] = {"rows": [bank.logical(c).cpu() for c in range(len(bank))], "ptr": list(bank.ptr)}
+    return state
+
+
+def restore_extras(ckpt, trainer, steps_per_epoch):
+    trainer.cur_iter = ckpt.get("cur_iter", ckpt.get("epoch", 0) * steps_per_epoch)
+    if "optimizer_state" in ckpt:
+        trainer.load_optimizer_state_dict(ckpt["optimizer_state"])
+    mb = ckpt.get("memobank")
+    if mb is not None and getattr(trainer, "memobank", None) is not None:
+        dev = trainer.memobank.buf[0].device
+        for c, rows in enumerate(mb["rows"]):
+            if rows.shape[0]:
+                trainer.memobank.load_logical(c, rows.to(dev))
+            trainer.memobank.ptr[c] = mb["ptr"][c]
+    rs = ckpt.get("rng_state")
+    if rs is not None:
+        torch.set_rng_state(rs["torch"])
+        torch.cuda.set_rng_state(rs["cuda"])
+        np.random.set_state(rs["numpy"])
+        random.setstate(rs["python"])
+
+
+def absolutize_paths(cfg, exp_path):
+    """reference configs hold paths relative to the experiment directory (train.sh cd's there); resolve them ONCE so
+    that datasets opened lazily in DataLoader workers and the pretrain checkpoint do not depend on the cwd"""
+    def fix(d, key):
+        if isinstance(d.get(key), str) and not osp.isabs(d[key]):
+            d[key] = osp.normpath(osp.join(exp_path, d[key]))
+    ds = cfg["dataset"]
+    for sub in (ds, ds.get("train", {}), ds.get("val", {})):
+        for key in ("data_root", "data_list"):
+            fix(sub, key)
+    if isinstance(cfg.get("saver", {}).get("pretrain"), str):
+        fix(cfg["saver"], "pretrain")
 
 
 def build(cfg, device, semi=True, steps_per_epoch=1):
@@ -106,24 +160,22 @@ def run(cfg, args, semi):
     cfg["save_path"] = osp.join(cfg["exp_path"], cfg["saver"]["snapshot_dir"])
     if rank == 0:
         os.makedirs(cfg["save_path"], exist_ok=True)
-    cwd = os.getcwd()
-    os.chdir(cfg["exp_path"])      # config paths are relative to the experiment dir
+    absolutize_paths(cfg, cfg["exp_path"])
     loaders = get_loader(cfg, seed=args.seed or 0)
-    os.chdir(cwd)
     loader_l, loader_u, loader_val = (loaders if semi else (loaders[0], None, loaders[1]))
     model, teacher, trainer = build(cfg, device, semi, steps_per_epoch=len(loader_l))
     best, start_epoch = 0.0, 0
     ck = osp.join(cfg["save_path"], "ckpt.pth")
     if cfg["saver"].get("auto_resume", False) and osp.exists(ck):
-        c = load_state(ck, model)
+        c = load_state(ck, model)      # parameters are views of the arenas: loaded in place
         if teacher is not None and "teacher_state" in c:
             load_state(ck, teacher, key="teacher_state")
-        trainer.resync_arenas()
         best, start_epoch = c.get("best_miou", 0.0), c.get("epoch", 0)
-        trainer.cur_iter = start_epoch * len(loader_l)
-    elif cfg["saver"].get("pretrain", False):
-        load_state(cfg["saver"]["pretrain"], model)
-        trainer.resync_arenas()
+        restore_extras(c, trainer, len(loader_l))      # momentum (optimizer_state), bank, iteration counter, RNG
+    elif cfg["saver"].get("pretrain", False):          # train_semi.py:152-154: student AND teacher
+        c = load_state(cfg["saver"]["pretrain"], model)
+        if teacher is not None and isinstance(c, dict) and "teacher_state" in c:
+            load_state(cfg["saver"]["pretrain"], teacher, key="teacher_state")
     for epoch in range(start_epoch, cfg["trainer"]["epochs"]):
         for ld in (loader_l, loader_u):
             if ld is not None and hasattr(ld.sampler, "set_epoch"):
@@ -158,9 +210,7 @@ def run(cfg, args, semi):
             use_teacher = semi and epoch >= cfg["trainer"].get("sup_only_epoch", 1)
             miou, _ = validate(teacher if use_teacher else model, loader_val, cfg, device)
             if rank == 0:
-                state = {"epoch": epoch + 1, "model_state": state_dict_ddp(model), "best_miou": max(best, miou)}
-                if teacher is not None:
-                    state["teacher_state"] = state_dict_ddp(teacher)
+                state = checkpoint_state(epoch + 1, max(best, miou), model, teacher, trainer)
                 if miou > best:
                     best = miou
                     torch.save(state, osp.join(cfg["save_path"], "ckpt_best.pth"))

@@ -650,6 +650,14 @@ class ParamArena:
                 p.grad = gv
         self.momentum_buf = None
         self.steps = 0
+        self._offs = {id(p): off for p, off in zip(self.params, offs)}
+
+    def momentum_view(self, p):
+        """view of the momentum arena shaped / strided like parameter p (allocated on first use)"""
+        if self.momentum_buf is None:
+            self.momentum_buf = torch.zeros_like(self.flat)
+        off = self._offs[id(p)]
+        return self.momentum_buf[off:off + p.numel()].as_strided(p.shape, p.stride())
 
     def zero_grad(self):
         self.grad.zero_()

@@ -24,7 +24,7 @@ import torch.distributed as dist
 from . import hipops as H
 from . import nn as K
 from .utils import loss_helper as LH
-from .utils.lr_helper import poly_lr
+from .utils.lr_helper import check_sgd_kwargs, load_sgd_state_dict, poly_lr, sgd_state_dict
 
 
 def _world():
@@ -104,12 +104,7 @@ class SemiTrainer:
         tr = cfg["trainer"]
         self.epochs = tr["epochs"]
         self.sup_only_epoch = tr.get("sup_only_epoch", 1)
-        ok = tr["optimizer"]
-        assert ok["type"] == "SGD", "flat-arena step implements torch.optim.SGD (reference configs use SGD)"
-        self.base_lr = ok["kwargs"]["lr"]
-        self.momentum = ok["kwargs"].get("momentum", 0.0)
-        self.weight_decay = ok["kwargs"].get("weight_decay", 0.0)
-        self.power = tr["lr_scheduler"]["kwargs"].get("power", 0.9) or 0.9
+        self._init_schedule(tr)
         times = 10 if cfg["dataset"]["type"].startswith("pascal") else 1  # train_semi.py:100-110
         groups = [list(model.encoder.parameters()), list(model.decoder.parameters())]
         tgroups = [list(model_teacher.encoder.parameters()), list(model_teacher.decoder.parameters())]
@@ -133,22 +128,58 @@ class SemiTrainer:
         self.cur_iter = 0
         self.use_aux = "aux_loss" in cfg["net"].keys()
 
+    def _init_schedule(self, tr):
+        ok = tr["optimizer"]
+        if ok["type"] != "SGD":
+            raise NotImplementedError("the flat-arena step implements torch.optim.SGD (what the reference configs use)")
+        check_sgd_kwargs(ok["kwargs"])
+        self.base_lr = ok["kwargs"]["lr"]
+        self.momentum = ok["kwargs"].get("momentum", 0.0)
+        self.weight_decay = ok["kwargs"].get("weight_decay", 0.0)
+        sch = tr["lr_scheduler"]
+        self.lr_mode = sch.get("mode", "poly")
+        kw = sch.get("kwargs", {}) or {}
+        if self.lr_mode == "poly":
+            self.power = kw.get("power", 0.9) or 0.9
+        elif self.lr_mode == "cosine":
+            self.targetlr = kw["targetlr"]
+        else:   # the reference accepts "multistep" but only implements "step" (lr_helper.py:47,84; Q9): neither is wired here
+            raise NotImplementedError(f"lr_scheduler.mode {self.lr_mode!r}: poly and cosine are implemented")
+
     # -- LRScheduler.step (lr_helper.py:78-113): lr for this step is set before the forward
     def _lrs(self):
         max_iter = self.epochs * self.steps_per_epoch
-        lr = poly_lr(self.base_lr, self.cur_iter, max_iter, self.power)
+        if self.lr_mode == "poly":
+            lrs = [poly_lr(self.base_lr * m, self.cur_iter, max_iter, self.power) for m in self.lr_mult]
+        else:
+            from math import cos, pi
+            lrs = [self.targetlr + (self.base_lr * m - self.targetlr) * (1 + cos(pi * self.cur_iter / max_iter)) / 2
+                   for m in self.lr_mult]
         self.cur_iter += 1
-        self.last_lr = lr
-        return [lr * m for m in self.lr_mult]
+        self.last_lr = lrs[0]
+        return lrs
+
+    # -- torch.optim.SGD.state_dict() layout in the reference's group order (train_semi.py:100-110,214; utils.py:622-625)
+    def _ref_groups(self):
+        enc, dec = list(self.model.encoder.parameters()), list(self.model.decoder.parameters())
+        aux = [list(self.model.auxor.parameters())] if hasattr(self.model, "auxor") else []
+        return [enc] + aux + [dec]
+
+    def optimizer_state_dict(self):
+        m = self.lr_mult
+        mult = [m[0]] + ([m[2]] if len(m) > 2 else []) + [m[1]]
+        lr = getattr(self, "last_lr", self.base_lr)
+        return sgd_state_dict(self._ref_groups(), [lr * k / m[0] for k in mult], self.momentum, self.weight_decay,
+                              self.arena.momentum_view, self.arena.steps > 0)
+
+    def load_optimizer_state_dict(self, sd):
+        if load_sgd_state_dict(sd, self._ref_groups(), self.arena.momentum_view):
+            self.arena.steps = max(self.arena.steps, 1)
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream() if os.environ.get("U2PL_NO_SIDE_STREAM") is None else torch.cuda.current_stream()
         return self._side
-
-    def resync_arenas(self):
-        """parameters were (re)loaded through load_state_dict: views already alias the arenas."""
-        return None
 
     def _reduce_grads_and_step(self, lrs):
         K.wgrad_stream_sync()   # weight gradients are produced on a side stream
@@ -309,11 +340,7 @@ class SupTrainer:
         self.cfg, self.model, self.sup_loss_fn, self.steps_per_epoch = cfg, model, sup_loss_fn, steps_per_epoch
         tr = cfg["trainer"]
         self.epochs = tr["epochs"]
-        ok = tr["optimizer"]
-        assert ok["type"] == "SGD"
-        self.base_lr, self.momentum = ok["kwargs"]["lr"], ok["kwargs"].get("momentum", 0.0)
-        self.weight_decay = ok["kwargs"].get("weight_decay", 0.0)
-        self.power = tr["lr_scheduler"]["kwargs"].get("power", 0.9) or 0.9
+        self._init_schedule(tr)
         times = 10 if cfg["dataset"]["type"].startswith("pascal") else 1
         groups = [list(model.encoder.parameters()), list(model.decoder.parameters())]
         self.lr_mult = [1, times]
@@ -324,8 +351,11 @@ class SupTrainer:
         self.cur_iter, self.last_lr = 0, self.base_lr
         self.use_aux = "aux_loss" in cfg["net"].keys()
 
+    _init_schedule = SemiTrainer._init_schedule
     _lrs = SemiTrainer._lrs
-    resync_arenas = SemiTrainer.resync_arenas
+    _ref_groups = SemiTrainer._ref_groups
+    optimizer_state_dict = SemiTrainer.optimizer_state_dict
+    load_optimizer_state_dict = SemiTrainer.load_optimizer_state_dict
 
     def train_step(self, image, label, epoch=0):
         lrs = self._lrs()

@@ -2,6 +2,8 @@
 poly / cosine, stepped per iteration, LR for step k set before that step's forward."""
 from math import cos, pi
 
+import torch
+
 
 def poly_lr(base_lr, cur_iter, max_iter, power=0.9):
     return base_lr * ((1 - float(cur_iter) / max_iter) ** power)
@@ -45,3 +47,116 @@ def get_scheduler(cfg_trainer, len_data, optimizer, start_epoch=0, use_iteration
     epochs = cfg_trainer["epochs"] if not use_iteration else 1
     return LRScheduler(cfg_trainer["lr_scheduler"]["mode"], cfg_trainer["lr_scheduler"]["kwargs"], len_data,
                        optimizer, epochs, start_epoch)
+
+
+# ------------------------------------------------------------------ optimizer seam (lr_helper.py:12-27)
+_SGD_DEFAULTS = dict(momentum=0, dampening=0, weight_decay=0, nesterov=False, maximize=False, foreach=None,
+                     differentiable=False, fused=None)
+
+
+def check_sgd_kwargs(kw):
+    """the flat-arena step implements plain torch.optim.SGD(lr, momentum, weight_decay); anything that would change the
+    update rule is rejected instead of being silently ignored"""
+    known = {"lr", "momentum", "weight_decay", "dampening", "nesterov"}
+    extra = set(kw) - known
+    if extra:
+        raise ValueError(f"optimizer kwargs not supported by the HIP SGD step: {sorted(extra)}")
+    if kw.get("nesterov", False) or kw.get("dampening", 0) not in (0, 0.0):
+        raise NotImplementedError("nesterov / dampening are not implemented by u2pl_sgd_step_f32 (never set by the reference configs)")
+
+
+def sgd_state_dict(ref_groups, lrs, momentum, weight_decay, momentum_of, stepped):
+    """torch.optim.SGD.state_dict() layout (what train_semi.py:210-224 saves and utils.py:622-625 reloads):
+    ref_groups: parameter lists in the REFERENCE's group order (encoder, [aux head], decoder: train_semi.py:100-110);
+    momentum_of(p) -> that parameter's momentum buffer (a view of the momentum arena)."""
+    state, groups, idx = {}, [], 0
+    for g, lr in zip(ref_groups, lrs):
+        ids = []
+        for p in g:
+            if stepped:
+                state[idx] = {"momentum_buffer": momentum_of(p).detach().cpu().contiguous()}
+            ids.append(idx)
+            idx += 1
+        groups.append(dict(_SGD_DEFAULTS, lr=lr, momentum=momentum, weight_decay=weight_decay, params=ids))
+    return {"state": state, "param_groups": groups}
+
+
+def load_sgd_state_dict(sd, ref_groups, momentum_of):
+    """copies the momentum buffers back into the arena; returns True when at least one step had been taken"""
+    params = [p for g in ref_groups for p in g]
+    if sum(len(g["params"]) for g in sd["param_groups"]) != len(params):
+        raise ValueError("optimizer_state has a different number of parameters than this model")
+    order = [i for g in sd["param_groups"] for i in g["params"]]
+    stepped = False
+    for p, i in zip(params, order):
+        st = sd["state"].get(i, sd["state"].get(str(i)))
+        if st is not None and st.get("momentum_buffer") is not None:
+            momentum_of(p).copy_(st["momentum_buffer"].to(momentum_of(p).device))
+            stepped = True
+    return stepped
+
+
+class ArenaSGD:
+    """`get_optimizer(params_list, cfg_optim)` of the reference (lr_helper.py:12-27) for `type: SGD`: the parameters
+    of all groups move into ONE flat arena (u2pl_amd.nn.ParamArena; layer kernels accumulate their weight gradients
+    straight into it) and step() is one launch.  torch.optim.SGD surface used by train_semi.py: param_groups (the
+    LRScheduler writes g['lr']), zero_grad(), step(), state_dict() / load_state_dict() in torch's layout.  Under a
+    process group step() also all-reduces the gradient arena (the layers bypass autograd's .grad accumulation, so a
+    DistributedDataParallel wrapper would never see them)."""
+
+    def __init__(self, params_list, lr, momentum=0.0, weight_decay=0.0, **kw):
+        from .. import nn as K
+        check_sgd_kwargs(dict(kw, lr=lr, momentum=momentum, weight_decay=weight_decay))
+        params_list = list(params_list)
+        if len(params_list) > 3:
+            raise ValueError("u2pl_sgd_step_f32 has three learning-rate segments (encoder / aux head / decoder)")
+        self.momentum, self.weight_decay = float(momentum), float(weight_decay)
+        # like torch.optim: the caller's group dicts are mutated (generators -> lists, defaults filled in) and KEPT, so a
+        # second optimizer built from the same dicts shares them -- the reference relies on that (SURVEY Q9: the
+        # scheduler drives `optimizer_start`, whose groups are `optimizer`'s groups)
+        for g in params_list:
+            g["params"] = list(g["params"])
+            for k, v in dict(_SGD_DEFAULTS, lr=lr, momentum=momentum, weight_decay=weight_decay).items():
+                g.setdefault(k, v)
+        self.param_groups = params_list
+        self.groups = [g["params"] for g in params_list]
+        owner = getattr(self.groups[0][0], "_u2pl_owner", None)
+        if owner is not None:            # second get_optimizer() over the same parameters: same arena, same momentum
+            self.arena = owner.arena
+        else:
+            self.arena = K.ParamArena(self.groups)
+            for g in self.groups:
+                for p in g:
+                    p._u2pl_owner = self
+
+    def zero_grad(self, set_to_none=False):
+        self.arena.zero_grad()
+
+    def step(self):
+        import torch.distributed as dist
+        from .. import nn as K
+        K.wgrad_stream_sync()
+        W = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if W > 1:
+            dist.all_reduce(self.arena.grad)
+        self.arena.sgd_step([g["lr"] for g in self.param_groups], self.momentum, self.weight_decay, grad_scale=1.0 / W)
+
+    def _mom(self, p):
+        return self.arena.momentum_view(p)
+
+    def state_dict(self):
+        return sgd_state_dict(self.groups, [g["lr"] for g in self.param_groups], self.momentum, self.weight_decay,
+                              self._mom, self.arena.steps > 0)
+
+    def load_state_dict(self, sd):
+        if load_sgd_state_dict(sd, self.groups, self._mom):
+            self.arena.steps = max(self.arena.steps, 1)
+        for g, src in zip(self.param_groups, sd["param_groups"]):
+            g["lr"] = src["lr"]
+
+
+def get_optimizer(parms, cfg_optim):
+    """lr_helper.py:12-27"""
+    if cfg_optim["type"] != "SGD":
+        raise NotImplementedError("only `SGD` (what every reference config uses) has a HIP step; got %r" % cfg_optim["type"])
+    return ArenaSGD(parms, **cfg_optim["kwargs"])

@@ -1,5 +1,9 @@
 """Host-side helpers with the reference's names (u2pl/utils/utils.py) for the
 pieces on the hot path: memory-bank enqueue with cross-rank key gather."""
+import logging
+import os
+import random
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -99,3 +103,94 @@ def dequeue_and_enqueue(keys, queue, queue_ptr, queue_size):
         ptr = (ptr + batch_size) % queue_size
     queue_ptr[0] = ptr
     return batch_size
+
+
+# ------------------------------------------------------------------ small host helpers train_semi.py imports (utils.py:62-95,378-492)
+def get_world_size():
+    return _world()
+
+
+def get_rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def set_random_seed(seed, deterministic=False):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+
+
+class AverageMeter(object):
+    """utils.py:438-471: running average, or a window of the last `length` values"""
+
+    def __init__(self, length=0):
+        self.length = length
+        self.reset()
+
+    def reset(self):
+        self.history, self.count, self.sum, self.val, self.avg = [], 0, 0.0, 0.0, 0.0
+
+    def update(self, val, num=1):
+        self.val = val
+        if self.length > 0:
+            assert num == 1
+            self.history = (self.history + [val])[-self.length:]
+            self.avg = float(np.mean(self.history))
+        else:
+            self.sum += val * num
+            self.count += num
+            self.avg = self.sum / self.count
+
+
+_LOGS = set()
+
+
+def init_log(name, level=logging.INFO):
+    if (name, level) in _LOGS:
+        return logging.getLogger(name)
+    _LOGS.add((name, level))
+    logger = logging.getLogger(name)
+    logger.setLevel(level)
+    ch = logging.StreamHandler()
+    ch.setLevel(level)
+    rank = int(os.environ.get("SLURM_PROCID", os.environ.get("RANK", 0)))
+    logger.addFilter(lambda record: rank == 0)
+    ch.setFormatter(logging.Formatter("[%(asctime)s][%(levelname)8s] %(message)s"))
+    logger.addHandler(ch)
+    return logger
+
+
+def label_onehot(inputs, num_segments):
+    """utils.py:50-59 INCLUDING the batch-slot-0 quirk: slot 0 holds the multi-hot union over the batch
+    (ignored pixels of the other samples contribute class 0), zeroed where sample 0 itself is 255; slots >= 1 are zero."""
+    B, Hh, Ww = inputs.shape
+    out = torch.zeros((B, num_segments, Hh, Ww), dtype=torch.int64, device=inputs.device)
+    lab = inputs.clone()
+    lab[lab == 255] = 0
+    for b in range(B):
+        out[0].scatter_(0, lab[b:b + 1], 1)
+    out[0][:, inputs[0] == 255] = 0
+    return out
+
+
+def intersectionAndUnion(output, target, K, ignore_index=255):
+    """utils.py:568-580 on device tensors / numpy arrays of class ids -> (area_intersection, area_union, area_target)"""
+    out = torch.as_tensor(output).reshape(-1).long().clone()
+    tgt = torch.as_tensor(target).reshape(-1).long().to(out.device)
+    out[tgt == ignore_index] = ignore_index
+    inter = out[out == tgt]
+    hist = lambda x: torch.bincount(x[(x >= 0) & (x < K)], minlength=K)[:K].cpu().numpy().astype(np.float64)
+    ai, ao, at = hist(inter), hist(out), hist(tgt)
+    return ai, ao + at - ai, at
+
+
+def load_state(path, model, optimizer=None, key="state_dict"):
+    """utils.py:583-636"""
+    from ..engine import load_state as _ls
+    if not os.path.isfile(path):
+        if get_rank() == 0:
+            print("=> no checkpoint found at '{}'".format(path))
+        return None
+    out = _ls(path, model, optimizer=optimizer, key=key)
+    return out if optimizer is not None else None

@@ -140,6 +140,11 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(2 + rank)
     batches = [synth_batch(args.batch, args.crop, C, dev, gen) for _ in range(2)]
     if not args.no_calibrate:
+        # A synthetic network is fragile: ONE SGD step at the reference's lr 0.01 on noise images collapses the
+        # pseudo-labels onto a single class (measured), which would idle the contrastive path from the second step on.
+        # The learning rate is a scalar argument of the same SGD launch: 1e-6 keeps the calibrated state through
+        # warm-up and timing without changing the work of a step.
+        trainer.base_lr = 1e-6
         # weights are calibrated on batches that are IDENTICAL on every rank (replicas must stay bit-identical);
         # each rank's own batches only get their labeled targets from the calibrated teacher
         gc = torch.Generator(device=dev).manual_seed(1234)
@@ -191,7 +196,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": ("synthetic (N(0,1) images; random-init weights put into a trained-like state: BN running statistics and "
                      "the classifier's last layer calibrated on the synthetic batches to confident, class-balanced "
-                     "predictions with logit std %g, student = teacher, labeled targets = teacher arg-max)" % args.sharpen)
+                     "predictions with logit std %g, student = teacher, labeled targets = teacher arg-max; lr 1e-6 so that "
+                     "state persists over the timed steps -- same launches as at lr 0.01)" % args.sharpen)
                     if not args.no_calibrate else
                     "synthetic (N(0,1) images, block labels; random-init weights, classifier last layer x%g)" % args.sharpen,
             "config": {"workload": f"U2PL semi {args.arch}-DeepLabv3+ Cityscapes-shaped {args.crop}x{args.crop}, per-GPU "

@@ -108,20 +108,23 @@ int u2pl_bank_append_multi_f32(const long long* desc_dev, int nclass, int D, lon
                                hipStream_t stream);
 /* cosine_similarity / temp + cross_entropy(target 0): loss_helper.py:173-230 */
 size_t u2pl_infonce_job_bytes(void);
-/* head (int [P], all -1 between calls) / next (int [njobs*Q]) may be NULL; when given, the entries that sampled the same
-   pixel are chained for u2pl_scatter_rows_ordered_f32 */
+/* head (int [P], all -1 between calls), next (int [njobs*Q]), seg_len (int [njobs*Q], > 0 for the first entry of every
+   group of entries of one job that sampled the same candidate; host-built) may all be NULL; when given, the group leaders
+   that hit the same pixel are chained for u2pl_scatter_rows_ordered_f32 */
 int u2pl_infonce_f32(const void* jobs_dev, int njobs, const float* rep, long ld, int D, int Q, int K,
                      float temp, float* loss_q, float* ganchor, int* anchor_pix, int* head, int* next,
-                     hipStream_t stream);
+                     const int* seg_len, hipStream_t stream);
 int u2pl_infonce_reduce_f32(const float* loss_q, int njobs, int Q, float inv_valid_seg, float* loss,
                             hipStream_t stream);
 int u2pl_scatter_add_rows_f32(float* dst, long ld, int D, const int* pix, const float* src, long n,
                               const float* gout_dev, float scale, hipStream_t stream);
 /* d loss / d rep (loss_helper.py:205-230 backward) without a dense zero fill and without float atomics: dst is a
    persistent all-zero (P, D) buffer; per sampled pixel dst[pix] = scale * gout * (sum of its entries' src rows in
-   ascending entry order); head is re-armed to -1.  u2pl_zero_rows_f32 clears those rows again afterwards. */
+   ascending entry order); head is re-armed to -1.  order / seg_pos / seg_len: host-built grouping of every job's entries
+   by sampled candidate (see hipops.group_entries).  u2pl_zero_rows_f32 clears those rows again afterwards. */
 int u2pl_scatter_rows_ordered_f32(float* dst, long ld, int D, const int* pix, const int* next, int* head,
-                                  const float* src, long n, const float* gout_dev, float scale, hipStream_t stream);
+                                  const int* order, const int* seg_pos, const int* seg_len, const float* src, long n,
+                                  const float* gout_dev, float scale, hipStream_t stream);
 int u2pl_zero_rows_f32(float* dst, long ld, int D, const int* pix, long n, hipStream_t stream);
 
 /* ---- losses.hip ----------------------------------------------------------- */

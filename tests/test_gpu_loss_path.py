@@ -529,15 +529,18 @@ def test_fused_reliability_split_full_size_equals_unfused(case):
 
 
 # ------------------------------------------------------------------ row-sparse ordered InfoNCE gradient
-@pytest.mark.parametrize("n_pix", [3000, 40, 2])
-def test_infonce_gradient_scatter_is_row_sparse_ordered_and_reproducible(n_pix):
-    """u2pl_scatter_rows_ordered_f32 + u2pl_zero_rows_f32 (the backward of the anchor gather, loss_helper.py:205-230):
-    rows of the persistent gradient buffer = scale * g * (sum of the entries that sampled the pixel, ASCENDING entry
-    order) -- bit-identical to a sequential host sum, bit-identical run to run, zero everywhere else, also when a pixel
-    is sampled hundreds of times (chains >= 64: the O(len^2) branch) and after the lazy re-zero of the previous call."""
+@pytest.mark.parametrize("n_cand", [3000, 40, 2])
+def test_infonce_gradient_scatter_is_row_sparse_ordered_and_reproducible(n_cand):
+    """u2pl_scatter_rows_ordered_f32 + u2pl_zero_rows_f32 (the backward of the anchor gather, loss_helper.py:205-230) with
+    the host-built grouping (hipops.group_entries): rows of the persistent gradient buffer = scale * g * (sum of the
+    entries that sampled the pixel, ASCENDING entry order) -- bit-identical to a sequential host sum and run to run, zero
+    everywhere else, also when a candidate is drawn ~100 times (tiny candidate lists), when the same pixel sits in
+    several jobs' lists (chain of group leaders), and after the lazy re-zero of the previous call."""
     from u2pl_amd._lib import call
-    P, D, n = 5000, 256, 19 * 256
-    g = torch.Generator().manual_seed(n_pix)
+    H = hip()
+    P, D, Q, nj = 6000, 256, 256, 19
+    n = nj * Q
+    g = torch.Generator().manual_seed(n_cand)
     grad = torch.zeros((P, D), device=DEV)
     head = torch.full((P,), -1, dtype=torch.int32, device=DEV)
     gout = torch.tensor(0.37, device=DEV)
@@ -545,22 +548,26 @@ def test_infonce_gradient_scatter_is_row_sparse_ordered_and_reproducible(n_pix):
     prev = None
     for trial in range(3):
         gsrc = torch.Generator().manual_seed(100 + (trial if trial < 2 else 0))       # trial 2 repeats trial 0's data
-        pix = torch.randint(0, n_pix, (n,), generator=gsrc).to(torch.int32) * (P // n_pix) + (0 if trial != 1 else 1)
+        # per job a candidate list of n_cand pixels (lists of different jobs overlap: multi-hot pixels), Q draws each
+        cands = [torch.randperm(P // 2, generator=gsrc)[:n_cand] * 2 + (0 if trial != 1 else 1) for _ in range(nj)]
+        ia = [torch.randint(0, n_cand, (Q,), generator=gsrc) for _ in range(nj)]
+        pix = torch.cat([c[i] for c, i in zip(cands, ia)]).to(torch.int32)
         src = torch.randn(n, D, generator=gsrc)
-        pd, sd = pix.to(DEV), src.to(DEV)
-        nxt = torch.empty(n, dtype=torch.int32, device=DEV)
-        # build the chains like k_infonce does (atomic exchange; order of arrival is arbitrary)
+        groups = H.group_entries([i.numpy() for i in ia], Q)
+        pd, sd, gd = pix.to(DEV), src.to(DEV), torch.from_numpy(groups).to(DEV)
+        # chain the group leaders like k_infonce does (atomic exchange; order of arrival is arbitrary)
         order = torch.randperm(n, generator=g)
         hh = head.cpu().numpy().copy()
         nn_ = np.zeros(n, np.int32)
         for e in order.numpy():
-            nn_[e] = hh[pix[e]]
-            hh[pix[e]] = e
+            if groups[2][e] > 0:
+                nn_[e] = hh[pix[e]]
+                hh[pix[e]] = e
         head.copy_(torch.from_numpy(hh))
-        nxt.copy_(torch.from_numpy(nn_))
+        nxt = torch.from_numpy(nn_).to(DEV)
         if prev is not None:
             call("u2pl_zero_rows_f32", grad, D, D, prev, prev.numel())
-        call("u2pl_scatter_rows_ordered_f32", grad, D, D, pd, nxt, head, sd, n, gout, 0.25)
+        call("u2pl_scatter_rows_ordered_f32", grad, D, D, pd, nxt, head, gd[0], gd[1], gd[2], sd, n, gout, 0.25)
         prev = pd
         torch.cuda.synchronize()
         assert int((head != -1).sum()) == 0                         # chain heads re-armed

@@ -505,7 +505,7 @@ template <int VPL>  // floats per lane = D / 64
 __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restrict__ rep, long ld, int D,
                           int Q, int K, float inv_temp, float* __restrict__ loss_q,
                           float* __restrict__ ganchor, int* __restrict__ anchor_pix, int* __restrict__ head,
-                          int* __restrict__ next) {
+                          int* __restrict__ next, const int* __restrict__ seg_len) {
     const int job = blockIdx.y;
     const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -603,10 +603,11 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
         const int e = job * Q + q;
         loss_q[e] = lse - l0;
         anchor_pix[e] = pix;
-        // entries that sampled the same pixel (anchors are drawn with replacement; a pixel can also sit in several
-        // class lists) are chained through an integer exchange: the backward pass sums each chain in ascending
-        // entry order, so the gradient needs no floating-point atomics and is reproducible bit for bit
-        if (head) next[e] = atomicExch(head + pix, e);
+        // Anchors are drawn with replacement: the entries of ONE job that sampled the same candidate were grouped on the
+        // host (it drew the indices), seg_len[e] > 0 marks the first entry of such a group.  A pixel can also sit in
+        // several class lists, so the group leaders (at most one per job) are chained through an integer exchange; the
+        // backward pass sums group by group in ascending entry order: no floating-point atomics, reproducible bits.
+        if (head && seg_len[e] > 0) next[e] = atomicExch(head + pix, e);
     }
     // d loss/d cos_j = (softmax_j - [j==0]) * inv_temp ; d cos_j/d a = (fhat_j - cos_j*ahat)/|a|
     const float inv_s = 1.0f / s;
@@ -619,16 +620,17 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
 
 U2PL_API int u2pl_infonce_f32(const void* jobs_dev, int njobs, const float* rep, long ld, int D, int Q, int K,
                               float temp, float* loss_q, float* ganchor, int* anchor_pix, int* head, int* next,
-                              hipStream_t stream) {
+                              const int* seg_len, hipStream_t stream) {
+    if (head && (!next || !seg_len)) return U2PL_EINVAL;
     if (njobs <= 0) return 0;
     dim3 grid(cdiv(Q, 4), njobs), block(256);
     const NceJob* jobs = (const NceJob*)jobs_dev;
     float it = 1.0f / temp;
     switch (D) {
-        case 64: hipLaunchKernelGGL(k_infonce<1>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next); break;
-        case 128: hipLaunchKernelGGL(k_infonce<2>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next); break;
-        case 256: hipLaunchKernelGGL(k_infonce<4>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next); break;
-        case 512: hipLaunchKernelGGL(k_infonce<8>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next); break;
+        case 64: hipLaunchKernelGGL(k_infonce<1>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next, seg_len); break;
+        case 128: hipLaunchKernelGGL(k_infonce<2>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next, seg_len); break;
+        case 256: hipLaunchKernelGGL(k_infonce<4>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next, seg_len); break;
+        case 512: hipLaunchKernelGGL(k_infonce<8>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next, seg_len); break;
         default: return U2PL_EINVAL;
     }
     U2PL_LAUNCH_CHECK();
@@ -682,64 +684,56 @@ U2PL_API int u2pl_scatter_add_rows_f32(float* dst, long ld, int D, const int* pi
 
 // ---------------------------------------------------------------------------
 // Row-sparse, ordered gradient of the anchors (replaces zero-filling the dense (P, D) gradient -- 152 MB at 769^2 --
-// and the float atomicAdd scatter): dst is a PERSISTENT all-zero buffer; the wave of the entry that heads a pixel's
-// chain (head[pix] == e) collects the chain (entries that sampled that pixel), sorts the entry ids ascending and
-// writes  dst[pix] = scale * gout * sum_{e ascending} src[e]  with a plain store; head[pix] is re-armed to -1.
-// The rows written here are cleared again by u2pl_zero_rows_f32 before the next backward pass reuses the buffer.
+// and the float atomicAdd scatter).  dst is a PERSISTENT all-zero buffer.  Host-side grouping (the host drew the anchor
+// indices): order[] lists every job's entries sorted by (candidate, entry), seg_pos[e] / seg_len[e] give the group of
+// leader e inside order[] (seg_len = 0 for non-leaders).  The wave of the leader that heads a pixel's chain
+// (head[pix] == e) collects the chain of leaders (<= one per job), sorts it ascending and adds the rows group by
+// group, member by member -- i.e. in ascending entry order -- then writes dst[pix] = scale * gout * sum with a plain
+// store and re-arms head[pix] = -1.  u2pl_zero_rows_f32 clears the written rows before the buffer is reused.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_scatter_rows_ordered(float* __restrict__ dst, long ld, int D,
                                                               const int* __restrict__ pix, const int* __restrict__ next,
-                                                              int* __restrict__ head, const float* __restrict__ src, int n,
+                                                              int* __restrict__ head, const int* __restrict__ order,
+                                                              const int* __restrict__ seg_pos, const int* __restrict__ seg_len,
+                                                              const float* __restrict__ src, int n,
                                                               const float* __restrict__ gout, float scale) {
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (e >= n) return;
+    if (seg_len[e] <= 0) return;                   // not a group leader
     const int p = pix[e];
     if (head[p] != e) return;                      // not the chain head: the head's wave does the work
     const float sc = scale * (gout ? *gout : 1.0f);
     int myid = 0x7fffffff, cnt = 0;
-    for (int cur = e; cur >= 0; cur = next[cur]) {   // wave-uniform walk (chains are 1-3 entries long in practice)
-        if (lane == (cnt & 63)) myid = cur;
-        if (++cnt == 64) break;
+    for (int cur = e; cur >= 0 && cnt < 64; cur = next[cur]) {   // <= one leader per job (MAXC = 32 jobs)
+        if (lane == cnt) myid = cur;
+        ++cnt;
     }
+    int rank = 0;
+    for (int j = 0; j < cnt; ++j) rank += __shfl(myid, j, 64) < myid;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool act = lane * 4 < D;
-    if (cnt < 64) {
-        // rank of my id among the chain (ids are distinct) -> add the rows in ascending id order
-        int rank = 0;
-        for (int j = 0; j < cnt; ++j) rank += __shfl(myid, j, 64) < myid;
-        for (int r = 0; r < cnt; ++r) {
-            const unsigned long long m = __ballot(lane < cnt && rank == r);
-            const int id = __shfl(myid, __ffsll((long long)m) - 1, 64);
+    for (int r = 0; r < cnt; ++r) {
+        const unsigned long long m = __ballot(lane < cnt && rank == r);
+        const int L = __shfl(myid, __ffsll((long long)m) - 1, 64);
+        const int pos = seg_pos[L], len = seg_len[L];
+        for (int k = 0; k < len; ++k) {            // independent row loads: they pipeline
+            const int id = order[pos + k];
             if (act) {
                 const float4 v = *(const float4*)(src + (long)id * D + lane * 4);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
-        }
-    } else {
-        // a pixel sampled >= 64 times (tiny candidate lists): repeated minimum search over the chain, O(len^2) hops
-        int last = -1;
-        while (true) {
-            int best = 0x7fffffff;
-            for (int cur = e; cur >= 0; cur = next[cur])
-                if (cur > last && cur < best) best = cur;
-            if (best == 0x7fffffff) break;
-            if (act) {
-                const float4 v = *(const float4*)(src + (long)best * D + lane * 4);
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            }
-            last = best;
         }
     }
     if (act) *(float4*)(dst + (long)p * ld + lane * 4) = make_float4(sc * acc.x, sc * acc.y, sc * acc.z, sc * acc.w);
     if (lane == 0) head[p] = -1;
 }
 U2PL_API int u2pl_scatter_rows_ordered_f32(float* dst, long ld, int D, const int* pix, const int* next, int* head,
-                                           const float* src, long n, const float* gout_dev, float scale,
-                                           hipStream_t stream) {
+                                           const int* order, const int* seg_pos, const int* seg_len, const float* src,
+                                           long n, const float* gout_dev, float scale, hipStream_t stream) {
     if (n <= 0) return 0;
     if (D % 4 || D > 256) return U2PL_EINVAL;
-    hipLaunchKernelGGL(k_scatter_rows_ordered, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, ld, D, pix, next, head, src, (int)n,
-                       gout_dev, scale);
+    hipLaunchKernelGGL(k_scatter_rows_ordered, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, ld, D, pix, next, head, order,
+                       seg_pos, seg_len, src, (int)n, gout_dev, scale);
     U2PL_LAUNCH_CHECK();
     return 0;
 }

@@ -91,14 +91,23 @@ def load_state(path, model, optimizer=None, key="model_state"):
     return ckpt
 
 
+def _rng_state():
+    """the four RNG streams of a step as tensors / plain scalars only (torch.load(weights_only=True) accepts the file)"""
+    kind, keys, pos, has_gauss, cached = np.random.get_state()
+    ver, pk, gauss = random.getstate()
+    return {"torch": torch.get_rng_state(), "cuda": torch.cuda.get_rng_state(),
+            "numpy_keys": torch.from_numpy(keys.astype(np.int64)), "numpy_pos": int(pos), "numpy_has_gauss": int(has_gauss),
+            "numpy_cached": float(cached), "python_version": int(ver), "python_keys": torch.tensor(pk, dtype=torch.int64),
+            "python_gauss": gauss}
+
+
 def checkpoint_state(epoch, best, model, teacher, trainer):
     """train_semi.py:210-224 wire format (`module.`-prefixed model_state / teacher_state, torch-SGD optimizer_state,
     best_miou, epoch) + what upstream forgets and a bit-faithful resume needs: the memory bank, the iteration counter
     and the RNG streams (extra keys, ignored by the reference's load_state)."""
     state = {"epoch": epoch, "model_state": state_dict_ddp(model), "optimizer_state": trainer.optimizer_state_dict(),
              "best_miou": best, "cur_iter": trainer.cur_iter,
-             "rng_state": {"torch": torch.get_rng_state(), "cuda": torch.cuda.get_rng_state(), "numpy": np.random.get_state(),
-                           "python": random.getstate()}}
+             "rng_state": _rng_state()}
     if teacher is not None:
         state["teacher_state"] = state_dict_ddp(teacher)
         bank = trainer.memobank
@@ -121,15 +130,16 @@ def restore_extras(ckpt, trainer, steps_per_epoch):
     if rs is not None:
         torch.set_rng_state(rs["torch"])
         torch.cuda.set_rng_state(rs["cuda"])
-        np.random.set_state(rs["numpy"])
-        random.setstate(rs["python"])
+        np.random.set_state(("MT19937", rs["numpy_keys"].numpy().astype(np.uint32), rs["numpy_pos"], rs["numpy_has_gauss"],
+                             rs["numpy_cached"]))
+        random.setstate((rs["python_version"], tuple(int(x) for x in rs["python_keys"]), rs["python_gauss"]))
 
 
 def absolutize_paths(cfg, exp_path):
     """reference configs hold paths relative to the experiment directory (train.sh cd's there); resolve them ONCE so
     that datasets opened lazily in DataLoader workers and the pretrain checkpoint do not depend on the cwd"""
     def fix(d, key):
-        if isinstance(d.get(key), str) and not osp.isabs(d[key]):
+        if isinstance(d.get(key), str) and d[key] and not osp.isabs(d[key]):
             d[key] = osp.normpath(osp.join(exp_path, d[key]))
     ds = cfg["dataset"]
     for sub in (ds, ds.get("train", {}), ds.get("val", {})):

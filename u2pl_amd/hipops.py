@@ -439,11 +439,30 @@ def _nce_state(device, P, D):
     return st
 
 
+def group_entries(ia_per_job, Q):
+    """host-side grouping of the anchor draws (the host drew them: loss_helper.py:179-181): per job, the entries sorted
+    by (candidate index, entry) and, for the first entry of every group of equal candidates, the group's position and
+    length.  -> int32 [3][njobs*Q]: order, seg_pos, seg_len (0 for non-leaders)."""
+    nj = len(ia_per_job)
+    out = np.zeros((3, nj * Q), dtype=np.int32)
+    for j, ia in enumerate(ia_per_job):
+        ia = np.asarray(ia)
+        o = np.argsort(ia, kind="stable")
+        si = ia[o]
+        starts = np.flatnonzero(np.r_[True, si[1:] != si[:-1]])
+        lens = np.diff(np.r_[starts, Q])
+        out[0, j * Q:(j + 1) * Q] = j * Q + o
+        lead = j * Q + o[starts]
+        out[1, lead] = j * Q + starts
+        out[2, lead] = lens
+    return out
+
+
 class _InfoNCE(torch.autograd.Function):
     """rep_rows: (P, D) contiguous view of the student features (requires grad)."""
 
     @staticmethod
-    def forward(ctx, rep_rows, jobs_dev, njobs, Q, K, temp, valid_seg, keepalive):
+    def forward(ctx, rep_rows, jobs_dev, njobs, Q, K, temp, valid_seg, groups, keepalive):
         P, D = rep_rows.shape
         dev = rep_rows.device
         st = _nce_state(dev, P, D)
@@ -451,24 +470,46 @@ class _InfoNCE(torch.autograd.Function):
         ganchor = torch.empty((njobs, Q, D), dtype=torch.float32, device=dev)
         apix = torch.empty((njobs, Q), dtype=torch.int32, device=dev)
         nxt = torch.empty((njobs, Q), dtype=torch.int32, device=dev)
-        call("u2pl_infonce_f32", jobs_dev, njobs, rep_rows, D, D, Q, K, float(temp), loss_q, ganchor, apix, st["head"], nxt)
+        call("u2pl_infonce_f32", jobs_dev, njobs, rep_rows, D, D, Q, K, float(temp), loss_q, ganchor, apix, st["head"], nxt,
+             groups[2])
         loss = torch.empty((), dtype=torch.float32, device=dev)
         call("u2pl_infonce_reduce_f32", loss_q, njobs, Q, 1.0 / valid_seg, loss)
-        ctx.save_for_backward(ganchor, apix, nxt)
+        ctx.save_for_backward(ganchor, apix, nxt, groups)
         ctx.meta = (P, D, njobs * Q, 1.0 / (Q * valid_seg))
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        ganchor, apix, nxt = ctx.saved_tensors
+        ganchor, apix, nxt, groups = ctx.saved_tensors
         P, D, n, scale = ctx.meta
         st = _nce_state(g.device, P, D)
         if st["dirty"] is not None:      # rows written by the previous step's backward (their consumer has long run)
             call("u2pl_zero_rows_f32", st["grad"], D, D, st["dirty"], st["dirty"].numel())
-        call("u2pl_scatter_rows_ordered_f32", st["grad"], D, D, apix, nxt, st["head"], ganchor, n, g.contiguous(),
-             float(scale))
+        call("u2pl_scatter_rows_ordered_f32", st["grad"], D, D, apix, nxt, st["head"], groups[0], groups[1], groups[2],
+             ganchor, n, g.contiguous(), float(scale))
         st["dirty"] = apix
-        return st["grad"], None, None, None, None, None, None, None
+        return st["grad"], None, None, None, None, None, None, None, None
+
+
+def infonce_kernels_once(rep_rows, jobs_dev, njobs, Q, K, temp, valid_seg, groups):
+    """the exact launch sequence of _InfoNCE forward + backward (bench.py's roofline replay): InfoNCE, loss reduce,
+    lazy re-zero of the previous rows, ordered row-sparse scatter"""
+    P, D = rep_rows.shape
+    dev = rep_rows.device
+    st = _nce_state(dev, P, D)
+    loss_q = torch.empty((njobs, Q), dtype=torch.float32, device=dev)
+    ganchor = torch.empty((njobs, Q, D), dtype=torch.float32, device=dev)
+    apix = torch.empty((njobs, Q), dtype=torch.int32, device=dev)
+    nxt = torch.empty((njobs, Q), dtype=torch.int32, device=dev)
+    call("u2pl_infonce_f32", jobs_dev, njobs, rep_rows, D, D, Q, K, float(temp), loss_q, ganchor, apix, st["head"], nxt, groups[2])
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    call("u2pl_infonce_reduce_f32", loss_q, njobs, Q, 1.0 / valid_seg, loss)
+    if st["dirty"] is not None:
+        call("u2pl_zero_rows_f32", st["grad"], D, D, st["dirty"], st["dirty"].numel())
+    call("u2pl_scatter_rows_ordered_f32", st["grad"], D, D, apix, nxt, st["head"], groups[0], groups[1], groups[2], ganchor,
+         njobs * Q, None, 1.0 / (Q * valid_seg))
+    st["dirty"] = apix
+    return loss
 
 
 class _ZeroTimesSum(torch.autograd.Function):
@@ -498,7 +539,7 @@ def infonce_loss(rep_rows, ph1, bank, valid_classes, counts_host, cfg, randint=N
     if randint is None:
         def randint(high, n):
             return torch.randint(high, size=(n,))
-    jobs, idx_chunks = [], []
+    jobs, idx_chunks, ia_list = [], [], []
     for i in range(valid_seg):
         n_cand = int(counts_host[0][i])
         vc = valid_classes[i]
@@ -507,6 +548,7 @@ def infonce_loss(rep_rows, ph1, bank, valid_classes, counts_host, cfg, randint=N
             inn = randint(bank.length[vc], Q * K)
             jobs.append((i, vc))
             idx_chunks += [ia.to(torch.int64), inn.to(torch.int64)]
+            ia_list.append(ia.numpy())
     infonce_loss.last_njobs = len(jobs)
     if not jobs:
         return None
@@ -527,8 +569,9 @@ def infonce_loss(rep_rows, ph1, bank, valid_classes, counts_host, cfg, randint=N
         off += Q + Q * K
     assert query("u2pl_infonce_job_bytes") == 56
     jobs_dev = h2d(torch.from_numpy(jb), dev)
+    groups = h2d(torch.from_numpy(group_entries(ia_list, Q)), dev)
     if REPLAY is not None:
-        REPLAY["infonce"] = (rep_rows.detach(), jobs_dev, len(jobs), Q, K, float(cfg["temperature"]), valid_seg,
+        REPLAY["infonce"] = (rep_rows.detach(), jobs_dev, len(jobs), Q, K, float(cfg["temperature"]), valid_seg, groups,
                              (idx_all, ph1, bank))
-    return _InfoNCE.apply(rep_rows, jobs_dev, len(jobs), Q, K, float(cfg["temperature"]), valid_seg,
+    return _InfoNCE.apply(rep_rows, jobs_dev, len(jobs), Q, K, float(cfg["temperature"]), valid_seg, groups,
                           (idx_all, ph1))

@@ -101,12 +101,10 @@ def replay_hbm_group(reps=10):
             dd, n, D, ld, mx = R["append"][:5]
             out["bank_append_us"] = timed(lambda: _lib.call("u2pl_bank_append_multi_f32", dd, n, D, ld, mx))
         if "infonce" in R:
-            rep_rows, jobs_dev, njobs, Q, K, temp, valid_seg, keep = R["infonce"]
+            rep_rows, jobs_dev, njobs, Q, K, temp, valid_seg, groups, keep = R["infonce"]
 
             def nce():
-                r = rep_rows.requires_grad_(True)
-                r.grad = None
-                H._InfoNCE.apply(r, jobs_dev, njobs, Q, K, temp, valid_seg, keep).backward()
+                H.infonce_kernels_once(rep_rows, jobs_dev, njobs, Q, K, temp, valid_seg, groups)
             out["infonce_fwd_bwd_us"] = timed(nce)
     finally:
         H.REPLAY = saved

@@ -97,3 +97,42 @@ def _syncbn_protocol_case(rank, world):
 def test_syncbn_shifted_sum_protocol_matches_global_batch_stats():
     for em, ev in _run(_syncbn_protocol_case):
         assert em < 1e-12 and ev < 1e-10
+
+
+def _bucket_case(rank, world):
+    """u2pl_amd.nn.ParamArena bucketed all-reduce (product code; the arena itself is plain torch): buckets complete as
+    their parameters are marked ready (reverse order, like backward), are launched asynchronously from the hook, one
+    parameter never gets a gradient (launched by finish_allreduce), result == one flat all-reduce"""
+    os.environ["U2PL_BUCKET_MB"] = "0.002"          # ~524 floats per bucket
+    from u2pl_amd import nn as K
+    g = torch.Generator().manual_seed(7)
+    shapes = [(64, 3, 3, 3), (64,), (64,), (128, 64, 1, 1), (128,), (300,), (19, 128, 1, 1), (19,)]
+    params = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    arena = K.ParamArena([params[:5], params[5:]])
+    assert len(arena.buckets) >= 4 and arena.buckets[-1][1] == arena.n
+    out = []
+    for step in range(2):
+        arena.zero_grad()
+        gs = torch.Generator().manual_seed(100 * step + rank)
+        launched_early = 0
+        for p in params:
+            p._u2pl_grad.add_(torch.randn(p.shape, generator=gs))
+        local = arena.grad.clone()                     # (the hooks reduce finished buckets IN PLACE right away)
+        for i in reversed(range(len(params))):
+            if i != 5:                                 # parameter 5 never reports (e.g. an unused head)
+                K._mark_ready(params[i]._u2pl_grad)
+        launched_early = sum(w is not None for w in arena._works)
+        arena.finish_allreduce()
+        ref = local.clone()
+        # what one flat all-reduce of the local gradients gives
+        dist.all_reduce(ref)
+        out.append((bool(torch.equal(arena.grad, ref)), launched_early, len(arena.buckets)))
+    return out
+
+
+def test_bucketed_gradient_allreduce_overlaps_and_equals_flat_allreduce():
+    r0, r1 = _run(_bucket_case)
+    for r in (r0, r1):
+        for same, early, nb in r:
+            assert same
+            assert 1 <= early < nb         # some buckets went out from the hooks, the one with the silent parameter did not

@@ -86,6 +86,15 @@ def _grad_sink(p):
     return getattr(p, "_u2pl_grad", None)
 
 
+def _mark_ready(sink):
+    """the gradient of this parameter is complete for this step: lets the arena launch the all-reduce of a finished
+    bucket while the rest of the backward pass is still running (no-op without a process group)"""
+    if sink is not None:
+        owner = getattr(sink, "_u2pl_ready", None)
+        if owner is not None:
+            owner[0].mark_ready(owner[1])
+
+
 # ------------------------------------------------------------------ convolution
 # Stride-1 "same" 3x3 convolutions can run in Winograd form (csrc/wino.hip): F(4x4,3x3) does 1/4 of the direct
 # multiplies (F(2x2,3x3): 4/9) in fp32 on the same matrix cores, at the cost of two HBM-bound transform passes.
@@ -259,12 +268,15 @@ class _ConvFn(torch.autograd.Function):
                         sink.add_(tgt[:Cout])
                     else:
                         dw = tgt[:Cout] if Cp != Cout else tgt
+        if ctx.needs_input_grad[1]:
+            _mark_ready(ctx.wsink)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             sums = torch.empty(2 * Cp, dtype=torch.float64, device=dev)
             wsb = _ws(query("u2pl_colreduce_workspace_bytes", M, 1, Cp), dev)
             call("u2pl_colsum_f32", gy, ldg, M, 1, Cp, wsb, sums)
             if ctx.bsink is not None:
                 call("u2pl_sums_to_f32", sums, Cout, 1.0, 1, ctx.bsink)
+                _mark_ready(ctx.bsink)
             else:
                 db = torch.empty(Cout, dtype=torch.float32, device=dev)
                 call("u2pl_sums_to_f32", sums, Cout, 1.0, 0, db)
@@ -366,6 +378,8 @@ class _BNFn(torch.autograd.Function):
             if ctx.gsink is not None:
                 call("u2pl_sums_to_f32", sums[C:], C, 1.0, 1, ctx.gsink)
                 call("u2pl_sums_to_f32", sums, C, 1.0, 1, ctx.bsink)
+                _mark_ready(ctx.gsink)
+                _mark_ready(ctx.bsink)
             else:
                 dgamma = torch.empty(C, dtype=torch.float32, device=dev)
                 dbeta = torch.empty(C, dtype=torch.float32, device=dev)
@@ -639,6 +653,7 @@ class ParamArena:
         # padding stays zero in every arena (zero grad, zero weight => SGD / EMA keep it zero)
         self.flat = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.n, dtype=torch.float32, device=dev) if with_grad else None
+        self._pidx = []
         for p, off in zip(self.params, offs):
             n = p.numel()
             view = self.flat[off:off + n].as_strided(p.shape, p.stride())
@@ -646,8 +661,11 @@ class ParamArena:
             p.data = view
             if with_grad:
                 gv = self.grad[off:off + n].as_strided(p.shape, p.stride())
+                gv._u2pl_ready = (self, len(self._pidx))
+                self._pidx.append(off)
                 p._u2pl_grad = gv
                 p.grad = gv
+        self._build_buckets(offs, float(os.environ.get("U2PL_BUCKET_MB", "32")))
         self.momentum_buf = None
         self.steps = 0
         self._offs = {id(p): off for p, off in zip(self.params, offs)}
@@ -659,8 +677,65 @@ class ParamArena:
         off = self._offs[id(p)]
         return self.momentum_buf[off:off + p.numel()].as_strided(p.shape, p.stride())
 
+    # ---- bucketed, overlapped gradient all-reduce (the reference gets this from DDP: train_semi.py:114-120) ----
+    def _build_buckets(self, offs, bucket_mb):
+        """contiguous slices of the gradient arena of ~bucket_mb each; backward produces gradients roughly from the end
+        of the arena towards its start, so the buckets complete one after the other while backward is still running"""
+        self.buckets, self._bucket_of = [], []
+        if self.grad is None:
+            return
+        lim = max(1, int(bucket_mb * (1 << 20) / 4))
+        lo, count = 0, 0
+        ends = offs[1:] + [self.n]
+        for i, end in enumerate(ends):
+            self._bucket_of.append(len(self.buckets))
+            count += 1
+            if end - lo >= lim or i == len(ends) - 1:
+                self.buckets.append([lo, end, count])
+                lo, count = end, 0
+        self._pending = [b[2] for b in self.buckets]
+        self._works = [None] * len(self.buckets)
+        self._streams = ()
+
     def zero_grad(self):
         self.grad.zero_()
+        if self.buckets:
+            self._pending = [b[2] for b in self.buckets]
+            self._works = [None] * len(self.buckets)
+            if self.grad.is_cuda:
+                ws = _WGRAD["stream"]
+                self._streams = tuple(x for x in (torch.cuda.current_stream(), ws) if x is not None)
+
+    def _launch(self, b):
+        lo, hi, _ = self.buckets[b]
+        if self.grad.is_cuda:       # the bucket's producers ran on the main stream (BN, bias) and on the wgrad side stream
+            cur = torch.cuda.current_stream()
+            for st in self._streams:
+                if st != cur:
+                    cur.wait_stream(st)
+        self._works[b] = dist.all_reduce(self.grad[lo:hi], async_op=True)
+
+    def mark_ready(self, pidx):
+        if _world() <= 1 or not self.buckets or os.environ.get("U2PL_NO_BUCKET_OVERLAP") is not None:
+            return
+        b = self._bucket_of[pidx]
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and self._works[b] is None:
+            self._launch(b)
+
+    def finish_allreduce(self):
+        """after backward: reduce whatever was not launched from the hooks (parameters without a gradient this step,
+        overlap disabled) and make the current stream wait for every bucket.  SUM; the mean is folded into sgd_step."""
+        if _world() <= 1:
+            return
+        if not self.buckets:
+            dist.all_reduce(self.grad)
+            return
+        for b in range(len(self.buckets)):
+            if self._works[b] is None:
+                self._launch(b)
+        for w in self._works:
+            w.wait()
 
     def sgd_step(self, lrs, momentum, weight_decay, grad_scale=1.0):
         """torch.optim.SGD(momentum, weight_decay) semantics with per-group lr."""

@@ -184,8 +184,9 @@ class SemiTrainer:
     def _reduce_grads_and_step(self, lrs):
         K.wgrad_stream_sync()   # weight gradients are produced on a side stream
         W = _world()
-        if W > 1:
-            dist.all_reduce(self.arena.grad)  # one flat RCCL all-reduce (DDP mean folded into the SGD launch)
+        # bucketed all-reduce: most buckets were launched from the backward hooks and overlapped with it; this
+        # launches the rest and joins them (DDP's mean is folded into the SGD launch)
+        self.arena.finish_allreduce()
         self.arena.sgd_step(lrs, self.momentum, self.weight_decay, grad_scale=1.0 / W)
 
     def train_step(self, image_l, label_l, image_u, epoch, cutmix_boxes=None, randint=None, debug=None):
@@ -372,8 +373,7 @@ class SupTrainer:
         loss.backward()
         K.wgrad_stream_sync()
         W = _world()
-        if W > 1:
-            dist.all_reduce(self.arena.grad)
+        self.arena.finish_allreduce()
         self.arena.sgd_step(lrs, self.momentum, self.weight_decay, grad_scale=1.0 / W)
         z = torch.zeros((), device=loss.device)
         meters = torch.stack((loss.detach(), z, z))

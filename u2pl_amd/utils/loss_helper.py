@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from .. import hipops as H
-from .utils import enqueue_all_classes
+from .utils import enqueue_all_classes, exchange_counts
 
 
 def compute_unsupervised_loss(predict, target, percent, pred_teacher):
@@ -57,9 +57,11 @@ def contra_memobank_core(rep, lbits, num_labeled, prob_l, prob_u, low_mask, high
     with torch.no_grad():
         ph1 = H.contra_phase1(rep_t_rows, D, D, prob, pstr, lbits, low_mask.contiguous(), high_mask.contiguous(),
                               num_labeled, C, h, w, cfg)
-        counts = ph1.counts.cpu().numpy()  # the one host sync: RNG bounds live on the host (loss_helper.py:179-196)
+        # the ONE host sync of the step: the RNG bounds live on the host (loss_helper.py:179-196).  Under a process group
+        # the ranks' key counts ride along (gathered on the device first), so the key exchange needs no second sync.
+        counts, all_neg = exchange_counts(ph1.counts, C)
         ph1.counts_host = counts
-        new_keys = enqueue_all_classes(memobank, rep_t_rows, D, ph1.idx[2], counts[2], C)
+        new_keys = enqueue_all_classes(memobank, rep_t_rows, D, ph1.idx[2], counts[2], C, all_counts=all_neg)
     valid_classes = [i for i in range(C) if counts[1][i] > 0]
     LAST_STATS.update(n_keys=int(sum(new_keys)), valid_seg=len(valid_classes), njobs=0,
                       Q=int(cfg["num_queries"]), K=int(cfg["num_negatives"]))

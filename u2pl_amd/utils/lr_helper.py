@@ -137,8 +137,7 @@ class ArenaSGD:
         from .. import nn as K
         K.wgrad_stream_sync()
         W = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        if W > 1:
-            dist.all_reduce(self.arena.grad)
+        self.arena.finish_allreduce()
         self.arena.sgd_step([g["lr"] for g in self.param_groups], self.momentum, self.weight_decay, grad_scale=1.0 / W)
 
     def _mom(self, p):

@@ -36,10 +36,23 @@ def gather_keys(keys):
     return torch.cat([o[:k] for o, k in zip(outs, ns)])
 
 
-def enqueue_all_classes(bank, rows, ld, idx, counts_c, C):
+def exchange_counts(counts_dev, C):
+    """phase-1 list lengths (u32 [3][32] on the device) -> host (this rank's [3][32]) and, under a process group, every
+    rank's negative-key counts [W][C]: the all-gather runs on the device BEFORE the single device-to-host copy."""
+    W = _world()
+    if W == 1:
+        return counts_dev.cpu().numpy(), None
+    outs = [torch.empty_like(counts_dev) for _ in range(W)]
+    dist.all_gather(outs, counts_dev)
+    host = torch.stack(outs).cpu().numpy()                   # [W][3][32]: the one sync
+    return host[dist.get_rank()], host[:, 2, :C].astype(np.int64)
+
+
+def enqueue_all_classes(bank, rows, ld, idx, counts_c, C, all_counts=None):
     """dequeue_and_enqueue for every class of one step (loss_helper.py:143-150 -> utils.py:27-47) with ONE
     count exchange and ONE padded key all-gather instead of a barrier + two object collectives per class.
-    idx[c]: int32 pixel list of class c, counts_c[c]: its length.  Returns the gathered batch size per class."""
+    idx[c]: int32 pixel list of class c, counts_c[c]: its length; all_counts: [W][C] from exchange_counts (saves the
+    exchange + host sync here).  Returns the gathered batch size per class."""
     W = _world()
     D = bank.D
     n_loc = [int(counts_c[c]) for c in range(C)]
@@ -47,11 +60,13 @@ def enqueue_all_classes(bank, rows, ld, idx, counts_c, C):
         bank.append_multi([(c, rows, n_loc[c], idx[c]) for c in range(C)], ld)
         return n_loc
     dev = rows.device
-    tot = sum(n_loc)
-    cnt = H.h2d(torch.tensor(n_loc, dtype=torch.int64), dev)
-    cnts = [torch.zeros_like(cnt) for _ in range(W)]
-    dist.all_gather(cnts, cnt)
-    cnts = torch.stack(cnts).cpu().numpy()                 # [W][C] -- the single host sync of the exchange
+    if all_counts is not None:
+        cnts = np.asarray(all_counts)
+    else:
+        cnt = H.h2d(torch.tensor(n_loc, dtype=torch.int64), dev)
+        cnts = [torch.zeros_like(cnt) for _ in range(W)]
+        dist.all_gather(cnts, cnt)
+        cnts = torch.stack(cnts).cpu().numpy()             # [W][C]
     m = int(cnts.sum(1).max())
     if m == 0:
         bank.append_multi([(c, rows, 0, None) for c in range(C)], D)

@@ -40,6 +40,9 @@ def parse():
                          "near-uniform, which would leave the contrastive path (anchors need p>0.3) idle")
     ap.add_argument("--no-calibrate", action="store_true", help="round-1 workload: classifier last layer x sharpen only")
     ap.add_argument("--no-bank-prefill", action="store_true")
+    ap.add_argument("--bf16", action="store_true",
+                    help="BASELINE configs[4] (config 5): student convolutions on the bf16 matrix cores (fp32 accumulate, fp32 "
+                         "master weights, fp32 EMA teacher); a SEPARATE line, never the headline (use with --crop 801)")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     return ap.parse_args()
 
@@ -121,6 +124,9 @@ def main():
     from u2pl_amd.models.model_helper import ModelBuilder
     from u2pl_amd.trainer import SemiTrainer
     from u2pl_amd.utils.loss_helper import get_criterion
+    if args.bf16:
+        from u2pl_amd import nn as KN0
+        KN0.CONV_ALGO["bf16"] = 1
 
     torch.manual_seed(2)
     np.random.seed(2)
@@ -185,15 +191,18 @@ def main():
         dist.barrier()
     from u2pl_amd import nn as KN
     wt = KN.CONV_ALGO["wino"]
-    conv_algo = ("fp32 implicit GEMM on v_mfma_f32_32x32x2_f32 for every layer (U2PL_CONV_WINO=0)" if wt not in (2, 4) else
+    conv_algo = ("student: bf16-operand implicit GEMM on v_mfma_f32_32x32x16_bf16 (fwd, dgrad, wgrad; direct, no Winograd); "
+                 "teacher: fp32 as in the headline" if args.bf16 else
+                 "fp32 implicit GEMM on v_mfma_f32_32x32x2_f32 for every layer (U2PL_CONV_WINO=0)" if wt not in (2, 4) else
                  f"fp32 Winograd F({wt}x{wt},3x3) for the stride-1 3x3 layers whose tile padding leaves >= "
                  f"{KN.CONV_ALGO['min_gain']}x fewer multiplies (forward, data and weight gradients; component products on "
                  "the same fp32 MFMA kernel), direct fp32 implicit GEMM elsewhere; U2PL_CONV_WINO=0|2|4 selects")
     if rank == 0:
         out = {
-            "metric": "train images/sec at 769x769 (R101-DeepLabv3+)", "value": round(value, 4), "unit": "images/s",
+            "metric": "train images/sec at %dx%d (R101-DeepLabv3+)" % (args.crop, args.crop), "value": round(value, 4), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 (student conv operands; fp32 accumulate / tensors / master weights / teacher)" if args.bf16 else "f32",
             "data": ("synthetic (N(0,1) images; random-init weights put into a trained-like state: BN running statistics and "
                      "the classifier's last layer calibrated on the synthetic batches to confident, class-balanced "
                      "predictions with logit std %g, student = teacher, labeled targets = teacher arg-max; lr 1e-6 so that "

@@ -184,6 +184,23 @@ int u2pl_wino_wgrad_finish_f32(const float* part, int nsplit, int O, int C, int 
                                hipStream_t stream);
 int u2pl_wino_output_f32(const float* Mb, int N, int H, int W, int O, int dil, int mt, const float* bias, float* y,
                          long ldy, float* stats_partial, const float* pivot, hipStream_t stream);
+/* BASELINE configs[4] ("config 5": reduced-precision student, fp32 EMA teacher / master weights): the same three
+ * convolution products with the operands rounded to bf16 (RNE) while they are staged into LDS and multiplied on the
+ * bf16 matrix cores (v_mfma_f32_32x32x16_bf16) with fp32 accumulation; every tensor in HBM stays fp32.  Arguments as the
+ * f32 entry points above. */
+int u2pl_conv2d_fwd_bf16op_f32(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, int N,
+                               int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S, int stride,
+                               int pad, int dil, hipStream_t stream);
+int u2pl_conv2d_fwd_bnstats_bf16op_f32(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
+                                       int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S,
+                                       int stride, int pad, int dil, const float* pivot, float* stats_partial,
+                                       hipStream_t stream);
+int u2pl_conv2d_dgrad_bf16op_f32(const float* dy, long lddy, const float* wT, float* dx, long lddx, int N, int Hin,
+                                 int Win, int Cin, int Hout, int Wout, int Cout, int R, int S, int stride, int pad,
+                                 int dil, hipStream_t stream);
+int u2pl_conv2d_wgrad_bf16op_f32(const float* dy, long lddy, const float* x, long ldx, float* dw, void* workspace,
+                                 int accumulate, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R,
+                                 int S, int stride, int pad, int dil, hipStream_t stream);
 /* autograd of nn.Conv2d under loss.backward() (train_semi.py:527): data and weight gradients */
 int u2pl_conv2d_dgrad_f32(const float* dy, long lddy, const float* wT, float* dx, long lddx, int N, int Hin,
                           int Win, int Cin, int Hout, int Wout, int Cout, int R, int S, int stride, int pad,

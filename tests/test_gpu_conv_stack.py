@@ -376,3 +376,109 @@ def test_full_size_winograd_agrees_with_direct_kernel(N, Cin, Cout, H, d):
         print(name, "max |wino - direct|", err, "scale", scale)
         assert err <= 2e-4 * scale, (name, err, scale)
     assert lin.abs().max().item() <= 2e-4 * res[0][0].abs().max().item()
+
+
+# ------------------------------------------------------------------ config 5: bf16-operand products
+BF16_CASES = [
+    # Cin, Cout, k, stride, dil, H, bias, N
+    (256, 256, 3, 1, 2, 49, False, 2),
+    (1024, 256, 1, 1, 1, 33, False, 3),
+    (128, 128, 3, 2, 1, 33, False, 2),     # strided
+    (512, 256, 3, 1, 1, 41, True, 2),
+    (256, 19, 1, 1, 1, 29, True, 2),       # narrow head (padded gradient columns)
+    (2048, 256, 3, 1, 12, 25, False, 2),   # ASPP
+    (64, 64, 3, 1, 1, 37, False, 2),       # 64-wide tiles
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,dil,H,bias,N", BF16_CASES)
+def test_bf16_operand_conv_matches_bf16_rounded_reference(Cin, Cout, k, stride, dil, H, bias, N):
+    """U2PL_CONV_BF16 (BASELINE configs[4]): forward, data gradient and weight gradient with operands rounded to bf16
+    (RNE) in LDS + fp32 accumulation == an fp32 convolution of the bf16-ROUNDED tensors (torch CPU), to fp32
+    summation-order accuracy; the teacher-style call (no gradient recorded) stays on the fp32 kernel."""
+    Kn = K()
+    saved = dict(Kn.CONV_ALGO)
+    Kn.CONV_ALGO.update(bf16=1)
+    try:
+        g = torch.Generator().manual_seed(Cin + Cout + k + H)
+        W = H + 3
+        pad = dil * (k // 2)
+        rb = lambda t: t.bfloat16().float()
+        x = torch.randn(N, Cin, H, W, generator=g)
+        ref = nn.Conv2d(Cin, Cout, k, stride=stride, padding=pad, dilation=dil, bias=bias)
+        with torch.no_grad():
+            ref.weight.copy_(torch.randn(ref.weight.shape, generator=g) / (Cin * k * k) ** 0.5)
+            if bias:
+                ref.bias.copy_(torch.randn(Cout, generator=g))
+        w = ref.weight.detach().clone()
+        # forward reference: conv(bf16(x), bf16(w)) + bias in fp32
+        yr = F.conv2d(rb(x), rb(w), ref.bias.detach() if bias else None, stride=stride, padding=pad, dilation=dil)
+        gy = torch.randn(yr.shape, generator=g)
+        # backward references: dgrad = conv_transpose(bf16(gy), bf16(w)); wgrad = corr(bf16(gy), bf16(x)); bias grad in fp32
+        xr = rb(x).requires_grad_(True)
+        wr = rb(w).requires_grad_(True)
+        F.conv2d(xr, wr.detach(), None, stride=stride, padding=pad, dilation=dil).backward(rb(gy))
+        F.conv2d(xr.detach(), wr, None, stride=stride, padding=pad, dilation=dil).backward(rb(gy))
+        mine = Kn.Conv2d(Cin, Cout, k, stride=stride, padding=pad, dilation=dil, bias=bias).to(DEV)
+        with torch.no_grad():
+            mine.weight.copy_(w.to(DEV))
+            if bias:
+                mine.bias.copy_(ref.bias.detach().to(DEV))
+        xd = x.to(DEV).contiguous(memory_format=CL).requires_grad_(True)
+        yd = mine(xd)
+        _close(yd, yr, rtol=2e-5, atol=2e-5, what="bf16 fwd")
+        yd.backward(gy.to(DEV).contiguous(memory_format=CL))
+        _close(xd.grad, xr.grad, rtol=2e-5, atol=2e-5, what="bf16 dgrad")
+        _close(mine.weight.grad, wr.grad, rtol=5e-5, atol=5e-5, what="bf16 wgrad")
+        if bias:
+            _close(mine.bias.grad, gy.sum(dim=(0, 2, 3)), rtol=3e-4, what="bgrad")
+        # rounding really happened (vs the un-rounded fp32 product) and the no-grad call is the fp32 kernel
+        y32 = F.conv2d(x, w, ref.bias.detach() if bias else None, stride=stride, padding=pad, dilation=dil)
+        assert (yd.detach().cpu() - y32).abs().max() > 1e-4
+        with torch.no_grad():
+            yt = mine(x.to(DEV).contiguous(memory_format=CL))
+        _close(yt, y32, what="teacher-style call stays fp32")
+    finally:
+        Kn.CONV_ALGO.update(saved)
+
+
+def test_bf16_student_training_step_tracks_the_fp32_step():
+    """one semi-supervised step with the bf16 student: finite, the three losses within 2 % of the fp32 step's (same
+    weights / inputs / draws), teacher path bit-identical (pseudo labels equal)"""
+    import numpy as np
+    from u2pl_amd import configs
+    from u2pl_amd.models.model_helper import ModelBuilder
+    from u2pl_amd.trainer import SemiTrainer
+    from u2pl_amd.utils.loss_helper import get_criterion
+    Kn = K()
+    S, B = 97, 2
+    cfg = configs.cityscapes_semi(arch="resnet50", crop=S, batch_size=B, sync_bn=False, epochs=20)
+    cfg["criterion"]["kwargs"]["min_kept"] = 4000
+    cfg["trainer"]["contrastive"]["current_class_threshold"] = 0.055
+    torch.manual_seed(0)
+    sd = {k: v.detach().clone() for k, v in ModelBuilder(cfg["net"]).state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    il, iu = torch.randn(B, 3, S, S, generator=g).to(DEV), torch.randn(B, 3, S, S, generator=g).to(DEV)
+    ll = torch.randint(0, 19, (B, S, S), generator=g).to(DEV)
+    out = {}
+    saved = dict(Kn.CONV_ALGO)
+    try:
+        for mode in (0, 1):
+            Kn.CONV_ALGO.update(bf16=mode)
+            model, teacher = ModelBuilder(cfg["net"]), ModelBuilder(cfg["net"])
+            model.load_state_dict(sd), teacher.load_state_dict(sd)
+            for m in list(model.modules()) + list(teacher.modules()):
+                if isinstance(m, nn.Dropout2d):
+                    m.p = 0.0      # (device RNG draws differ between the two runs; the comparison is about the conv arithmetic)
+            tr = SemiTrainer(cfg, model.to(DEV), teacher.to(DEV), get_criterion(cfg), steps_per_epoch=5)
+            np.random.seed(1), torch.manual_seed(1)
+            dbg = {}
+            m = tr.train_step(il, ll, iu, epoch=0, debug=dbg)
+            out[mode] = ([float(v) for v in m.cpu()], dbg["label_u"].cpu())
+    finally:
+        Kn.CONV_ALGO.update(saved)
+    print("fp32", out[0][0], "bf16", out[1][0])
+    assert all(np.isfinite(out[1][0]))
+    assert torch.equal(out[0][1], out[1][1])                     # teacher (fp32) pseudo labels identical
+    for a, b in zip(out[0][0], out[1][0]):
+        assert abs(a - b) <= 0.02 * max(1.0, abs(a)), (out[0][0], out[1][0])

@@ -42,7 +42,20 @@ __device__ __forceinline__ bool gather_coord(int base, int tap, int step, int lo
 }
 
 // WM = wave rows of the block (2: 4 waves / 256 threads; 4: 8 waves / 512 threads with half the rows per wave)
-template <int TM, int TN, int WM = 2>
+// BF: the A / B tiles are rounded to bf16 (round-to-nearest-even) on their way into LDS and multiplied on the bf16
+// matrix cores (v_mfma_f32_32x32x16_bf16, 16x the f32-input rate) with fp32 accumulation -- BASELINE configs[4]
+// ("config 5": reduced-precision student, fp32 master weights / EMA teacher).  Tensors in HBM stay fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define LDPH (BK + 8)   // LDS row pitch of the bf16 tiles (elements): 80 B, 16 B aligned
+__device__ __forceinline__ unsigned bf16_rne(float f) {      // fp32 -> bf16 bits, round to nearest even (NaN stays NaN)
+    const unsigned u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ uint2 pack4_bf16(float4 v) {
+    return make_uint2(bf16_rne(v.x) | (bf16_rne(v.y) << 16), bf16_rne(v.z) | (bf16_rne(v.w) << 16));
+}
+
+template <int TM, int TN, int WM = 2, bool BF = false>
 __global__ __launch_bounds__(128 * WM, WM) void k_conv_igemm(const float* __restrict__ x, long ldx,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
@@ -60,6 +73,8 @@ __global__ __launch_bounds__(128 * WM, WM) void k_conv_igemm(const float* __rest
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                  // [2][BM][LDP]
     float* Bs = smem + 2 * BM * LDP;   // [2][BN][LDP]
+    unsigned short* Ah = (unsigned short*)smem;          // BF: [2][BM][LDPH] bf16
+    unsigned short* Bh = Ah + 2 * BM * LDPH;             //     [2][BN][LDPH]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -112,6 +127,13 @@ __global__ __launch_bounds__(128 * WM, WM) void k_conv_igemm(const float* __rest
         }
     };
     auto store_chunk = [&](int buf, const float4 (&ra)[RA], const float4 (&rb)[RB]) {
+        if (BF) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) *(uint2*)(Ah + ((long)buf * BM + r0 + RPP * i) * LDPH + kq * 4) = pack4_bf16(ra[i]);
+#pragma unroll
+            for (int i = 0; i < RB; ++i) *(uint2*)(Bh + ((long)buf * BN + r0 + RPP * i) * LDPH + kq * 4) = pack4_bf16(rb[i]);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < RA; ++i) *(float4*)(As + ((long)buf * BM + r0 + RPP * i) * LDP + kq * 4) = ra[i];
 #pragma unroll
@@ -128,6 +150,24 @@ __global__ __launch_bounds__(128 * WM, WM) void k_conv_igemm(const float* __rest
 
     const int li = lane & 31, lh = lane >> 5;
     auto mma = [&](int buf) {
+        if (BF) {   // lane (li, lh) supplies row li, k = 16*gk + 8*lh + (0..7) of A and of B: one ds_read_b128 each
+            const unsigned short* Ab = Ah + ((long)buf * BM + wm * 32 * TM + li) * LDPH + 8 * lh;
+            const unsigned short* Bb = Bh + ((long)buf * BN + wn * 32 * TN + li) * LDPH + 8 * lh;
+#pragma unroll
+            for (int gk = 0; gk < BK / 16; ++gk) {
+                bf16x8 a8[TM], b8[TN];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) a8[a] = __builtin_bit_cast(bf16x8, *(const uint4*)(Ab + a * 32 * LDPH + gk * 16));
+#pragma unroll
+                for (int b = 0; b < TN; ++b) b8[b] = __builtin_bit_cast(bf16x8, *(const uint4*)(Bb + b * 32 * LDPH + gk * 16));
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[a], b8[b], acc[a][b], 0, 0, 0);
+            }
+            return;
+        }
         const float* Ab = As + ((long)buf * BM + wm * 32 * TM + li) * LDP + 4 * lh;
         const float* Bb = Bs + ((long)buf * BN + wn * 32 * TN + li) * LDP + 4 * lh;
 #pragma unroll
@@ -253,7 +293,7 @@ __global__ __launch_bounds__(128 * WM, WM) void k_conv_igemm(const float* __rest
     }
 }
 
-template <int TM, int TN, int WM = 2>
+template <int TM, int TN, int WM = 2, bool BF = false>
 static int launch_igemm(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
                         const ConvGeom& g, long m_begin, long m_end, hipStream_t stream, float* stats = nullptr,
                         const float* pivot = nullptr, int batch = 1, long zx = 0, long zw = 0, long zy = 0) {
@@ -262,7 +302,7 @@ static int launch_igemm(const float* x, long ldx, const float* w, const float* b
     const size_t lds = (size_t)2 * (BM + BN) * LDP * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_conv_igemm<TM, TN, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_conv_igemm<TM, TN, WM, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     // byte extents of the gathered tensor and of the weight matrix (raw-buffer descriptors)
@@ -270,7 +310,7 @@ static int launch_igemm(const float* x, long ldx, const float* w, const float* b
     const long wb = (long)g.Cout * g.R * g.S * g.Cin * 4;
     if (xb >= (1L << 31) || wb >= (1L << 31)) return U2PL_EINVAL;
     dim3 grid((unsigned)cdiv(m_end - m_begin, BM), (unsigned)cdiv(g.Cout, BN), (unsigned)batch);
-    hipLaunchKernelGGL((k_conv_igemm<TM, TN, WM>), grid, dim3(128 * WM), lds, stream, x, ldx, w, bias, y, ldy, g, (unsigned)xb,
+    hipLaunchKernelGGL((k_conv_igemm<TM, TN, WM, BF>), grid, dim3(128 * WM), lds, stream, x, ldx, w, bias, y, ldy, g, (unsigned)xb,
                        (unsigned)wb, m_begin, m_end, stats, pivot, zx, zw, zy);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -315,10 +355,19 @@ static IgemmPlan plan_igemm(const ConvGeom& g, int batch = 1) {
 }
 static int run_igemm(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
                      const ConvGeom& g, hipStream_t stream, float* stats = nullptr, const float* pivot = nullptr,
-                     int batch = 1, long zx = 0, long zw = 0, long zy = 0) {
+                     int batch = 1, long zx = 0, long zw = 0, long zy = 0, bool bf = false) {
     if (g.Cin % BK) return U2PL_EINVAL;
     const long M = (long)g.N * g.Hout * g.Wout;
     const IgemmPlan p = plan_igemm(g, batch);
+    if (bf) {   // bf16-operand variants of the same tile shapes
+        if (g.Cout <= 64) return launch_igemm<2, 1, 2, true>(x, ldx, w, bias, y, ldy, g, 0, M, stream, stats, pivot, batch, zx, zw, zy);
+        int rc = launch_igemm<1, 2, 4, true>(x, ldx, w, bias, y, ldy, g, 0, p.m_body, stream, stats, pivot, batch, zx, zw, zy);
+        if (rc || p.nblk_tail == 0) return rc;
+        float* st = stats ? stats + (long)p.nblk_body * 2 * g.Cout : nullptr;
+        if (p.tail_tm == 2) return launch_igemm<2, 2, 2, true>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy);
+        if (p.tail_tn == 2) return launch_igemm<1, 2, 2, true>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy);
+        return launch_igemm<1, 1, 2, true>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy);
+    }
     if (g.Cout <= 64) return launch_igemm<2, 1>(x, ldx, w, bias, y, ldy, g, 0, M, stream, stats, pivot, batch, zx, zw, zy);
     // 128x128 body tiles are computed by 8 waves (4x2, 32x64 outputs each; 4 waves per SIMD with two resident
     // blocks): +6 % MFMA throughput over 4 waves of 64x64 (98.7 -> 104.6 TFLOP/s on the step's launch mix; more
@@ -364,6 +413,29 @@ U2PL_API int u2pl_conv2d_fwd_bnstats_f32(const float* x, long ldx, const float* 
                                          float* stats_partial, hipStream_t stream) {
     ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
     return run_igemm(x, ldx, w, bias, y, ldy, g, stream, stats_partial, pivot);
+}
+
+// the same three products with bf16-rounded operands on the bf16 matrix cores (fp32 accumulate / fp32 tensors)
+U2PL_API int u2pl_conv2d_fwd_bf16op_f32(const float* x, long ldx, const float* w, const float* bias, float* y,
+                                        long ldy, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
+                                        int R, int S, int stride, int pad, int dil, hipStream_t stream) {
+    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
+    return run_igemm(x, ldx, w, bias, y, ldy, g, stream, nullptr, nullptr, 1, 0, 0, 0, true);
+}
+U2PL_API int u2pl_conv2d_fwd_bnstats_bf16op_f32(const float* x, long ldx, const float* w, const float* bias, float* y,
+                                                long ldy, int N, int Hin, int Win, int Cin, int Hout, int Wout,
+                                                int Cout, int R, int S, int stride, int pad, int dil,
+                                                const float* pivot, float* stats_partial, hipStream_t stream) {
+    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
+    return run_igemm(x, ldx, w, bias, y, ldy, g, stream, stats_partial, pivot, 1, 0, 0, 0, true);
+}
+U2PL_API int u2pl_conv2d_dgrad_bf16op_f32(const float* dy, long lddy, const float* wT, float* dx, long lddx, int N,
+                                          int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S,
+                                          int stride, int pad, int dil, hipStream_t stream) {
+    int l2 = log2_exact(stride);
+    if (l2 < 0) return U2PL_EINVAL;
+    ConvGeom g = {N, Hout, Wout, Cout, Hin, Win, Cin, R, S, 1, pad, pad, -dil, l2};
+    return run_igemm(dy, lddy, wT, nullptr, dx, lddx, g, stream, nullptr, nullptr, 1, 0, 0, 0, true);
 }
 
 // data gradient: dX[n,hi,wi,ci] = sum_{r,s,co} dY[n,(hi+pad-r*dil)/st,(wi+pad-s*dil)/st,co] * W[co][r][s][ci]
@@ -523,6 +595,132 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const float* __restrict__
         }
 }
 
+// bf16-operand weight gradient (config 5): the reduction runs over PIXELS while memory is channel-contiguous, so the
+// tiles are transposed on their way into LDS: thread (pixel pair pp, channel quad cq) loads the same four channels of
+// two consecutive pixels and writes four 32-bit words {bf16(pixel 2pp), bf16(pixel 2pp+1)} into [channel][pixel]
+// rows (pitch 36 bf16 = 72 B), from which lane (li, lh) fetches its 8 consecutive pixels of channel li with two
+// ds_read_b64.  Same split-K slabs / ordered reduce as the fp32 kernel.
+#define LDPW 36
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad_bf16(const float* __restrict__ dy, long lddy,
+                                                            const float* __restrict__ x, long ldx,
+                                                            float* __restrict__ part, ConvGeom g, int ctiles,
+                                                            int chunks_per_split, unsigned dybytes, unsigned xbytes) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, dybytes), rx = make_rsrc(x, xbytes);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* Ah = (unsigned short*)smem;      // [2][BM][LDPW]
+    unsigned short* Bh = Ah + 2 * BM * LDPW;          // [2][BN][LDPW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long M = (long)g.N * g.Hout * g.Wout;
+    const int co0 = blockIdx.y * BM;
+    const int tap = blockIdx.x / ctiles, ci0 = (blockIdx.x - tap * ctiles) * BN;
+    const int r = tap / g.S, s = tap - r * g.S;
+    const long nchunks = (M + BK - 1) / BK;
+    const long c_begin = (long)blockIdx.z * chunks_per_split;
+    const long c_end = min(nchunks, c_begin + chunks_per_split);
+    const int pp = tid >> 4, cq = tid & 15;          // pixel pair 0..15 of the 32-pixel chunk, channel quad 0..15 (64 ch / pass)
+    constexpr int JA = BM / 64, JB = BN / 64;
+    float4 ra[JA][2], rb[JB][2];
+    const int lddyb = (int)lddy * 4, ldxb = (int)ldx * 4;
+    auto load_chunk = [&](long ch) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long m = ch * BK + 2 * pp + h;
+            const bool mv = m < M;
+            const unsigned mm = mv ? (unsigned)m : 0u;
+            const unsigned t = mm / (unsigned)g.Wout;
+            const int wo = (int)(mm - t * (unsigned)g.Wout);
+            const unsigned n_ = t / (unsigned)g.Hout;
+            const int ho = (int)(t - n_ * (unsigned)g.Hout);
+            int ih, iw;
+            const bool okh = gather_coord(ho * g.mul + g.off_h, r, g.step, 0, g.Hin, ih);
+            const bool okw = gather_coord(wo * g.mul + g.off_w, s, g.step, 0, g.Win, iw);
+            const bool okb = mv & okh & okw;
+            const int dyo = (int)mm * lddyb;
+            const int xo = ((int)n_ * g.Hin * g.Win + ih * g.Win + iw) * ldxb;
+#pragma unroll
+            for (int j = 0; j < JA; ++j) {
+                const int co = co0 + j * 64 + cq * 4;
+                ra[j][h] = buf_load4(rdy, (mv & (co < g.Cout)) ? dyo + co * 4 : OOB_OFF);
+            }
+#pragma unroll
+            for (int j = 0; j < JB; ++j) {
+                const int ci = ci0 + j * 64 + cq * 4;
+                rb[j][h] = buf_load4(rx, (okb & (ci < g.Cin)) ? xo + ci * 4 : OOB_OFF);
+            }
+        }
+    };
+    auto put4 = [&](unsigned short* base, const float4& p0, const float4& p1) {   // rows c..c+3, pixels 2pp, 2pp+1
+        *(unsigned*)(base + 0 * LDPW) = bf16_rne(p0.x) | (bf16_rne(p1.x) << 16);
+        *(unsigned*)(base + 1 * LDPW) = bf16_rne(p0.y) | (bf16_rne(p1.y) << 16);
+        *(unsigned*)(base + 2 * LDPW) = bf16_rne(p0.z) | (bf16_rne(p1.z) << 16);
+        *(unsigned*)(base + 3 * LDPW) = bf16_rne(p0.w) | (bf16_rne(p1.w) << 16);
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < JA; ++j) put4(Ah + ((long)buf * BM + j * 64 + cq * 4) * LDPW + 2 * pp, ra[j][0], ra[j][1]);
+#pragma unroll
+        for (int j = 0; j < JB; ++j) put4(Bh + ((long)buf * BN + j * 64 + cq * 4) * LDPW + 2 * pp, rb[j][0], rb[j][1]);
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    const int li = lane & 31, lh = lane >> 5;
+    if (c_begin < c_end) {
+        load_chunk(c_begin);
+        store_chunk(0);
+        __syncthreads();
+        for (long ch = c_begin; ch < c_end; ++ch) {
+            const int buf = (int)((ch - c_begin) & 1);
+            if (ch + 1 < c_end) load_chunk(ch + 1);
+            const unsigned short* Ab = Ah + ((long)buf * BM + wm * 32 * TM + li) * LDPW + 8 * lh;
+            const unsigned short* Bb = Bh + ((long)buf * BN + wn * 32 * TN + li) * LDPW + 8 * lh;
+#pragma unroll
+            for (int gk = 0; gk < BK / 16; ++gk) {
+                bf16x8 a8[TM], b8[TN];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const uint2 lo = *(const uint2*)(Ab + a * 32 * LDPW + gk * 16), hi = *(const uint2*)(Ab + a * 32 * LDPW + gk * 16 + 4);
+                    a8[a] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                }
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const uint2 lo = *(const uint2*)(Bb + b * 32 * LDPW + gk * 16), hi = *(const uint2*)(Bb + b * 32 * LDPW + gk * 16 + 4);
+                    b8[b] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                }
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[a], b8[b], acc[a][b], 0, 0, 0);
+            }
+            if (ch + 1 < c_end) store_chunk(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    const long wsz = (long)g.Cout * g.R * g.S * g.Cin;
+    float* out = part + (long)blockIdx.z * wsz;
+    const long rowlen = (long)g.R * g.S * g.Cin;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int ci = ci0 + wn * 32 * TN + b * 32 + li;
+            if (ci >= g.Cin) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + wm * 32 * TM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (co < g.Cout) out[(long)co * rowlen + (long)tap * g.Cin + ci] = acc[a][b][e];
+            }
+        }
+}
+
 // dW = (accumulate ? dW : 0) + sum_z part[z]   (ordered => deterministic)
 __global__ void k_wgrad_reduce(const float* __restrict__ part, long wsz, int nsplit, int accumulate,
                                float* __restrict__ dw) {
@@ -603,6 +801,43 @@ U2PL_API int u2pl_conv2d_wgrad_f32(const float* dy, long lddy, const float* x, l
     else if (BM == 128) rc = launch_wgrad<2, 1>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
     else if (BN == 128) rc = launch_wgrad<1, 2>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
     else rc = launch_wgrad<1, 1>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
+    if (rc) return rc;
+    const long wsz = (long)Cout * R * S * Cin;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(grid_for(wsz / 4, 256)), dim3(256), 0, stream, part, wsz, ns, accumulate, dw);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int TM, int TN>
+static int launch_wgrad_bf16(const float* dy, long lddy, const float* x, long ldx, float* part, const ConvGeom& g,
+                             int ctiles, int nsplit, int cps, hipStream_t stream) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    const size_t lds = (size_t)2 * (BM + BN) * LDPW * sizeof(unsigned short);
+    const long dyb = (((long)g.N * g.Hout * g.Wout - 1) * lddy + g.Cout) * 4;
+    const long xb = (((long)g.N * g.Hin * g.Win - 1) * ldx + g.Cin) * 4;
+    if (dyb >= (1L << 31) || xb >= (1L << 31)) return U2PL_EINVAL;
+    dim3 grid((unsigned)(ctiles * g.R * g.S), (unsigned)cdiv(g.Cout, BM), (unsigned)nsplit);
+    hipLaunchKernelGGL((k_conv_wgrad_bf16<TM, TN>), grid, dim3(256), lds, stream, dy, lddy, x, ldx, part, g, ctiles, cps,
+                       (unsigned)dyb, (unsigned)xb);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+// weight gradient with bf16-rounded dY / X operands (fp32 accumulate); workspace as u2pl_conv2d_wgrad_workspace_bytes
+U2PL_API int u2pl_conv2d_wgrad_bf16op_f32(const float* dy, long lddy, const float* x, long ldx, float* dw,
+                                          void* workspace, int accumulate, int N, int Hin, int Win, int Cin, int Hout,
+                                          int Wout, int Cout, int R, int S, int stride, int pad, int dil,
+                                          hipStream_t stream) {
+    if (Cin % 4 || Cout % 4) return U2PL_EINVAL;
+    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
+    const int BM = Cout > 64 ? 128 : 64, BN = Cin > 64 ? 128 : 64;
+    int ct, ns, cps;
+    wgrad_plan(g, BM, BN, ct, ns, cps);
+    float* part = (float*)workspace;
+    int rc;
+    if (BM == 128 && BN == 128) rc = launch_wgrad_bf16<2, 2>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
+    else if (BM == 128) rc = launch_wgrad_bf16<2, 1>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
+    else if (BN == 128) rc = launch_wgrad_bf16<1, 2>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
+    else rc = launch_wgrad_bf16<1, 1>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
     if (rc) return rc;
     const long wsz = (long)Cout * R * S * Cin;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(grid_for(wsz / 4, 256)), dim3(256), 0, stream, part, wsz, ns, accumulate, dw);

@@ -101,8 +101,12 @@ def _mark_ready(sink):
 # U2PL_CONV_WINO = 0 (direct implicit GEMM only) | 2 | 4 (tile size; default 4).  Dilated convolutions are
 # decomposed into d*d sub-images; a layer only takes the Winograd path when the multiply reduction that is
 # left after tile padding is worth the transforms.
+# U2PL_CONV_BF16 = 1 (BASELINE configs[4], "config 5"): the STUDENT's convolutions (every call that records a gradient)
+# round their operands to bf16 while staging them into LDS and run on the bf16 matrix cores with fp32 accumulation
+# (forward, data and weight gradient; direct kernel -- no Winograd on 8-bit mantissas); tensors, master weights, the EMA
+# teacher (no_grad calls) and the 3-channel stem stay fp32.  Never the default: the headline is the reference's fp32.
 CONV_ALGO = {"wino": int(os.environ.get("U2PL_CONV_WINO", "4")), "min_gain": float(os.environ.get("U2PL_WINO_MIN_GAIN", "1.7")),
-             "wgrad": int(os.environ.get("U2PL_WINO_WGRAD", "1"))}
+             "wgrad": int(os.environ.get("U2PL_WINO_WGRAD", "1")), "bf16": int(os.environ.get("U2PL_CONV_BF16", "0"))}
 
 
 def wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W):
@@ -139,7 +143,7 @@ def _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, mt, transposed,
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, dil, wsink, bsink, pivot=None):
+    def forward(ctx, x, weight, bias, stride, pad, dil, wsink, bsink, pivot=None, recording=True):
         """pivot (a BatchNorm running_mean) requests the fused train-mode BN statistics of the output:
         returns (y, sums) with sums = double [2C+1] (S1, S2 pivot-shifted; last slot spare for the count)."""
         x, ldx = as_rows(x)
@@ -151,6 +155,11 @@ class _ConvFn(torch.autograd.Function):
             raise HipError("conv weight must be stored channels_last ([Cout][R][S][Cin])")
         y = new_act(N, Cout, Ho, Wo, x.device)
         col = None
+        # `recording`: grad mode at the call site (inside forward() it is always off); the teacher's calls run under no_grad
+        use_bf = (bool(CONV_ALGO.get("bf16", 0)) and recording and any(ctx.needs_input_grad[:3]) and Cin % 32 == 0
+                  and H * W > 1)
+        ctx.bf = use_bf
+        sfx = "_bf16op_f32" if use_bf else "_f32"
         if H * W == 1 and R == 1 and S == 1 and stride == 1 and pad == 0 and N <= 16 and Cin % 4 == 0:
             # image-pooling branch of the ASPP: float64-accumulated dense layer (see csrc/nn.hip:k_dense_small)
             call("u2pl_dense_small_f32", x, ldx, weight, bias, y, Cout, N, Cin, Cout)
@@ -162,7 +171,7 @@ class _ConvFn(torch.autograd.Function):
             wp = torch.zeros((Cout, Kp), dtype=torch.float32, device=x.device)
             wp[:, : R * S * Cin] = weight.permute(0, 2, 3, 1).reshape(Cout, R * S * Cin)
             call("u2pl_conv2d_fwd_f32", col, Kp, wp, bias, y, Cout, N, Ho, Wo, Kp, Ho, Wo, Cout, 1, 1, 1, 0, 1)
-        elif wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W):
+        elif not use_bf and wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W):
             mt = wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W)
             part, V = _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, mt, False, pivot)
             if ctx.needs_input_grad[1]:
@@ -173,12 +182,12 @@ class _ConvFn(torch.autograd.Function):
         elif pivot is not None and pivot is not False:
             nblk = query("u2pl_conv2d_fwd_stat_blocks", N, Ho, Wo, Cout)
             part = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=x.device)
-            call("u2pl_conv2d_fwd_bnstats_f32", x, ldx, weight, bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S, stride,
+            call("u2pl_conv2d_fwd_bnstats" + sfx, x, ldx, weight, bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S, stride,
                  pad, dil, pivot, part)
             sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=x.device)
             call("u2pl_colreduce_finish_f32", part, nblk, Cout, sums)
         else:
-            call("u2pl_conv2d_fwd_f32", x, ldx, weight, bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil)
+            call("u2pl_conv2d_fwd" + sfx, x, ldx, weight, bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil)
         ctx.save_for_backward(x, weight, col)
         ctx.geom = (N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ldx)
         ctx.has_bias = bias is not None
@@ -211,13 +220,14 @@ class _ConvFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = new_act(N, Cin, H, W, dev)
-            mt = wino_tile(Cp, Cin, R, S, stride, pad, dil, H, W) if Cp == Cout else 0
+            mt = wino_tile(Cp, Cin, R, S, stride, pad, dil, H, W) if (Cp == Cout and not ctx.bf) else 0
             if mt:   # data gradient = the same convolution with rotated taps and swapped channel roles
                 _wino_conv(gy, ldg, weight_k, None, dx, N, H, W, Cin, Cout, dil, mt, True)[0]
             else:
                 wT = torch.empty(Cin * R * S * Cp, dtype=torch.float32, device=dev)
                 call("u2pl_weight_transpose_f32", weight_k, wT, Cp, R * S, Cin)
-                call("u2pl_conv2d_dgrad_f32", gy, ldg, wT, dx, Cin, N, H, W, Cin, Ho, Wo, Cp, R, S, stride, pad, dil)
+                call("u2pl_conv2d_dgrad_bf16op_f32" if ctx.bf else "u2pl_conv2d_dgrad_f32", gy, ldg, wT, dx, Cin, N, H, W, Cin,
+                     Ho, Wo, Cp, R, S, stride, pad, dil)
         side = _wgrad_stream() if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) else None
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
@@ -239,7 +249,7 @@ class _ConvFn(torch.autograd.Function):
                     sink.add_(g)
                 else:
                     dw = g.contiguous(memory_format=_CL)
-            elif Cp == Cout and CONV_ALGO.get("wgrad", 1) and wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W):
+            elif Cp == Cout and not ctx.bf and CONV_ALGO.get("wgrad", 1) and wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W):
                 # Winograd weight gradient: dU = sum_tiles (A dY A^T) (x) (B^T x B), dW = G^T dU G
                 mt = wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W)
                 a2 = (mt + 2) ** 2
@@ -261,8 +271,8 @@ class _ConvFn(torch.autograd.Function):
                 wsb = _ws(query("u2pl_conv2d_wgrad_workspace_bytes", N, Ho, Wo, Cin, Cp, R, S), dev)
                 direct = sink is not None and Cp == Cout
                 tgt = sink if direct else torch.empty_like(weight_k)
-                call("u2pl_conv2d_wgrad_f32", gy, ldg, x, ldx, tgt, wsb, int(direct), N, H, W, Cin, Ho, Wo, Cp, R, S,
-                     stride, pad, dil)
+                call("u2pl_conv2d_wgrad_bf16op_f32" if ctx.bf else "u2pl_conv2d_wgrad_f32", gy, ldg, x, ldx, tgt, wsb,
+                     int(direct), N, H, W, Cin, Ho, Wo, Cp, R, S, stride, pad, dil)
                 if not direct:
                     if sink is not None:
                         sink.add_(tgt[:Cout])
@@ -286,7 +296,7 @@ class _ConvFn(torch.autograd.Function):
                 if t_ is not None:   # returned to autograd on the main stream
                     torch.cuda.current_stream().wait_stream(side)
                     break
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 class Conv2d(nn.Module):
@@ -312,7 +322,8 @@ class Conv2d(nn.Module):
     def forward(self, x, stat_pivot=None):
         """stat_pivot: running_mean of a following train-mode BatchNorm -> returns (y, fused BN sums)."""
         out = _ConvFn.apply(x, self.weight, self.bias, self.stride, self.padding, self.dilation,
-                            _grad_sink(self.weight), _grad_sink(self.bias) if self.bias is not None else None, stat_pivot)
+                            _grad_sink(self.weight), _grad_sink(self.bias) if self.bias is not None else None, stat_pivot,
+                            torch.is_grad_enabled())
         return out
 
     def extra_repr(self):

@@ -15,7 +15,10 @@ ALGO_TFLOP_PER_IMAGE_769 = 6.60   # 26.4 TFLOP per step of 2+2 imag
 # positions of the geometry ints inside each conv entry point's argument list
 _CONV_GEOM = {
     "u2pl_conv2d_fwd_f32": 6, "u2pl_conv2d_fwd_bnstats_f32": 6, "u2pl_conv2d_dgrad_f32": 5, "u2pl_conv2d_wgrad_f32": 7,
+    "u2pl_conv2d_fwd_bf16op_f32": 6, "u2pl_conv2d_fwd_bnstats_bf16op_f32": 6, "u2pl_conv2d_dgrad_bf16op_f32": 5,
+    "u2pl_conv2d_wgrad_bf16op_f32": 7,
 }
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense
 
 
 def _conv_flops(name, args):
@@ -58,7 +61,7 @@ def profile_step(step_fn):
             fl = _conv_flops(name, args)
             d["flops"] += fl
             i = _CONV_GEOM[name]
-            key = (name[12:-4].replace("fwd_bnstats", "fwd"),) + tuple(args[i:i + 9]) + tuple(args[i + 9:i + 12])
+            key = (name[12:-4].replace("fwd_bnstats", "fwd").replace("_bf16op", "@bf16"),) + tuple(args[i:i + 9]) + tuple(args[i + 9:i + 12])
             sd = shapes.setdefault(key, dict(ms=0.0, calls=0, flops=0.0))
             sd["ms"] += ms
             sd["calls"] += 1
@@ -166,6 +169,18 @@ def measure(trainer, batch, args, ms_per_step):
                                    note="frac/achieved: executed FLOPs of this kernel's launches over their own HIP-event "
                                         "time (serialised extra step); algorithmic_*: 26.4 TFLOP (SURVEY 8d, every layer "
                                         "counted as a direct convolution) over the WHOLE timed step")
+    bfs = [agg.get(n) for n in ("u2pl_conv2d_fwd_bf16op_f32", "u2pl_conv2d_fwd_bnstats_bf16op_f32", "u2pl_conv2d_dgrad_bf16op_f32",
+                                "u2pl_conv2d_wgrad_bf16op_f32")]
+    bfs = [x for x in bfs if x]
+    if bfs:   # config 5: the student's products on the bf16 matrix cores (operands rounded in LDS, fp32 tensors in HBM)
+        fl, t, n = sum(x["flops"] for x in bfs), sum(x["ms"] for x in bfs), sum(x["calls"] for x in bfs)
+        ach = fl / (t * 1e-3) / 1e12
+        out["roofline_bf16"] = {"kernel": "k_conv_igemm<BF> / k_conv_wgrad_bf16 (student fwd + dgrad + wgrad, bf16 operands, fp32 accumulate)",
+                                "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None, "launches_per_step": n,
+                                "ms_per_step": round(t, 2), "executed_tflop_per_step": round(fl / 1e12, 3),
+                                "note": "fp32 activations / weights are read from HBM and rounded on the way into LDS: these "
+                                        "launches are HBM / LDS bound long before the 2.5 PFLOP/s matrix-core peak"}
     wgs = [x for x in (agg.get("u2pl_conv2d_wgrad_f32"), agg.get("u2pl_wgrad_batched_f32")) if x]
     wg = dict(flops=sum(x["flops"] for x in wgs), ms=sum(x["ms"] for x in wgs), calls=sum(x["calls"] for x in wgs)) if wgs else None
     if wg:

@@ -134,6 +134,13 @@ int u2pl_ce_fwd_f32(const float* logits_nchw, const long long* target, int ignor
                     int unsup_weight, void* workspace, float* out3, hipStream_t stream);
 int u2pl_ce_bwd_f32(const float* logits_nchw, const long long* target, int ignore, int N, int C, int H, int W,
                     const float* out3_dev, const float* gout_dev, float gmul, float* grad, hipStream_t stream);
+/* nn.CrossEntropyLoss(weight=class_weight, ignore_index, reduction="mean") of the `use_weight: True` criteria
+   (loss_helper.py:265-292,461-488): loss = sum w[t]*l / sum w[t]; out3 = {loss, 1/sum w, sum w} */
+int u2pl_ce_fwd_weighted_f32(const float* logits_nchw, const long long* target, int ignore, int N, int C, int H, int W,
+                             const float* class_weight, void* workspace, float* out3, hipStream_t stream);
+int u2pl_ce_bwd_weighted_f32(const float* logits_nchw, const long long* target, int ignore, int N, int C, int H, int W,
+                             const float* class_weight, const float* out3_dev, const float* gout_dev, float gmul,
+                             float* grad, hipStream_t stream);
 /* OhemCrossEntropy2dTensor: loss_helper.py:502-531 */
 int u2pl_ohem_prob_f32(const float* logits_nchw, const long long* target, int ignore, int N, int C, int H,
                        int W, float* mask_prob, unsigned* ws, hipStream_t stream);

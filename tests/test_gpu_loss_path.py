@@ -583,3 +583,41 @@ def test_infonce_gradient_scatter_is_row_sparse_ordered_and_reproducible(n_cand)
         assert np.array_equal(out, ref), trial
         results.append(out.copy())
     assert np.array_equal(results[0], results[2])                   # same data, different chain order: same bits
+
+
+# ------------------------------------------------------------------ class-weighted criteria (use_weight: True)
+def test_class_weighted_criteria_match_torch():
+    """CriterionOhem / Criterion with use_weight=True (loss_helper.py:258-360,451-500): nn.CrossEntropyLoss(weight=...)
+    semantics (weighted mean over the kept pixels), loss and gradient vs torch CPU"""
+    import torch.nn.functional as F
+    from u2pl_amd.utils import loss_helper as LH
+    g = torch.Generator().manual_seed(3)
+    N, C, S = 2, 19, 41
+    logits = torch.randn(N, C, S, S, generator=g) * 2
+    aux = torch.randn(N, C, S, S, generator=g)
+    tgt = torch.randint(0, C, (N, S, S), generator=g)
+    tgt[:, :3] = 255
+    # plain CE criterion with use_weight (aux branch): CE + weighted CE on main, CE on aux
+    w = torch.tensor(LH.CE_CLASS_WEIGHT)
+    lr = logits.clone().requires_grad_(True)
+    ar = aux.clone().requires_grad_(True)
+    ref = (F.cross_entropy(lr, tgt, ignore_index=255) + F.cross_entropy(lr, tgt, weight=w, ignore_index=255)
+           + 0.4 * F.cross_entropy(ar, tgt, ignore_index=255))
+    ref.backward()
+    ld, ad = logits.to(DEV).requires_grad_(True), aux.to(DEV).requires_grad_(True)
+    crit = LH.Criterion(0.4, ignore_index=255, use_weight=True)
+    out = crit([ld, ad], tgt.to(DEV))
+    out.backward()
+    assert abs(float(out) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    assert (ld.grad.cpu() - lr.grad).abs().max() <= 1e-7 + 1e-5 * lr.grad.abs().max()
+    # OHEM with the reference's class weights: same kept set as the unweighted criterion, weighted mean on it
+    crit_o = LH.CriterionOhem(0.0, thresh=0.7, min_kept=500, ignore_index=255, use_weight=True)
+    ld2 = logits.to(DEV).requires_grad_(True)
+    out_o = crit_o(ld2, tgt.to(DEV))
+    out_o.backward()
+    kept = H_kept = hip().ohem_kept_target(logits.to(DEV), tgt.to(DEV), 0.7, 500, 255).cpu()
+    lr2 = logits.clone().requires_grad_(True)
+    ref_o = F.cross_entropy(lr2, kept, weight=torch.tensor(LH.OHEM_CLASS_WEIGHT), ignore_index=255)
+    ref_o.backward()
+    assert abs(float(out_o) - float(ref_o)) <= 1e-5 * max(1.0, abs(float(ref_o)))
+    assert (ld2.grad.cpu() - lr2.grad).abs().max() <= 1e-7 + 1e-5 * lr2.grad.abs().max()

@@ -7,7 +7,7 @@
 
 // per-pixel log-softmax pick; block partial sums in double -> partial[2*blk+{0,1}]
 __global__ void k_ce_fwd(const float* __restrict__ z, const long long* __restrict__ target, int ignore, int N,
-                         int C, long HW, double* __restrict__ partial) {
+                         int C, long HW, double* __restrict__ partial, const float* __restrict__ cw) {
     __shared__ double sh_l[4], sh_c[4];
     long total = (long)N * HW;
     double lsum = 0.0, cnt = 0.0;
@@ -21,8 +21,10 @@ __global__ void k_ce_fwd(const float* __restrict__ z, const long long* __restric
         float s = 0.f;
         for (int c = 0; c < C; ++c) s += expf(b[(long)c * HW] - m);
         float lse = m + logf(s);
-        lsum += (double)(lse - b[(long)t * HW]);
-        cnt += 1.0;
+        // nn.CrossEntropyLoss(weight=w, reduction="mean"): sum_i w[t_i] * l_i / sum_i w[t_i]  (loss_helper.py:258-320,451-500)
+        const double wt = cw ? (double)cw[t] : 1.0;
+        lsum += wt * (double)(lse - b[(long)t * HW]);
+        cnt += wt;
     }
     lsum = wave_sum_d(lsum);
     cnt = wave_sum_d(cnt);
@@ -66,9 +68,24 @@ U2PL_API int u2pl_ce_fwd_f32(const float* logits, const long long* target, int i
     long total = (long)N * H * W;
     if (total <= 0) return U2PL_EINVAL;
     int nblk = grid_for(total, 256, CE_BLOCKS);
-    hipLaunchKernelGGL(k_ce_fwd, dim3(nblk), dim3(256), 0, stream, logits, target, ignore, N, C, (long)H * W, (double*)workspace);
+    hipLaunchKernelGGL(k_ce_fwd, dim3(nblk), dim3(256), 0, stream, logits, target, ignore, N, C, (long)H * W, (double*)workspace,
+                       (const float*)nullptr);
     U2PL_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ce_finish, dim3(1), dim3(256), 0, stream, (const double*)workspace, nblk, (double)total, unsup_weight, out3);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+// class-weighted variant (use_weight: True, loss_helper.py:265-292,461-488): out3 = {loss, 1 / sum of weights, sum of weights}
+U2PL_API int u2pl_ce_fwd_weighted_f32(const float* logits, const long long* target, int ignore, int N, int C, int H,
+                                      int W, const float* class_weight, void* workspace, float* out3,
+                                      hipStream_t stream) {
+    long total = (long)N * H * W;
+    if (total <= 0 || !class_weight) return U2PL_EINVAL;
+    int nblk = grid_for(total, 256, CE_BLOCKS);
+    hipLaunchKernelGGL(k_ce_fwd, dim3(nblk), dim3(256), 0, stream, logits, target, ignore, N, C, (long)H * W, (double*)workspace,
+                       class_weight);
+    U2PL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ce_finish, dim3(1), dim3(256), 0, stream, (const double*)workspace, nblk, (double)total, 0, out3);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -76,8 +93,8 @@ U2PL_API int u2pl_ce_fwd_f32(const float* logits, const long long* target, int i
 // grad[n][c][q] = (softmax_c - [c==t]) * scale * gout  for valid pixels, else 0
 __global__ void k_ce_bwd(const float* __restrict__ z, const long long* __restrict__ target, int ignore, int N,
                          int C, long HW, const float* __restrict__ scale, const float* __restrict__ gout,
-                         float gmul, float* __restrict__ grad) {
-    const float sc = scale[1] * (gout ? *gout : 1.0f) * gmul;
+                         float gmul, float* __restrict__ grad, const float* __restrict__ cw) {
+    const float sc0 = scale[1] * (gout ? *gout : 1.0f) * gmul;
     long total = (long)N * HW;
     for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
         long n = p / HW, q = p % HW;
@@ -88,6 +105,7 @@ __global__ void k_ce_bwd(const float* __restrict__ z, const long long* __restric
             for (int c = 0; c < C; ++c) g[(long)c * HW] = 0.f;
             continue;
         }
+        const float sc = cw ? sc0 * cw[t] : sc0;
         float m = b[0];
         for (int c = 1; c < C; ++c) m = fmaxf(m, b[(long)c * HW]);
         float s = 0.f;
@@ -105,7 +123,17 @@ U2PL_API int u2pl_ce_bwd_f32(const float* logits, const long long* target, int i
     long total = (long)N * H * W;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(k_ce_bwd, dim3(grid_for(total, 256)), dim3(256), 0, stream, logits, target, ignore, N, C,
-                       (long)H * W, out3_dev, gout_dev, gmul, grad);
+                       (long)H * W, out3_dev, gout_dev, gmul, grad, (const float*)nullptr);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+U2PL_API int u2pl_ce_bwd_weighted_f32(const float* logits, const long long* target, int ignore, int N, int C, int H,
+                                      int W, const float* class_weight, const float* out3_dev, const float* gout_dev,
+                                      float gmul, float* grad, hipStream_t stream) {
+    long total = (long)N * H * W;
+    if (total <= 0 || !class_weight) return U2PL_EINVAL;
+    hipLaunchKernelGGL(k_ce_bwd, dim3(grid_for(total, 256)), dim3(256), 0, stream, logits, target, ignore, N, C,
+                       (long)H * W, out3_dev, gout_dev, gmul, grad, class_weight);
     U2PL_LAUNCH_CHECK();
     return 0;
 }

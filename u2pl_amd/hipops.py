@@ -229,31 +229,41 @@ def reliability_split(logits_low, size, label_l, label_u_aug, out_hw, percents, 
 # --------------------------------------------------------------------------- cross entropy
 class _CrossEntropy(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, ignore, unsup_weight, gmul):
+    def forward(ctx, logits, target, ignore, unsup_weight, gmul, class_weight=None):
         _chk_cuda(logits, target)
         x = _f32c(logits).contiguous()
         N, C, H, W = x.shape
         work = torch.empty(query("u2pl_ce_workspace_bytes"), dtype=torch.uint8, device=x.device)
         out3 = torch.empty(3, dtype=torch.float32, device=x.device)
-        call("u2pl_ce_fwd_f32", x, target, ignore, N, C, H, W, int(unsup_weight), work, out3)
-        ctx.save_for_backward(x, target, out3)
+        if class_weight is not None:
+            call("u2pl_ce_fwd_weighted_f32", x, target, ignore, N, C, H, W, class_weight, work, out3)
+        else:
+            call("u2pl_ce_fwd_f32", x, target, ignore, N, C, H, W, int(unsup_weight), work, out3)
+        ctx.save_for_backward(x, target, out3, class_weight)
         ctx.ignore, ctx.gmul = ignore, gmul
         return out3[0].clone() * gmul if gmul != 1.0 else out3[0].clone()
 
     @staticmethod
     def backward(ctx, g):
-        x, target, out3 = ctx.saved_tensors
+        x, target, out3, cw = ctx.saved_tensors
         N, C, H, W = x.shape
         grad = torch.empty_like(x)
-        call("u2pl_ce_bwd_f32", x, target, ctx.ignore, N, C, H, W, out3, g.contiguous(), float(ctx.gmul), grad)
-        return grad, None, None, None, None
+        if cw is not None:
+            call("u2pl_ce_bwd_weighted_f32", x, target, ctx.ignore, N, C, H, W, cw, out3, g.contiguous(), float(ctx.gmul), grad)
+        else:
+            call("u2pl_ce_bwd_f32", x, target, ctx.ignore, N, C, H, W, out3, g.contiguous(), float(ctx.gmul), grad)
+        return grad, None, None, None, None, None
 
 
-def cross_entropy(logits, target, ignore_index=255, unsup_weight=False, scale=1.0):
-    """F.cross_entropy(logits, target, ignore_index) [* B*H*W/n_valid if unsup_weight] * scale."""
+def cross_entropy(logits, target, ignore_index=255, unsup_weight=False, scale=1.0, class_weight=None):
+    """F.cross_entropy(logits, target, ignore_index[, weight=class_weight]) [* B*H*W/n_valid if unsup_weight] * scale."""
     if target.dtype != torch.int64 or not target.is_contiguous():
         target = target.long().contiguous()
-    return _CrossEntropy.apply(logits, target, int(ignore_index), bool(unsup_weight), float(scale))
+    if class_weight is not None:
+        if unsup_weight or class_weight.numel() != logits.shape[1]:
+            raise _lib.HipError("class_weight needs one weight per class and excludes unsup_weight")
+        class_weight = class_weight.to(device=logits.device, dtype=torch.float32).contiguous()
+    return _CrossEntropy.apply(logits, target, int(ignore_index), bool(unsup_weight), float(scale), class_weight)
 
 
 def ohem_kept_target(pred, target, thresh, min_kept, ignore_index=255):
@@ -435,8 +445,16 @@ def _nce_state(device, P, D):
     st = _NCE_STATE.get(key)
     if st is None:
         st = _NCE_STATE[key] = dict(grad=torch.zeros((P, D), dtype=torch.float32, device=device),
-                                    head=torch.full((P,), -1, dtype=torch.int32, device=device), dirty=None)
+                                    head=torch.full((P,), -1, dtype=torch.int32, device=device), dirty=None, pending=None)
     return st
+
+
+def _nce_rearm(st):
+    """a forward pass whose backward never ran (loss evaluated without gradients) left its chain heads armed: clear them
+    before new chains are built on top (rare path, plain torch)"""
+    if st["pending"] is not None:
+        st["head"].index_fill_(0, st["pending"].reshape(-1).long(), -1)
+        st["pending"] = None
 
 
 def group_entries(ia_per_job, Q):
@@ -470,8 +488,10 @@ class _InfoNCE(torch.autograd.Function):
         ganchor = torch.empty((njobs, Q, D), dtype=torch.float32, device=dev)
         apix = torch.empty((njobs, Q), dtype=torch.int32, device=dev)
         nxt = torch.empty((njobs, Q), dtype=torch.int32, device=dev)
+        _nce_rearm(st)
         call("u2pl_infonce_f32", jobs_dev, njobs, rep_rows, D, D, Q, K, float(temp), loss_q, ganchor, apix, st["head"], nxt,
              groups[2])
+        st["pending"] = apix
         loss = torch.empty((), dtype=torch.float32, device=dev)
         call("u2pl_infonce_reduce_f32", loss_q, njobs, Q, 1.0 / valid_seg, loss)
         ctx.save_for_backward(ganchor, apix, nxt, groups)
@@ -483,6 +503,10 @@ class _InfoNCE(torch.autograd.Function):
         ganchor, apix, nxt, groups = ctx.saved_tensors
         P, D, n, scale = ctx.meta
         st = _nce_state(g.device, P, D)
+        if st["pending"] is not apix:
+            raise _lib.HipError("InfoNCE backward must follow its own forward exactly once (the per-pixel chains are "
+                                "consumed by the backward pass; retain_graph / interleaved forwards are not supported)")
+        st["pending"] = None
         if st["dirty"] is not None:      # rows written by the previous step's backward (their consumer has long run)
             call("u2pl_zero_rows_f32", st["grad"], D, D, st["dirty"], st["dirty"].numel())
         call("u2pl_scatter_rows_ordered_f32", st["grad"], D, D, apix, nxt, st["head"], groups[0], groups[1], groups[2],
@@ -501,6 +525,7 @@ def infonce_kernels_once(rep_rows, jobs_dev, njobs, Q, K, temp, valid_seg, group
     ganchor = torch.empty((njobs, Q, D), dtype=torch.float32, device=dev)
     apix = torch.empty((njobs, Q), dtype=torch.int32, device=dev)
     nxt = torch.empty((njobs, Q), dtype=torch.int32, device=dev)
+    _nce_rearm(st)
     call("u2pl_infonce_f32", jobs_dev, njobs, rep_rows, D, D, Q, K, float(temp), loss_q, ganchor, apix, st["head"], nxt, groups[2])
     loss = torch.empty((), dtype=torch.float32, device=dev)
     call("u2pl_infonce_reduce_f32", loss_q, njobs, Q, 1.0 / valid_seg, loss)

@@ -100,16 +100,23 @@ def compute_contra_memobank_loss(rep, label_l, label_u, prob_l, prob_u, low_mask
     return new_keys, loss
 
 
+# the reference's hard-coded Cityscapes class weights (loss_helper.py:461-488 for OHEM, 265-292 for CELoss)
+OHEM_CLASS_WEIGHT = [0.8373, 0.918, 0.866, 1.0345, 1.0166, 0.9969, 0.9754, 1.0489, 0.8786, 1.0023, 0.9539, 0.9843, 1.1116,
+                     0.9037, 1.0865, 1.0955, 1.0865, 1.1529, 1.0507]
+CE_CLASS_WEIGHT = [0.0, 0.0, 0.0, 1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 1.0, 0.0, 0.0, 1.0, 0.0, 1.0, 0.0, 1.0, 1.0, 1.0]
+
+
 class OhemCrossEntropy2dTensor(nn.Module):
     def __init__(self, ignore_index=255, thresh=0.7, min_kept=256, use_weight=False, reduce=False):
         super().__init__()
-        if use_weight or reduce:
-            raise NotImplementedError("class-weighted / unreduced OHEM is never enabled by the reference configs")
+        if reduce:
+            raise NotImplementedError("reduction='none' OHEM has no caller in the reference")
         self.ignore_index, self.thresh, self.min_kept = ignore_index, float(thresh), int(min_kept)
+        self.class_weight = torch.tensor(OHEM_CLASS_WEIGHT, dtype=torch.float32) if use_weight else None
 
     def forward(self, pred, target, scale=1.0):
         kept = H.ohem_kept_target(pred, target, self.thresh, self.min_kept, self.ignore_index)
-        return H.cross_entropy(pred, kept, self.ignore_index, scale=scale)
+        return H.cross_entropy(pred, kept, self.ignore_index, scale=scale, class_weight=self.class_weight)
 
 
 class _AuxMixin:
@@ -141,13 +148,15 @@ class CriterionOhem(nn.Module, _AuxMixin):
 class Criterion(nn.Module, _AuxMixin):
     def __init__(self, aux_weight, ignore_index=255, use_weight=False):
         super().__init__()
-        if use_weight:
-            raise NotImplementedError("use_weight is never enabled by the reference configs")
         self._aux_weight, self._ignore_index = aux_weight, ignore_index
+        self.class_weight = torch.tensor(CE_CLASS_WEIGHT, dtype=torch.float32) if use_weight else None
 
     def forward(self, preds, target):
         main, aux = self._split(preds, target)
         loss = H.cross_entropy(main, target, self._ignore_index)
+        if self.class_weight is not None and aux is not None:
+            # loss_helper.py:308-312: plain CE + class-weighted CE on the main head (only in the aux-loss branch upstream)
+            loss = loss + H.cross_entropy(main, target, self._ignore_index, class_weight=self.class_weight)
         if aux is not None:
             loss = loss + H.cross_entropy(aux, target, self._ignore_index, scale=self._aux_weight)
         return loss

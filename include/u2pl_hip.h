@@ -116,8 +116,6 @@ int u2pl_infonce_f32(const void* jobs_dev, int njobs, const float* rep, long ld,
                      const int* seg_len, hipStream_t stream);
 int u2pl_infonce_reduce_f32(const float* loss_q, int njobs, int Q, float inv_valid_seg, float* loss,
                             hipStream_t stream);
-int u2pl_scatter_add_rows_f32(float* dst, long ld, int D, const int* pix, const float* src, long n,
-                              const float* gout_dev, float scale, hipStream_t stream);
 /* d loss / d rep (loss_helper.py:205-230 backward) without a dense zero fill and without float atomics: dst is a
    persistent all-zero (P, D) buffer; per sampled pixel dst[pix] = scale * gout * (sum of its entries' src rows in
    ascending entry order); head is re-armed to -1.  order / seg_pos / seg_len: host-built grouping of every job's entries

@@ -661,27 +661,6 @@ U2PL_API int u2pl_infonce_reduce_f32(const float* loss_q, int njobs, int Q, floa
     return 0;
 }
 
-// grad_rep[pix] += scale * ganchor  (anchors are sampled with replacement =>
-// duplicates: float atomics; everything else in grad_rep stays zero)
-__global__ void k_scatter_add_rows(float* __restrict__ dst, long ld, int D, const int* __restrict__ pix,
-                                   const float* __restrict__ src, long n, const float* __restrict__ gout,
-                                   float scale) {
-    const float sc = scale * (gout ? *gout : 1.0f);
-    long total = n * D;
-    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        long r = t / D;
-        int d = (int)(t % D);
-        atomicAdd(&dst[(long)pix[r] * ld + d], sc * src[t]);
-    }
-}
-U2PL_API int u2pl_scatter_add_rows_f32(float* dst, long ld, int D, const int* pix, const float* src, long n,
-                                       const float* gout_dev, float scale, hipStream_t stream) {
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_scatter_add_rows, dim3(grid_for(n * D, 256)), dim3(256), 0, stream, dst, ld, D, pix, src, n, gout_dev, scale);
-    U2PL_LAUNCH_CHECK();
-    return 0;
-}
-
 // ---------------------------------------------------------------------------
 // Row-sparse, ordered gradient of the anchors (replaces zero-filling the dense (P, D) gradient -- 152 MB at 769^2 --
 // and the float atomicAdd scatter).  dst is a PERSISTENT all-zero buffer.  Host-side grouping (the host drew the anchor

@@ -236,7 +236,7 @@ def measure(trainer, batch, args, ms_per_step):
     rel_names = ["u2pl_entropy_f32", "u2pl_entropy_up_f32", "u2pl_select_f32", "u2pl_apply_drop_i64",
                  "u2pl_reliability_masks", "u2pl_reliability_apply", "u2pl_reliability_fused"]
     con_names = ["u2pl_contra_classify", "u2pl_compact_lists", "u2pl_class_prototypes", "u2pl_bank_append_f32", "u2pl_bank_append_multi_f32",
-                 "u2pl_infonce_f32", "u2pl_infonce_reduce_f32", "u2pl_scatter_add_rows_f32", "u2pl_scatter_rows_ordered_f32",
+                 "u2pl_infonce_f32", "u2pl_infonce_reduce_f32", "u2pl_scatter_rows_ordered_f32",
                  "u2pl_zero_rows_f32"]
     rel_b, con_b = hbm_algorithmic_bytes(B, C, H, W, h, w, 256, LH.LAST_STATS)
     t_rel = sum(agg[n]["ms"] for n in rel_names if n in agg)

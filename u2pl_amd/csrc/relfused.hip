@@ -56,6 +56,17 @@ struct RfArgs {
 
 U2PL_API size_t u2pl_reliability_fused_workspace_bytes(int G) { return (size_t)(RFW_SLAB + (size_t)G * RF_BINS) * sizeof(unsigned); }
 
+// exp(x) for x <= 0 (the max-shifted logits): 2^(x * log2 e) on v_exp_f32 with the rounding error of the product carried in
+// a first-order correction -- ~1.5 ulp, 6 VALU instructions instead of the 13 of the library expf (no range checks, no
+// ldexp: the argument never overflows and flushing below 2^-126 is harmless for a softmax term)
+__device__ __forceinline__ float rf_exp_neg(float x) {
+    const float t = __fmul_rn(x, 1.44269502162933349609375f);
+    float r = __fmaf_rn(x, 1.44269502162933349609375f, -t);
+    r = __fmaf_rn(x, 1.92596299e-8f, r);
+    const float e = __builtin_amdgcn_exp2f(t);
+    return __fmaf_rn(e, __fmul_rn(r, 0.693147180559945f), e);
+}
+
 __device__ __forceinline__ int rf_bin(float e, float scale) {
     // monotone non-decreasing in e (e is not NaN); bin 0: e < 2^-22 (incl. the tiny negatives of rounding)
     if (!(e >= 2.384185791015625e-07f)) return 0;
@@ -415,30 +426,61 @@ __global__ __launch_bounds__(RF_T, 1) void k_reliability_fused(RfArgs A) {
                 const AcCoord cx = ac_coord(min(ox0 + a, A.W - 1), A.sx, A.w);
                 lx0[a] = cx.l0; lx1[a] = cx.l1;
             }
-            float m[4], s[4], tt[4];
+            // two pixels at a time: their CT up-sampled logits stay in registers between the max pass and the exp pass
+            // (the bilinear form is evaluated once per value instead of twice)
+            float s[4], tt[4];
+            if constexpr (CT <= 19) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) { m[a] = -INFINITY; s[a] = 0.f; tt[a] = 0.f; }
-#pragma unroll 4
-            for (int c = 0; c < CT; ++c) {
-                const float v00 = cv[0][c][cl], v01 = cv[1][c][cl], v10 = cv[2][c][cl], v11 = cv[3][c][cl];
+            for (int hf = 0; hf < 2; ++hf) {
+                float z0[CT], z1[CT], m0 = -INFINITY, m1 = -INFINITY;
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const float top = __fmaf_rn(lx0[a], v00, __fmul_rn(lx1[a], v01));
-                    const float bot = __fmaf_rn(lx0[a], v10, __fmul_rn(lx1[a], v11));
-                    m[a] = fmaxf(m[a], __fmaf_rn(cy.l0, top, __fmul_rn(cy.l1, bot)));
+                for (int c = 0; c < CT; ++c) {
+                    const float v00 = cv[0][c][cl], v01 = cv[1][c][cl], v10 = cv[2][c][cl], v11 = cv[3][c][cl];
+                    const float t0 = __fmaf_rn(lx0[2 * hf], v00, __fmul_rn(lx1[2 * hf], v01));
+                    const float b0 = __fmaf_rn(lx0[2 * hf], v10, __fmul_rn(lx1[2 * hf], v11));
+                    const float t1 = __fmaf_rn(lx0[2 * hf + 1], v00, __fmul_rn(lx1[2 * hf + 1], v01));
+                    const float b1 = __fmaf_rn(lx0[2 * hf + 1], v10, __fmul_rn(lx1[2 * hf + 1], v11));
+                    z0[c] = __fmaf_rn(cy.l0, t0, __fmul_rn(cy.l1, b0));
+                    z1[c] = __fmaf_rn(cy.l0, t1, __fmul_rn(cy.l1, b1));
+                    m0 = fmaxf(m0, z0[c]);
+                    m1 = fmaxf(m1, z1[c]);
                 }
-            }
-#pragma unroll 4
-            for (int c = 0; c < CT; ++c) {
-                const float v00 = cv[0][c][cl], v01 = cv[1][c][cl], v10 = cv[2][c][cl], v11 = cv[3][c][cl];
+                float s0 = 0.f, s1 = 0.f, u0 = 0.f, u1 = 0.f;
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const float top = __fmaf_rn(lx0[a], v00, __fmul_rn(lx1[a], v01));
-                    const float bot = __fmaf_rn(lx0[a], v10, __fmul_rn(lx1[a], v11));
-                    const float z = __fmaf_rn(cy.l0, top, __fmul_rn(cy.l1, bot)) - m[a];
-                    const float e = expf(z);
-                    s[a] += e;
-                    tt[a] += e * z;
+                for (int c = 0; c < CT; ++c) {
+                    const float d0 = z0[c] - m0, d1 = z1[c] - m1;
+                    const float e0 = rf_exp_neg(d0), e1 = rf_exp_neg(d1);
+                    s0 += e0; u0 += e0 * d0;
+                    s1 += e1; u1 += e1 * d1;
+                }
+                s[2 * hf] = s0; s[2 * hf + 1] = s1; tt[2 * hf] = u0; tt[2 * hf + 1] = u1;
+            }
+            } else {      // more classes: the 2 x CT register copy would spill -> evaluate the bilinear form in both passes
+                float m[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { m[a] = -INFINITY; s[a] = 0.f; tt[a] = 0.f; }
+#pragma unroll 4
+                for (int c = 0; c < CT; ++c) {
+                    const float v00 = cv[0][c][cl], v01 = cv[1][c][cl], v10 = cv[2][c][cl], v11 = cv[3][c][cl];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const float top = __fmaf_rn(lx0[a], v00, __fmul_rn(lx1[a], v01));
+                        const float bot = __fmaf_rn(lx0[a], v10, __fmul_rn(lx1[a], v11));
+                        m[a] = fmaxf(m[a], __fmaf_rn(cy.l0, top, __fmul_rn(cy.l1, bot)));
+                    }
+                }
+#pragma unroll 4
+                for (int c = 0; c < CT; ++c) {
+                    const float v00 = cv[0][c][cl], v01 = cv[1][c][cl], v10 = cv[2][c][cl], v11 = cv[3][c][cl];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const float top = __fmaf_rn(lx0[a], v00, __fmul_rn(lx1[a], v01));
+                        const float bot = __fmaf_rn(lx0[a], v10, __fmul_rn(lx1[a], v11));
+                        const float z = __fmaf_rn(cy.l0, top, __fmul_rn(cy.l1, bot)) - m[a];
+                        const float e = rf_exp_neg(z);
+                        s[a] += e;
+                        tt[a] += e * z;
+                    }
                 }
             }
             const int nx = min(4, A.W - ox0);
@@ -486,7 +528,7 @@ __global__ __launch_bounds__(RF_T, 1) void k_reliability_fused(RfArgs A) {
                     const float top = __fmaf_rn(cx.l0, cv[0][c][cl], __fmul_rn(cx.l1, cv[1][c][cl]));
                     const float bot = __fmaf_rn(cx.l0, cv[2][c][cl], __fmul_rn(cx.l1, cv[3][c][cl]));
                     const float z = __fmaf_rn(cy.l0, top, __fmul_rn(cy.l1, bot)) - m;
-                    const float e = expf(z);
+                    const float e = rf_exp_neg(z);
                     sm += e;
                     tt += e * z;
                 }

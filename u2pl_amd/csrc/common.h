@@ -27,6 +27,24 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// All-lanes sum without the LDS crossbar: four DPP row rotations give every lane the total of its 16-lane row (VALU rate;
+// __shfl_xor compiles to ds_bpermute_b32, an LDS-pipeline instruction), the four row totals are read as wave-uniform
+// scalars.  The InfoNCE kernel does ~100 such reductions per anchor and was bound by them, not by HBM (a pure gather of
+// the same rows runs at 6 TB/s: tools/micro/gather_bench.hip).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_allsum_dpp(float v) {
+    v = dpp_add<0x128>(v);   // row_ror:8
+    v = dpp_add<0x124>(v);   // row_ror:4
+    v = dpp_add<0x122>(v);   // row_ror:2
+    v = dpp_add<0x121>(v);   // row_ror:1
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -517,22 +517,28 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
     float na = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) { a[i] = ar[i]; na += a[i] * a[i]; acc[i] = 0.f; }
-    na = fmaxf(sqrtf(wave_sum(na)), 1e-8f);
+    na = fmaxf(sqrtf(wave_allsum_dpp(na)), 1e-8f);
 #pragma unroll
     for (int i = 0; i < VPL; ++i) ah[i] = a[i] / na;
-    // online softmax over the 1+K logits, accumulating sum_j softmax_j * fhat_j.  Features are processed
-    // four at a time: four independent 1 KiB row loads in flight per wave and four interleaved shuffle
-    // reductions (the kernel is a latency-bound gather otherwise).
-    float m = -INFINITY, s = 0.f, l0 = 0.f, cw = 0.f;  // cw = sum_j w_j * cos_j (un-normalised)
+    // softmax over the 1+K logits, accumulating sum_j softmax_j * fhat_j.  The logits are cosines / temp, i.e. bounded by
+    // 1 / temp in magnitude: shifting by that bound keeps every exponent in [-2/temp, 0] (temp = 0.5: e^-4 .. 1), so no
+    // running maximum, no rescaling of the accumulators and ONE exp per row (the online-max form needed two exps and a
+    // dependent rescale chain across the rows).  Rows are processed four at a time: four independent 1 KiB row loads in
+    // flight per wave and eight interleaved all-lane sums.
+    float s = 0.f, l0 = 0.f, cw = 0.f;  // cw = sum_j w_j * cos_j (un-normalised)
+    const float shift = inv_temp;        // >= every logit
     float f0h[VPL];
     // the K sampled bank rows of this anchor: one coalesced index load, then lane broadcasts (no dependent
     // index -> row latency chain inside the loop)
     const bool pre = K <= 64;
     long myrow = 0;
-    if (pre && lane < K) myrow = (J.bank_head + J.idx_n[(long)q * K + lane]) % J.bank_cap;
+    // logical row -> physical slot of the ring: head + idx < 2 * cap (idx < length <= cap), so one conditional subtract
+    // replaces the 64-bit modulo (a ~40-instruction software division per row)
+    auto slot = [&](long long idx) -> long { const long r = J.bank_head + (long)idx; return r >= J.bank_cap ? r - J.bank_cap : r; };
+    if (pre && lane < K) myrow = slot(J.idx_n[(long)q * K + lane]);
     auto row_ptr = [&](int j) -> const float* {
         if (j == 0) return J.proto + lane * VPL;
-        const long r = pre ? __shfl(myrow, j - 1, 64) : (J.bank_head + J.idx_n[(long)q * K + (j - 1)]) % J.bank_cap;
+        const long r = pre ? __shfl(myrow, j - 1, 64) : slot(J.idx_n[(long)q * K + (j - 1)]);
         return J.bank + r * D + lane * VPL;
     };
     auto load4 = [&](float (&f)[4][VPL], int j0) {
@@ -548,43 +554,31 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             nf[u] = 0.f;
-#pragma unroll
-            for (int i = 0; i < VPL; ++i) nf[u] += f[u][i] * f[u][i];
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) nf[u] += __shfl_xor(nf[u], o, 64);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            nf[u] = fmaxf(sqrtf(nf[u]), 1e-8f);
             dot[u] = 0.f;
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) dot[u] += ah[i] * f[u][i];
+            for (int i = 0; i < VPL; ++i) { nf[u] += f[u][i] * f[u][i]; dot[u] += ah[i] * f[u][i]; }
         }
+        // eight independent all-lane sums (DPP row rotations + scalar row totals): no LDS-crossbar shuffles
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) dot[u] += __shfl_xor(dot[u], o, 64);
+        for (int u = 0; u < 4; ++u) { nf[u] = wave_allsum_dpp(nf[u]); dot[u] = wave_allsum_dpp(dot[u]); }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (j0 + u > K) continue;
-            // one division per row (wave-uniform) instead of one per element: cos = (ahat . f) / |f|
-            const float cosv = dot[u] / nf[u];
+            // one reciprocal per row (wave-uniform): cos = (ahat . f) / |f|, fhat = f / |f|
+            const float inv = 1.0f / fmaxf(sqrtf(nf[u]), 1e-8f);
+            const float cosv = dot[u] * inv;
             const float l = cosv * inv_temp;
             if (j0 + u == 0) {
                 l0 = l;
 #pragma unroll
-                for (int i = 0; i < VPL; ++i) f0h[i] = f[u][i] / nf[u];
+                for (int i = 0; i < VPL; ++i) f0h[i] = f[u][i] * inv;
             }
-            const float mn = fmaxf(m, l);
-            const float sc = expf(m - mn), w = expf(l - mn);
-            s = s * sc + w;
-            cw = cw * sc + w * cosv;
-            const float wn = w / nf[u];   // softmax weight x 1/|f| : acc accumulates w * fhat
+            const float w = expf(l - shift);
+            s += w;
+            cw += w * cosv;
+            const float wn = w * inv;   // softmax weight x 1/|f| : acc accumulates w * fhat
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) acc[i] = acc[i] * sc + wn * f[u][i];
-            m = mn;
+            for (int i = 0; i < VPL; ++i) acc[i] += wn * f[u][i];
         }
     };
     // two batches of four rows in flight: the next batch is requested before the current one is reduced
@@ -598,7 +592,7 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
         if (j0 + 8 <= K) load4(fa, j0 + 8);
         process4(fb, j0 + 4);
     }
-    const float lse = m + logf(s);
+    const float lse = shift + logf(s);
     if (lane == 0) {
         const int e = job * Q + q;
         loss_q[e] = lse - l0;

@@ -45,6 +45,24 @@ __device__ __forceinline__ float wave_allsum_dpp(float v) {
     const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
     return (r0 + r1) + (r2 + r3);
 }
+// wave total as a wave-uniform scalar: row rotations, then the gfx9 wave-level DPP broadcasts (row_bcast:15 adds the
+// previous row's total into rows 1 and 3, row_bcast:31 adds lane 31's into rows 2 and 3): lane 63 holds the total.
+// 6 DPP adds + 1 readlane.
+__device__ __forceinline__ float wave_sum_sgpr(float v) {
+    v = dpp_add<0x128>(v);
+    v = dpp_add<0x124>(v);
+    v = dpp_add<0x122>(v);
+    v = dpp_add<0x121>(v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));   // row_bcast:15
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));   // row_bcast:31
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float lane_put(float old, float val, int lane) {   // val is wave-uniform: one v_cndmask
+    return (int)(threadIdx.x & 63) == lane ? val : old;
+}
+__device__ __forceinline__ float lane_get(float v, int lane) {                // v_readlane_b32 -> wave-uniform
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

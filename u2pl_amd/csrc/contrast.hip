@@ -517,7 +517,7 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
     float na = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) { a[i] = ar[i]; na += a[i] * a[i]; acc[i] = 0.f; }
-    na = fmaxf(sqrtf(wave_allsum_dpp(na)), 1e-8f);
+    na = fmaxf(sqrtf(wave_sum_sgpr(na)), 1e-8f);
 #pragma unroll
     for (int i = 0; i < VPL; ++i) ah[i] = a[i] / na;
     // softmax over the 1+K logits, accumulating sum_j softmax_j * fhat_j.  The logits are cosines / temp, i.e. bounded by
@@ -558,27 +558,34 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
 #pragma unroll
             for (int i = 0; i < VPL; ++i) { nf[u] += f[u][i] * f[u][i]; dot[u] += ah[i] * f[u][i]; }
         }
-        // eight independent all-lane sums (DPP row rotations + scalar row totals): no LDS-crossbar shuffles
+        // eight wave totals (DPP only, no LDS-crossbar shuffles), parked in lanes 0..3 of two registers so that the
+        // per-row scalar chain (sqrt, reciprocal, exp) runs ONCE for the four rows instead of four times on all lanes
+        float vn = 1.f, vd = 0.f;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { nf[u] = wave_allsum_dpp(nf[u]); dot[u] = wave_allsum_dpp(dot[u]); }
+        for (int u = 0; u < 4; ++u) {
+            vn = lane_put(vn, wave_sum_sgpr(nf[u]), u);
+            vd = lane_put(vd, wave_sum_sgpr(dot[u]), u);
+        }
+        // cos = (ahat . f) / |f|, fhat = f / |f|; softmax weight w = exp(l - shift)
+        const float vinv = 1.0f / fmaxf(sqrtf(vn), 1e-8f);
+        const float vcos = vd * vinv;
+        const float vl = vcos * inv_temp;
+        const float vw = expf(vl - shift);
+        const float vwn = vw * vinv;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (j0 + u > K) continue;
-            // one reciprocal per row (wave-uniform): cos = (ahat . f) / |f|, fhat = f / |f|
-            const float inv = 1.0f / fmaxf(sqrtf(nf[u]), 1e-8f);
-            const float cosv = dot[u] * inv;
-            const float l = cosv * inv_temp;
+            const float w = lane_get(vw, u), cosv = lane_get(vcos, u), wn = lane_get(vwn, u);
             if (j0 + u == 0) {
-                l0 = l;
+                l0 = lane_get(vl, u);
+                const float inv = lane_get(vinv, u);
 #pragma unroll
                 for (int i = 0; i < VPL; ++i) f0h[i] = f[u][i] * inv;
             }
-            const float w = expf(l - shift);
             s += w;
             cw += w * cosv;
-            const float wn = w * inv;   // softmax weight x 1/|f| : acc accumulates w * fhat
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) acc[i] += wn * f[u][i];
+            for (int i = 0; i < VPL; ++i) acc[i] += wn * f[u][i];   // acc accumulates w * fhat
         }
     };
     // two batches of four rows in flight: the next batch is requested before the current one is reduced

@@ -223,7 +223,17 @@ def reliability_split(logits_low, size, label_l, label_u_aug, out_hw, percents, 
          low, high, lbits, ws, cand, G, slot[3] & 0x3FFFFFF)
     slot[3] += 1
     return dict(entropy=ent, thr=ws[16:16 + nspec].view(torch.float32), target_u=target, low_mask=low, high_mask=high,
-                lbits=lbits, nkept=ws[2:3])
+                lbits=lbits, nkept=ws[2:3], err=ws[3:4])
+
+
+def check_split(rs):
+    """the persistent split kernel gives up (error word set, results undefined) when its blocks could not all become
+    resident within ~0.5 s -- e.g. another process occupying the GPU.  Called where the step synchronises anyway."""
+    err = rs.get("err") if isinstance(rs, dict) else None
+    if err is not None and int(err) != 0:
+        err.zero_()
+        raise _lib.HipError("u2pl_reliability_fused: device-wide barrier timed out (GPU shared with another workload?); "
+                            "set U2PL_NO_FUSED_SPLIT=1 to use the multi-launch path")
 
 
 # --------------------------------------------------------------------------- cross entropy

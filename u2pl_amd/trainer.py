@@ -308,6 +308,7 @@ class SemiTrainer:
                 _, contra_local = LH.contra_memobank_core(
                     rep_all, lbits, B, prob_all_t[:B], prob_all_t[B:], low_mask, high_mask, ccfg, self.memobank,
                     rep_all_t, randint=randint)
+                H.check_split(rs)     # (the contrastive block just synchronised with the host: this read is free)
                 # Q5: value = cross-rank mean, gradient = local / world
                 contra_loss = contra_local * (float(ccfg.get("loss_weight", 1)) / _world())
             else:

@@ -25,6 +25,10 @@ def _worker(rank, world, port, fn, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
+    # two processes on ONE GPU: the persistent reliability-split kernel needs all of its blocks co-resident for its
+    # device-wide barriers; two of them launched in lockstep by the two ranks can starve each other (the kernel then
+    # reports a barrier timeout and the op raises).  One process per GPU -- the production layout -- has no such peer.
+    os.environ["U2PL_NO_FUSED_SPLIT"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ret[rank] = fn(rank, world)
@@ -113,7 +117,7 @@ def test_bench_two_ranks_runs_and_reports_weak_scaling_line():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, U2PL_DIST_BACKEND="gloo")
+    env = dict(os.environ, U2PL_DIST_BACKEND="gloo")   # (bench.py itself drops the persistent split when ranks share a GPU)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--arch", "resnet50", "--crop", "193"]

@@ -478,13 +478,17 @@ U2PL_API int u2pl_weight_transpose_f32(const float* w, float* wt, int Cout, int 
 // MFMA operand fetch (lane l -> row k = 2*kk + (l>>5), column l&31) is a
 // conflict-free ds_read_b32.
 // ---------------------------------------------------------------------------
-template <int TM, int TN>
-__global__ __launch_bounds__(256, 2) void k_conv_wgrad(const float* __restrict__ dy, long lddy,
-                                                       const float* __restrict__ x, long ldx,
-                                                       float* __restrict__ part, ConvGeom g, int ctiles,
-                                                       int chunks_per_split, unsigned dybytes, unsigned xbytes,
-                                                       long zdy, long zx) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+// WM = wave rows of the block (2: 4 waves; 4: 8 waves with half the output rows per wave -- the 128x128 tile then keeps
+// 16 waves per CU in flight instead of 8, like the forward kernel's 8-wave body)
+template <int TM, int TN, int WM = 2>
+__global__ __launch_bounds__(128 * WM, 2) void k_conv_wgrad(const float* __restrict__ dy, long lddy,
+                                                            const float* __restrict__ x, long ldx,
+                                                            float* __restrict__ part, ConvGeom g, int ctiles,
+                                                            int chunks_per_split, unsigned dybytes, unsigned xbytes,
+                                                            long zdy, long zx) {
+    constexpr int BM = 32 * TM * WM, BN = 64 * TN;
+    constexpr int QL = 128 * WM / BK;        // threads per pixel row of a chunk (8 | 16), one float4 each per pass
+    constexpr int CW = 4 * QL;               // channels covered per pass (32 | 64)
     // batched use (Winograd components as "taps" with an identity gather): tap t reads dy + t*zdy, x + t*zx
     {
         const int tap_b = blockIdx.x / ctiles;
@@ -506,8 +510,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const float* __restrict__
     const long c_begin = (long)blockIdx.z * chunks_per_split;
     const long c_end = min(nchunks, c_begin + chunks_per_split);
 
-    const int prow = tid >> 3, q = tid & 7;  // pixel row in chunk, float4 lane within 32 channels
-    constexpr int JA = BM / 32, JB = BN / 32;
+    const int prow = tid / QL, q = tid % QL;  // pixel row in chunk, float4 lane within CW channels
+    constexpr int JA = BM / CW, JB = BN / CW;
+    static_assert(BM % CW == 0 && BN % CW == 0, "tile narrower than one load pass");
     float4 ra[JA], rb[JB];
     const int lddyb = (int)lddy * 4, ldxb = (int)ldx * 4;
     // Cout, Cin are multiples of 4 (host pads narrow heads): a float4 is entirely in or out of range
@@ -528,20 +533,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const float* __restrict__
         const int xo = (n * g.Hin * g.Win + ih * g.Win + iw) * ldxb;
 #pragma unroll
         for (int j = 0; j < JA; ++j) {
-            const int co = co0 + j * 32 + q * 4;
+            const int co = co0 + j * CW + q * 4;
             ra[j] = buf_load4(rdy, (mv & (co < g.Cout)) ? dyo + co * 4 : OOB_OFF);
         }
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
-            const int ci = ci0 + j * 32 + q * 4;
+            const int ci = ci0 + j * CW + q * 4;
             rb[j] = buf_load4(rx, (okb & (ci < g.Cin)) ? xo + ci * 4 : OOB_OFF);
         }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < JA; ++j) *(float4*)(As + ((long)buf * BK + prow) * PA + j * 32 + q * 4) = ra[j];
+        for (int j = 0; j < JA; ++j) *(float4*)(As + ((long)buf * BK + prow) * PA + j * CW + q * 4) = ra[j];
 #pragma unroll
-        for (int j = 0; j < JB; ++j) *(float4*)(Bs + ((long)buf * BK + prow) * PB + j * 32 + q * 4) = rb[j];
+        for (int j = 0; j < JB; ++j) *(float4*)(Bs + ((long)buf * BK + prow) * PB + j * CW + q * 4) = rb[j];
     };
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -765,21 +770,30 @@ U2PL_API size_t u2pl_conv2d_wgrad_workspace_bytes(int N, int Hout, int Wout, int
     return (size_t)ns * Cout * R * S * Cin * sizeof(float);
 }
 
-template <int TM, int TN>
+// U2PL_WGRAD_WAVES = 8 (default) | 4: block shape of the 128x128 weight-gradient tile (A/B switch; same results)
+static int wgrad_waves() {
+    static int v = 0;
+    if (!v) {
+        const char* e = getenv("U2PL_WGRAD_WAVES");
+        v = (e && atoi(e) == 4) ? 4 : 8;
+    }
+    return v;
+}
+template <int TM, int TN, int WM = 2>
 static int launch_wgrad(const float* dy, long lddy, const float* x, long ldx, float* part, const ConvGeom& g,
                         int ctiles, int nsplit, int cps, hipStream_t stream, long zdy = 0, long zx = 0) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int BM = 32 * TM * WM, BN = 64 * TN;
     const size_t lds = (size_t)2 * BK * (BM + 4 + BN + 4) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_conv_wgrad<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_conv_wgrad<TM, TN, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const long dyb = (((long)g.N * g.Hout * g.Wout - 1) * lddy + g.Cout) * 4;
     const long xb = (((long)g.N * g.Hin * g.Win - 1) * ldx + g.Cin) * 4;
     if (dyb >= (1L << 31) || xb >= (1L << 31)) return U2PL_EINVAL;
     dim3 grid((unsigned)(ctiles * g.R * g.S), (unsigned)cdiv(g.Cout, BM), (unsigned)nsplit);
-    hipLaunchKernelGGL((k_conv_wgrad<TM, TN>), grid, dim3(256), lds, stream, dy, lddy, x, ldx, part, g, ctiles, cps,
+    hipLaunchKernelGGL((k_conv_wgrad<TM, TN, WM>), grid, dim3(128 * WM), lds, stream, dy, lddy, x, ldx, part, g, ctiles, cps,
                        (unsigned)dyb, (unsigned)xb, zdy, zx);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -797,7 +811,9 @@ U2PL_API int u2pl_conv2d_wgrad_f32(const float* dy, long lddy, const float* x, l
     wgrad_plan(g, BM, BN, ct, ns, cps);
     float* part = (float*)workspace;
     int rc;
-    if (BM == 128 && BN == 128) rc = launch_wgrad<2, 2>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
+    if (BM == 128 && BN == 128)
+        rc = wgrad_waves() == 8 ? launch_wgrad<1, 2, 4>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream)
+                                : launch_wgrad<2, 2>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
     else if (BM == 128) rc = launch_wgrad<2, 1>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
     else if (BN == 128) rc = launch_wgrad<1, 2>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
     else rc = launch_wgrad<1, 1>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
@@ -868,7 +884,9 @@ U2PL_API int u2pl_wgrad_batched_f32(const float* dy, long lddy, long zdy, const 
     const int BM = Cout > 64 ? 128 : 64, BN = Cin > 64 ? 128 : 64;
     int ct, ns, cps;
     wgrad_plan(g, BM, BN, ct, ns, cps);
-    if (BM == 128 && BN == 128) return launch_wgrad<2, 2>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx);
+    if (BM == 128 && BN == 128)
+        return wgrad_waves() == 8 ? launch_wgrad<1, 2, 4>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx)
+                                  : launch_wgrad<2, 2>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx);
     if (BM == 128) return launch_wgrad<2, 1>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx);
     if (BN == 128) return launch_wgrad<1, 2>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx);
     return launch_wgrad<1, 1>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx);

@@ -189,7 +189,9 @@ def reliability_split(logits_low, size, label_l, label_u_aug, out_hw, percents, 
     dev = logits_low.device
     nspec = len(percents)
     if fused is None:
-        fused = os.environ.get("U2PL_NO_FUSED_SPLIT") is None
+        # the persistent kernel owns the GPU for its two device-wide barriers: not when several ranks share one device
+        fused = (os.environ.get("U2PL_NO_FUSED_SPLIT") is None
+                 and int(os.environ.get("LOCAL_WORLD_SIZE", "1")) <= torch.cuda.device_count())
     ok = (fused and C in (19, 21) and nspec in (1, 3) and h >= 2 and w >= 2 and H - 1 == 4 * (h - 1) and W - 1 == 4 * (w - 1)
           and H <= 1024 and W <= 1024 and hm <= H and wm <= W and 0 <= ignore <= 255)
     if ok:

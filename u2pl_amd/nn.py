@@ -355,7 +355,7 @@ class _BNFn(torch.autograd.Function):
             count = float(M)
             if sync:
                 sums[2 * C] = float(M)
-                dist.all_reduce(sums)
+                dist.all_reduce(sums, group=mod.group)
                 count = float(M * _world())  # equal per-rank shapes (drop_last loaders)
             mean = torch.empty(C, dtype=torch.float32, device=dev)
             invstd = torch.empty(C, dtype=torch.float32, device=dev)
@@ -370,7 +370,7 @@ class _BNFn(torch.autograd.Function):
         call("u2pl_bn_apply_f32", x, ldx, mean, invstd, gamma, beta, rr, ldr or 0, int(relu), drop, H * W, y, C, M, C)
         ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma, drop)
         ctx.meta = (N, C, H, W, ldx, training, sync, count, res is not None)
-        ctx.gsink, ctx.bsink = gsink, bsink
+        ctx.gsink, ctx.bsink, ctx.group = gsink, bsink, mod.group
         return y
 
     @staticmethod
@@ -397,7 +397,7 @@ class _BNFn(torch.autograd.Function):
                 call("u2pl_sums_to_f32", sums[C:], C, 1.0, 0, dgamma)
                 call("u2pl_sums_to_f32", sums, C, 1.0, 0, dbeta)
         if sync and training:
-            dist.all_reduce(sums)
+            dist.all_reduce(sums, group=ctx.group)
         dx = new_act(N, C, H, W, dev) if ctx.needs_input_grad[0] else None
         dres = new_act(N, C, H, W, dev) if has_res and ctx.needs_input_grad[3] else None
         if dx is not None:
@@ -414,6 +414,7 @@ class BatchNorm2d(nn.Module):
     def __init__(self, num_features, eps=1e-5, momentum=0.1, sync=False):
         super().__init__()
         self.num_features, self.eps, self.momentum, self.sync = num_features, eps, momentum, sync
+        self.group = None     # process group of the statistics exchange (None: the default group); see use_process_group
         self.weight = nn.Parameter(torch.ones(num_features))
         self.bias = nn.Parameter(torch.zeros(num_features))
         self.register_buffer("running_mean", torch.zeros(num_features))
@@ -437,6 +438,16 @@ def conv_bn(conv, bn, x, res=None, relu=False, drop=None):
         y, sums = conv(x, stat_pivot=bn.running_mean)
         return bn(y, res=res, relu=relu, drop=drop, pre_sums=sums)
     return bn(conv(x), res=res, relu=relu, drop=drop)
+
+
+def use_process_group(model, group):
+    """Route the SyncBN statistics exchange of every BatchNorm of `model` through `group`.  Collectives of one communicator
+    execute in issue order on its own stream: the teacher's passes (side HIP stream) and the student's forward (main
+    stream) only overlap across ranks when their per-layer all-reduces do not queue behind each other, so the trainer
+    gives the teacher a communicator of its own."""
+    for m in model.modules():
+        if isinstance(m, BatchNorm2d):
+            m.group = group
 
 
 class SyncBatchNorm(BatchNorm2d):
@@ -706,6 +717,7 @@ class ParamArena:
                 lo, count = end, 0
         self._pending = [b[2] for b in self.buckets]
         self._works = [None] * len(self.buckets)
+        self._next = len(self.buckets) - 1
         self._streams = ()
 
     def zero_grad(self):
@@ -713,6 +725,7 @@ class ParamArena:
         if self.buckets:
             self._pending = [b[2] for b in self.buckets]
             self._works = [None] * len(self.buckets)
+            self._next = len(self.buckets) - 1
             if self.grad.is_cuda:
                 ws = _WGRAD["stream"]
                 self._streams = tuple(x for x in (torch.cuda.current_stream(), ws) if x is not None)
@@ -729,10 +742,13 @@ class ParamArena:
     def mark_ready(self, pidx):
         if _world() <= 1 or not self.buckets or os.environ.get("U2PL_NO_BUCKET_OVERLAP") is not None:
             return
-        b = self._bucket_of[pidx]
-        self._pending[b] -= 1
-        if self._pending[b] == 0 and self._works[b] is None:
-            self._launch(b)
+        self._pending[self._bucket_of[pidx]] -= 1
+        # Buckets go out in ONE fixed order (last bucket first, the order backward fills them), like DDP's reducer: the
+        # sequence of collectives on the communicator is then the same on every rank even when the ranks' autograd
+        # graphs differ at the top (a rank without contrastive anchors back-propagates 0 * rep.sum(), Q13).
+        while self._next >= 0 and self._pending[self._next] == 0:
+            self._launch(self._next)
+            self._next -= 1
 
     def finish_allreduce(self):
         """after backward: reduce whatever was not launched from the hooks (parameters without a gradient this step,
@@ -742,9 +758,9 @@ class ParamArena:
         if not self.buckets:
             dist.all_reduce(self.grad)
             return
-        for b in range(len(self.buckets)):
-            if self._works[b] is None:
-                self._launch(b)
+        while self._next >= 0:      # same descending order as the hooks
+            self._launch(self._next)
+            self._next -= 1
         for w in self._works:
             w.wait()
 

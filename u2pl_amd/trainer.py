@@ -117,6 +117,11 @@ class SemiTrainer:
         self.t_arena = K.ParamArena(tgroups, with_grad=False)
         for p in model_teacher.parameters():
             p.requires_grad = False
+        if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+                and os.environ.get("U2PL_TEACHER_COMM", "1") != "0"):
+            # the teacher's train-mode forward runs on the side HIP stream next to the student's forward: its ~105 SyncBN
+            # all-reduces get their own communicator (every rank builds the trainer, so new_group is collective-safe)
+            K.use_process_group(model_teacher, dist.new_group())
         C = cfg["net"]["num_classes"]
         self.num_classes = C
         dev = next(model.parameters()).device

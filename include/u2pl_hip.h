@@ -163,6 +163,15 @@ int u2pl_conv2d_fwd_bnstats_f32(const float* x, long ldx, const float* w, const 
                                 int stride, int pad, int dil, const float* pivot, float* stats_partial,
                                 hipStream_t stream);
 int u2pl_colreduce_finish_f32(const float* partial, int nblk, int C, double* sums, hipStream_t stream);
+/* forward + the EVAL-mode BatchNorm (+ residual, ReLU) that follows it, applied in the conv epilogue: the conv -> bn -> relu
+ * (-> += identity) chains of resnet.py:118-138, base.py:23-83, decoder.py:60-106 when the model is in eval mode (teacher
+ * pseudo-label pass train_semi.py:317-324, validate() :595-654, eval.py).  y = [relu]((conv + bias - mean) * invstd * gamma
+ * + beta [+ res]) with the operation order of u2pl_bn_apply_f32, i.e. bit-identical to conv followed by that kernel.
+ * res: [N*Hout*Wout][ldr] rows or NULL; Cout % 4 == 0 */
+int u2pl_conv2d_fwd_bnact_f32(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, int N,
+                              int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S, int stride,
+                              int pad, int dil, const float* mean, const float* invstd, const float* gamma,
+                              const float* beta, const float* res, long ldr, int relu, hipStream_t stream);
 /* batch independent row-major GEMMs Y_z[M][Nn] = X_z[M][K] * W_z[Nn][K]^T on the fp32 matrix cores (element
    strides zx/zw/zy between the problems): the component products of the Winograd convolutions below */
 int u2pl_gemm_batched_f32(const float* x, long ldx, long zx, const float* w, long zw, float* y, long ldy, long zy,
@@ -189,6 +198,10 @@ int u2pl_wino_wgrad_finish_f32(const float* part, int nsplit, int O, int C, int 
                                hipStream_t stream);
 int u2pl_wino_output_f32(const float* Mb, int N, int H, int W, int O, int dil, int mt, const float* bias, float* y,
                          long ldy, float* stats_partial, const float* pivot, hipStream_t stream);
+/* Winograd form of u2pl_conv2d_fwd_bnact_f32: the output transform applies the eval-mode BatchNorm (+res, ReLU) */
+int u2pl_wino_output_bnact_f32(const float* Mb, int N, int H, int W, int O, int dil, int mt, const float* bias, float* y,
+                               long ldy, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                               const float* res, long ldr, int relu, hipStream_t stream);
 /* BASELINE configs[4] ("config 5": reduced-precision student, fp32 EMA teacher / master weights): the same three
  * convolution products with the operands rounded to bf16 (RNE) while they are staged into LDS and multiplied on the
  * bf16 matrix cores (v_mfma_f32_32x32x16_bf16) with fp32 accumulation; every tensor in HBM stays fp32.  Arguments as the

@@ -340,6 +340,17 @@ def test_model_builder_vs_reference_golden(tag, arch, S, C, aux, conv_algo):
         oe = model(x)
     chk(oe["pred"], "pred_eval", "pred_eval64", "pred_eval")
     chk(oe["rep"], "rep_eval", "rep_eval64", "rep_eval")
+    # the no-grad eval forward above ran every conv -> BN (-> +identity -> ReLU) chain in the conv epilogue / Winograd
+    # output transform (nn.conv_bn_eval); the two-kernel form (conv, then u2pl_bn_apply_f32) must give the same BITS
+    assert Kn.FUSE_EVAL_BN
+    Kn.FUSE_EVAL_BN = False
+    try:
+        with torch.no_grad():
+            ou = model(x)
+    finally:
+        Kn.FUSE_EVAL_BN = True
+    for k_ in ("pred", "rep") + (("aux",) if aux else ()):
+        assert torch.equal(ou[k_], oe[k_]), f"fused eval-BN epilogue changed {k_}: max diff {(ou[k_] - oe[k_]).abs().max().item():.3e}"
     print("\n".join(f"{k}: hip {v[0]:.3e} ref32 {v[1]:.3e}" for k, v in report.items()))
     assert not fails, "\n".join(fails)
 

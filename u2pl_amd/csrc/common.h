@@ -140,3 +140,14 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, int byte_o
     u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+
+// ---- fused eval-mode BatchNorm epilogue --------------------------------------
+// Eval-mode BatchNorm (+ residual, ReLU) applied in the GEMM epilogue instead of a separate pass over the conv output
+// (u2pl_conv2d_fwd_bnact_f32): y = [relu]((v - mean) * invstd * gamma + beta [+ res]), the arithmetic of k_bn_apply
+// (csrc/nn.hip) operation for operation, so the fused and the two-kernel forms give identical bits.  mean == NULL: off.
+struct BnEpi {
+    const float *mean, *invstd, *gamma, *beta, *res;
+    long ldr;
+    int relu;
+};
+

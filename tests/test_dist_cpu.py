@@ -136,3 +136,40 @@ def test_bucketed_gradient_allreduce_overlaps_and_equals_flat_allreduce():
         for same, early, nb in r:
             assert same
             assert 1 <= early < nb         # some buckets went out from the hooks, the one with the silent parameter did not
+
+
+def test_bucket_launch_order_is_fixed_whatever_order_the_gradients_arrive(monkeypatch):
+    """host logic only (no process group): buckets are handed to the communicator strictly from the last one down,
+    like DDP's reducer, so every rank issues the same sequence of collectives even if its autograd graph differs"""
+    os.environ["U2PL_BUCKET_MB"] = "0.002"
+    from u2pl_amd import nn as K
+    monkeypatch.setattr(K, "_world", lambda: 2)
+    g = torch.Generator().manual_seed(3)
+    params = [torch.nn.Parameter(torch.randn(600, generator=g)) for _ in range(6)]     # one parameter per bucket
+    arena = K.ParamArena([params])
+    assert len(arena.buckets) == 6
+    launched = []
+    monkeypatch.setattr(arena, "_launch", lambda b: (launched.append(b), arena._works.__setitem__(b, "sent")))
+    arena.zero_grad()
+    for i in (0, 5, 2, 4):                     # gradients arrive out of order; 3 and 1 are still missing
+        K._mark_ready(params[i]._u2pl_grad)
+    assert launched == [5, 4]                  # 2 and 0 are complete but wait for 3 (and 1)
+    K._mark_ready(params[3]._u2pl_grad)
+    assert launched == [5, 4, 3, 2]
+    K._mark_ready(params[1]._u2pl_grad)
+    assert launched == [5, 4, 3, 2, 1, 0]
+    # next step: the pointer is re-armed
+    arena.zero_grad()
+    launched.clear()
+    K._mark_ready(params[5]._u2pl_grad)
+    assert launched == [5]
+
+
+def test_use_process_group_routes_every_batchnorm():
+    from u2pl_amd import nn as K
+    net = torch.nn.Sequential(K.Conv2d(32, 32, 3, padding=1, bias=False), K.SyncBatchNorm(32), torch.nn.ReLU(),
+                              torch.nn.Sequential(K.Conv2d(32, 64, 1, bias=False), K.BatchNorm2d(64)))
+    token = object()
+    K.use_process_group(net, token)
+    bns = [m for m in net.modules() if isinstance(m, K.BatchNorm2d)]
+    assert len(bns) == 2 and all(m.group is token for m in bns)

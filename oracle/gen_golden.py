@@ -163,17 +163,28 @@ def formula_bank(c, n, D):
     return (((r * 131 + d * 31 + c * 17 + (r * d) % 7) % 1000).float() / 500.0 - 1.0)
 
 
-def gen_contra(ns, seed, B, S, s, C, alpha_t, tag, prefill=0, steps=1, queue_size=3000, D=256):
-    """steps>1: call the reference repeatedly on fresh inputs (bank carries over)."""
+def gen_contra(ns, seed, B, S, s, C, alpha_t, tag, prefill=0, steps=1, queue_size=3000, D=256, temperature=None,
+               queue_size0=None, prefill0=None):
+    """steps>1: call the reference repeatedly on fresh inputs (bank carries over).
+    temperature: overrides CONTRA_CFG's 0.5 (stored in the fixture); queue_size0 / prefill0: capacity / pre-fill of class 0
+    (the real run uses 30000 and 50000 for class 0, train_semi.py:161-169; with a pre-fill just below capacity the
+    enqueue of step 0 wraps the ring and step 1 samples from a wrapped ring)."""
     torch.manual_seed(seed + 1000)  # global generator used by torch.randint inside the reference
+    cfg = dict(CONTRA_CFG)
+    if temperature is not None:
+        cfg["temperature"] = temperature
+    fill = [prefill + 3 * i for i in range(C)]
+    if prefill0 is not None:     # "just below capacity" fixtures: every class `prefill` rows, class 0 `prefill0`
+        fill = [prefill0] + [prefill] * (C - 1)
     memobank = [[torch.zeros(0, D)] for _ in range(C)]
     if prefill:
-        memobank = [[formula_bank(i, prefill + 3 * i, D)] for i in range(C)]
+        memobank = [[formula_bank(i, fill[i], D)] for i in range(C)]
     queue_ptrlis = [torch.zeros(1, dtype=torch.long) for _ in range(C)]
     queue_size_l = [queue_size] * C
-    queue_size_l[0] = queue_size + 500
+    queue_size_l[0] = queue_size + 500 if queue_size0 is None else queue_size0
     fx = dict(num_steps=np.int64(steps), queue_size=np.array(queue_size_l), alpha_t=np.float64(alpha_t),
-              prefill=np.int64(prefill), D=np.int64(D))
+              prefill=np.int64(prefill), D=np.int64(D), temperature=np.float64(cfg["temperature"]),
+              fill=np.array(fill if prefill else [0] * C))
     for st in range(steps):
         inp = make_step_inputs(seed + 31 * st, B, S, s, C, D=D)
         rs = relsplit_reference(ns, inp["pred_u_large_teacher"], inp["label_u_aug"], inp["label_l"], alpha_t, (s, s), C)
@@ -181,7 +192,7 @@ def gen_contra(ns, seed, B, S, s, C, alpha_t, tag, prefill=0, steps=1, queue_siz
         rng_state = torch.get_rng_state()
         new_keys, loss = ns.loss_helper.compute_contra_memobank_loss(
             rep, rs["label_l_small"], rs["label_u_small"], inp["prob_all"][:B], inp["prob_all"][B:],
-            rs["low_mask_all"], rs["high_mask_all"], CONTRA_CFG, memobank, queue_ptrlis, queue_size_l,
+            rs["low_mask_all"], rs["high_mask_all"], cfg, memobank, queue_ptrlis, queue_size_l,
             inp["rep_teacher"])
         loss.backward()
         p = f"s{st}_"
@@ -853,6 +864,86 @@ def gen_eval_window(ns, tag, H, W, crop, seed):
     save(f"evalwin_{tag}", x=x, out=out, out64=out64.float(), crop=np.int64(crop))
 
 
+def _pattern(key, n, scale, mul):
+    """low-entropy closed-form values (period 251, exact in fp32): the ~0.5 GB checkpoint gzips to < 1 MB"""
+    h = sum((i + 1) * ord(c) for i, c in enumerate(key)) % 251
+    idx = torch.arange(n, dtype=torch.int64)
+    return (((idx * mul + h) % 251) - 125).to(torch.float32) / scale
+
+
+def gen_ref_ckpt(ns):
+    """A ckpt.pth produced the way the reference produces it (train_semi.py:61-120 and 210-224), committed gzipped as
+    tests/golden/ref_ckpt_r50.pth.gz together with ref_ckpt_r50.npz (which optimizer index is which parameter, by name,
+    as seen from the REFERENCE's objects -- the independent statement of the group order our loader must reproduce).
+
+    reference ModelBuilder (R50 + aux head) x 2, the reference's parameter groups [encoder | auxor, decoder]
+    (train_semi.py:79-110) into the reference's get_optimizer (lr_helper.py:12-27), DistributedDataParallel wrappers
+    (-> `module.` keys), ONE optimizer.step() so that momentum buffers exist, then the dict of train_semi.py:210-216 and
+    torch.save.  Parameter / gradient VALUES are low-entropy patterns (not trained weights) so the file compresses."""
+    import copy
+    import gzip
+    import io
+    net = dict(
+        num_classes=19, sync_bn=False, ema_decay=0.99,
+        encoder=dict(type="u2pl.models.resnet.resnet50",
+                     kwargs=dict(multi_grid=True, zero_init_residual=True, fpn=True,
+                                 replace_stride_with_dilation=[False, True, True], pretrained=False)),
+        decoder=dict(type="u2pl.models.decoder.dec_deeplabv3_plus", kwargs=dict(inner_planes=256, dilations=[12, 24, 36])),
+        aux_loss=dict(aux_plane=1024, loss_weight=0.4),
+    )
+    cfg_optim = dict(type="SGD", kwargs=dict(lr=0.01, momentum=0.9, weight_decay=0.0005))
+    model = ns.model_helper.ModelBuilder(copy.deepcopy(net))
+    modules_back, modules_head = [model.encoder], [model.auxor, model.decoder]       # train_semi.py:79-84
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if v.dtype.is_floating_point:
+                v.copy_(_pattern("s:" + k, v.numel(), 256.0, 7).reshape(v.shape))
+    params_list = []
+    for module in modules_back:                                                      # train_semi.py:102-110
+        params_list.append(dict(params=module.parameters(), lr=cfg_optim["kwargs"]["lr"]))
+    for module in modules_head:
+        params_list.append(dict(params=module.parameters(), lr=cfg_optim["kwargs"]["lr"] * 1))
+    optimizer = ns.lr_helper.get_optimizer(params_list, cfg_optim)
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    for n, p in model.named_parameters():
+        p.grad = _pattern("g:" + n, p.numel(), 1024.0, 5).reshape(p.shape)
+    optimizer.step()
+    model = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=False)    # train_semi.py:114-120
+    teacher = ns.model_helper.ModelBuilder(copy.deepcopy(net))
+    with torch.no_grad():
+        for k, v in teacher.state_dict().items():
+            if v.dtype.is_floating_point:
+                v.copy_(_pattern("t:" + k, v.numel(), 512.0, 11).reshape(v.shape))
+    teacher = torch.nn.parallel.DistributedDataParallel(teacher, find_unused_parameters=False)
+    state = {"epoch": 3, "model_state": model.state_dict(), "optimizer_state": optimizer.state_dict(),    # train_semi.py:210-216
+             "teacher_state": teacher.state_dict(), "best_miou": 0.4321}
+    buf = io.BytesIO()
+    torch.save(state, buf)
+    raw = buf.getvalue()
+    path = os.path.join(OUT, "ref_ckpt_r50.pth.gz")
+    with gzip.open(path, "wb", compresslevel=6) as f:
+        f.write(raw)
+    print("wrote", path, len(raw) >> 20, "MiB ->", os.path.getsize(path) >> 10, "KiB")
+    osd = optimizer.state_dict()
+    names, group_of = [], []
+    flat = [p for g in optimizer.param_groups for p in g["params"]]
+    for gi, g in enumerate(osd["param_groups"]):
+        for i in g["params"]:
+            names.append(name_of[id(flat[i])])
+            group_of.append(gi)
+    probe = ["encoder.conv1.0.weight", "encoder.layer3.4.conv2.weight", "auxor.aux.0.weight", "decoder.classifier.8.bias",
+             "decoder.aspp.conv3.1.weight"]
+    fx = dict(opt_names=np.array(names), opt_group=np.array(group_of), probe=np.array(probe),
+              group_lr=np.array([g["lr"] for g in osd["param_groups"]]), n_model_keys=np.int64(len(state["model_state"])))
+    for n in probe:
+        i = names.index(n)
+        fx["mom_head__" + n] = osd["state"][i]["momentum_buffer"].flatten()[:16]
+        fx["mom_sum__" + n] = osd["state"][i]["momentum_buffer"].double().sum()
+        fx["par_head__" + n] = state["model_state"]["module." + n].flatten()[:16]
+        fx["tea_head__" + n] = state["teacher_state"]["module." + n].flatten()[:16]
+    save("ref_ckpt_r50", **fx)
+
+
 def main():
     which = set(sys.argv[1:])
     if "world2" in which:       # two gloo ranks: each worker installs the shim inside ITS process group
@@ -878,6 +969,13 @@ def main():
     if want("contra"):
         gen_contra(ns, 41, 2, 65, 17, 19, 20.0, "65_empty", prefill=0, steps=2)
         gen_contra(ns, 42, 2, 65, 17, 19, 20.0, "65_prefill", prefill=2990, steps=2, D=64)
+    if want("contra_t007"):     # temperature 0.07 (loss_helper.py:205-230 is max-shifted: any temperature must work)
+        gen_contra(ns, 43, 2, 65, 17, 19, 20.0, "65_t007", prefill=2990, steps=1, D=64, temperature=0.07)
+    if want("contra_t001"):     # temperature 0.01: 2/temp = 200, the fixed-shift softmax would underflow -> online-max kernel
+        gen_contra(ns, 44, 2, 65, 17, 19, 20.0, "65_t001", prefill=2990, steps=1, D=64, temperature=0.01)
+    if want("contra_wrap"):     # the REAL capacities (30000, class 0: 50000), pre-filled to just below them: step 0 wraps
+        gen_contra(ns, 45, 2, 65, 17, 19, 20.0, "65_wrap", prefill=29996, steps=2, D=64, queue_size=30000,
+                   queue_size0=50000, prefill0=49998)
     if want("bank"):
         gen_bank_seq(ns, 51)
     if want("cutmix"):
@@ -904,6 +1002,8 @@ def main():
     if want("evalwin"):
         gen_eval_window(ns, "70x100", 70, 100, 65, 91)     # 2 x 2 overlapping windows, last ones pulled back
         gen_eval_window(ns, "50x90", 50, 90, 65, 92)       # image shorter than the crop: symmetric zero padding
+    if "refckpt" in which:       # ~0.6 GB in memory: only on request
+        gen_ref_ckpt(ns)
     if want("model"):
         gen_model(ns, "r50_65", "resnet50", 65, 2, 19, aux=True)
         gen_model(ns, "r101_33", "resnet101", 33, 2, 21, aux=False)

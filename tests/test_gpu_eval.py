@@ -80,3 +80,28 @@ def test_evaluate_miou_matches_cpu_restatement():
     ref_iou = inter / (union + 1e-10)
     print("mIoU hip", miou, "cpu", float(ref_iou.mean()))
     assert abs(miou - float(ref_iou.mean())) < 3e-3
+
+
+def test_confusion_hist_kernel_vs_reference_intersection_and_union_golden():
+    """u2pl_confusion_hist_f32 (argmax + the three class histograms of validate(), train_semi.py:620-641) against
+    tests/golden/miou_hist.npz, written by the reference's utils.intersectionAndUnion (utils.py:568-580): ignored
+    pixels (random + a band), a class that never occurs in the ground truth; logits are built so that their arg-max is
+    the fixture's prediction map, once with a clear margin and once with the winner only one ulp ahead."""
+    from u2pl_amd._lib import call
+    g = golden("miou_hist")
+    out, tgt = g["out"].astype(np.int64), g["tgt"].astype(np.int64)
+    N, H, W = out.shape
+    C = 19
+    rng = np.random.default_rng(3)
+    for margin in (1.0, None):
+        logits = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        top = logits.max(1)
+        win = top + margin if margin is not None else np.nextafter(top, np.float32(np.inf), dtype=np.float32)
+        np.put_along_axis(logits, out[:, None], win[:, None], axis=1)
+        assert np.array_equal(logits.argmax(1), out)
+        hist = torch.zeros(3 * C, dtype=torch.int64, device=DEV)
+        for rep in range(2):      # the kernel ACCUMULATES (validate() sums over batches): two calls = twice the counts
+            call("u2pl_confusion_hist_f32", torch.from_numpy(logits).to(DEV), torch.from_numpy(tgt).to(DEV), 255, N, C, H, W, hist)
+        h = hist.cpu().numpy().reshape(3, C).astype(np.float64) / 2
+        inter, union, target = h[0], h[1] + h[2] - h[0], h[2]
+        assert np.array_equal(inter, g["inter"]) and np.array_equal(union, g["union"]) and np.array_equal(target, g["target"])

@@ -146,23 +146,27 @@ def _compare(tag, wino):
 
 
 def _assert_step(r, first):
-    """Measured on MI355X (profiles/r02_full_size_parity.json): step-0 losses 6e-7 .. 5e-6 from the reference's own
-    train(); pseudo labels identical; 26 (direct) / 36 (Winograd) of 1,182,722 unsup-target pixels and 0-2 of the
-    148,996 low/high mask pixels on the other side of their fp32 percentile threshold.  Exact equality is not
-    attainable FROM LOGITS at this depth: the reference's own fp32 result differs from a float64 evaluation of the
-    same step by a comparable number of pixels (oracle/mask_noise_floor.py -> profiles/r02_mask_noise_floor_*.json);
-    the Tier-A tests (tests/test_gpu_loss_path.py) hold every mask kernel to bit-exactness given identical inputs."""
+    """Bounds = what was measured on MI355X plus a small margin (profiles/r02_full_size_parity.json; every run re-writes
+    the counts to gpurun_out/ and prints them).  Step 0 (identical weights): losses 1e-7 .. 1.5e-6 from the reference's own
+    train(); pseudo labels, low / high masks and class bits IDENTICAL; 2 (direct) / 6 (Winograd) of 1,182,722
+    unsup-target pixels on the other side of their fp32 percentile threshold.  VOC step 1 (two independently updated
+    fp32 weight sets; the CPU port itself is 12 px off the reference there): 34 / 47 target pixels, 1-4 mask pixels.
+    Exact equality is not attainable FROM LOGITS at this depth: the reference's own fp32 result differs from a float64
+    evaluation of the same step by a comparable number of pixels (oracle/mask_noise_floor.py ->
+    profiles/r02_mask_noise_floor_*.json); the Tier-A tests (tests/test_gpu_loss_path.py) hold every mask kernel to
+    bit-exactness given identical inputs."""
     tol = 1e-4 if first else 2e-3
     # supervised / unsupervised losses never depend on the sampling: always within the north_star tolerance
     for j in (0, 1):
         assert r["loss_err_vs_reference"][j] <= tol and r["loss_err_vs_port"][j] <= tol, r
     if "px" not in r:
         return
-    assert r["entropy_max_err_vs_port"] <= 3e-3, r
-    assert r["label_u_diff_vs_reference"] <= (0 if first else 1e-5 * r["px"]), r
-    assert r["target_u_diff_vs_reference"] <= (1e-4 if first else 3e-4) * r["px"], r
-    assert r["low_mask_diff_vs_reference"] <= 8 and r["high_mask_diff_vs_reference"] <= 8, r
-    assert r["lbits_diff_vs_reference"] <= 4, r
+    assert r["entropy_max_err_vs_port"] <= (3e-4 if first else 3e-3), r       # measured 4e-5 / 1e-4 (step 0), 4.5e-4 (VOC step 1)
+    assert r["label_u_diff_vs_reference"] <= (0 if first else 4), r            # measured 0 / 0
+    assert r["target_u_diff_vs_reference"] <= (16 if first else 96), r         # measured 2 / 6 (step 0), 34 / 47 (VOC step 1)
+    mask_max = 4 if first else 8                                               # measured 0 (step 0), 1-4 (VOC step 1)
+    assert r["low_mask_diff_vs_reference"] <= mask_max and r["high_mask_diff_vs_reference"] <= mask_max, r
+    assert r["lbits_diff_vs_reference"] <= 2, r                                # measured 0 everywhere
     same_counts = (r["low_mask_diff_vs_reference"] + r["high_mask_diff_vs_reference"] + r["lbits_diff_vs_reference"]) == 0
     # the contrastive loss samples anchors / negatives with torch.randint(n_candidates): one flipped mask pixel can
     # shift every later draw, so the 1e-4 bound applies when the masks agree; otherwise the two estimates of the
@@ -177,7 +181,7 @@ def test_headline_config_step_vs_port_and_reference(wino):
     assert r["port_target_diff_vs_reference"] == 0      # the port itself sits exactly on the reference at full size
     _assert_step(r, first=True)
     assert r["loss_err_vs_reference"][2] <= 1e-4, r       # measured 4e-7 / 6e-7: the sampled sets were identical
-    assert sum(abs(a - b) for a, b in zip(rep["bank_len_hip"], r["bank_len_reference"])) <= 4
+    assert sum(abs(a - b) for a, b in zip(rep["bank_len_hip"], r["bank_len_reference"])) <= 2     # measured 0
     for k, (err, upd) in rep["param_err_over_update"].items():
         assert err <= 0.05 * upd + 1e-6, (k, err, upd)
 

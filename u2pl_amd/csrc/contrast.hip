@@ -514,7 +514,14 @@ struct NceJob {
 };
 
 // PRE: K <= 64 -- the K sampled row indices of an anchor sit in the lanes of one register (no index loads in the loop)
-template <int VPL, bool PRE>  // floats per lane = D / 64
+// ONLINE: running-maximum softmax for small temperatures.  The default form shifts every logit by the bound 1/temp, so
+// its terms are exp(l - 1/temp) with l in [-1/temp, 1/temp]: below temp ~ 0.023 every term can underflow fp32 and the
+// loss would be log(0), where the reference's max-shifted F.cross_entropy (loss_helper.py:228-230) stays finite.  The
+// host selects ONLINE when 2/temp > NCE_FIXED_SHIFT_MAX (the stock temp = 0.5 gives 4): the maximum of the logits seen
+// so far is carried across the four-row batches and the accumulators are rescaled when it grows (one more exp and
+// three more multiplies per batch).
+#define NCE_FIXED_SHIFT_MAX 80.0f
+template <int VPL, bool PRE, bool ONLINE = false>  // floats per lane = D / 64
 __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restrict__ rep, long ld, int D,
                           int Q, int K, float inv_temp, float* __restrict__ loss_q,
                           float* __restrict__ ganchor, int* __restrict__ anchor_pix, int* __restrict__ head,
@@ -541,7 +548,7 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
     // dependent rescale chain across the rows).  Rows are processed four at a time: four independent 1 KiB row loads in
     // flight per wave and eight interleaved all-lane sums.
     float s = 0.f, l0 = 0.f, cw = 0.f;  // cw = sum_j w_j * cos_j (un-normalised)
-    const float shift = inv_temp;        // >= every logit
+    float shift = ONLINE ? -INFINITY : inv_temp;        // fixed form: >= every logit; ONLINE: running maximum
     float f0h[VPL];
     // the K sampled bank rows of this anchor: one coalesced index load, then lane broadcasts (no dependent
     // index -> row latency chain inside the loop)
@@ -593,6 +600,17 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
         const float vinv = __frsqrt_rn(fmaxf(vn, 1e-16f));
         const float vcos = vd * vinv;
         const float vl = vcos * inv_temp;
+        if constexpr (ONLINE) {
+            // rows past the end are clamped duplicates of row K (a real logit): including them in the maximum is harmless
+            const float m4 = fmaxf(fmaxf(lane_get(vl, 0), lane_get(vl, 1)), fmaxf(lane_get(vl, 2), lane_get(vl, 3)));
+            const float mnew = fmaxf(shift, m4);
+            const float resc = __expf(shift - mnew);      // first batch: exp(-inf) = 0 on all-zero accumulators
+            shift = mnew;
+            s *= resc;
+            cw *= resc;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) acc[i] *= resc;
+        }
         const float vw = __expf(vl - shift);          // v_exp_f32 on an argument in [-2/temp, 0]
         const float vwn = vw * vinv;
 #pragma unroll
@@ -659,10 +677,16 @@ U2PL_API int u2pl_infonce_f32(const void* jobs_dev, int njobs, const float* rep,
     if (njobs <= 0) return 0;
     dim3 grid(cdiv(Q, 4), njobs), block(256);
     const NceJob* jobs = (const NceJob*)jobs_dev;
-    float it = 1.0f / temp;
-#define NCE_LAUNCH(V)                                                                                                  \
-    if (K <= 64) hipLaunchKernelGGL((k_infonce<V, true>), grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next, seg_len); \
-    else hipLaunchKernelGGL((k_infonce<V, false>), grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next, seg_len);
+    const float it = 1.0f / temp;
+    if (!(temp > 0.f)) return U2PL_EINVAL;
+    const bool online = 2.0f * it > NCE_FIXED_SHIFT_MAX;      // see k_infonce: the fixed shift would underflow
+#define NCE_ARGS grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next, seg_len
+#define NCE_LAUNCH(V)                                                                    \
+    if (online) {                                                                        \
+        if (K <= 64) hipLaunchKernelGGL((k_infonce<V, true, true>), NCE_ARGS);           \
+        else hipLaunchKernelGGL((k_infonce<V, false, true>), NCE_ARGS);                  \
+    } else if (K <= 64) hipLaunchKernelGGL((k_infonce<V, true>), NCE_ARGS);              \
+    else hipLaunchKernelGGL((k_infonce<V, false>), NCE_ARGS);
     switch (D) {
         case 64: NCE_LAUNCH(1) break;
         case 128: NCE_LAUNCH(2) break;
@@ -671,6 +695,7 @@ U2PL_API int u2pl_infonce_f32(const void* jobs_dev, int njobs, const float* rep,
         default: return U2PL_EINVAL;
     }
 #undef NCE_LAUNCH
+#undef NCE_ARGS
     U2PL_LAUNCH_CHECK();
     return 0;
 }

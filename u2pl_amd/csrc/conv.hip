@@ -47,13 +47,17 @@ __device__ __forceinline__ bool gather_coord(int base, int tap, int step, int lo
 // ("config 5": reduced-precision student, fp32 master weights / EMA teacher).  Tensors in HBM stay fp32.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define LDPH (BK + 8)   // LDS row pitch of the bf16 tiles (elements): 80 B, 16 B aligned
-__device__ __forceinline__ unsigned bf16_rne(float f) {      // fp32 -> bf16 bits, round to nearest even (NaN stays NaN)
-    const unsigned u = __float_as_uint(f);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16 pair (lo in bits 0..15): ONE v_cvt_pk_bf16_f32 on gfx950 (round to nearest even, NaN stays a
+// quiet NaN, Inf stays Inf) instead of the 4-5 integer VALU operations per element of an add-and-shift rounding (which
+// also turned small-payload NaNs into Inf)
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
+    bf16x2_t v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return *(unsigned*)&v;
 }
-__device__ __forceinline__ uint2 pack4_bf16(float4 v) {
-    return make_uint2(bf16_rne(v.x) | (bf16_rne(v.y) << 16), bf16_rne(v.z) | (bf16_rne(v.w) << 16));
-}
+__device__ __forceinline__ uint2 pack4_bf16(float4 v) { return make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w)); }
 
 template <int TM, int TN, int WM = 2, bool BF = false>
 __global__ __launch_bounds__(128 * WM, WM) void k_conv_igemm(const float* __restrict__ x, long ldx,
@@ -691,10 +695,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_bf16(const float* __restr
         }
     };
     auto put4 = [&](unsigned short* base, const float4& p0, const float4& p1) {   // rows c..c+3, pixels 2pp, 2pp+1
-        *(unsigned*)(base + 0 * LDPW) = bf16_rne(p0.x) | (bf16_rne(p1.x) << 16);
-        *(unsigned*)(base + 1 * LDPW) = bf16_rne(p0.y) | (bf16_rne(p1.y) << 16);
-        *(unsigned*)(base + 2 * LDPW) = bf16_rne(p0.z) | (bf16_rne(p1.z) << 16);
-        *(unsigned*)(base + 3 * LDPW) = bf16_rne(p0.w) | (bf16_rne(p1.w) << 16);
+        *(unsigned*)(base + 0 * LDPW) = pack2_bf16(p0.x, p1.x);
+        *(unsigned*)(base + 1 * LDPW) = pack2_bf16(p0.y, p1.y);
+        *(unsigned*)(base + 2 * LDPW) = pack2_bf16(p0.z, p1.z);
+        *(unsigned*)(base + 3 * LDPW) = pack2_bf16(p0.w, p1.w);
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll

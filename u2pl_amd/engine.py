@@ -95,7 +95,7 @@ def _rng_state():
     """the four RNG streams of a step as tensors / plain scalars only (torch.load(weights_only=True) accepts the file)"""
     kind, keys, pos, has_gauss, cached = np.random.get_state()
     ver, pk, gauss = random.getstate()
-    return {"torch": torch.get_rng_state(), "cuda": torch.cuda.get_rng_state(),
+    return {"torch": torch.get_rng_state(), "cuda": torch.cuda.get_rng_state() if torch.cuda.is_available() else None,
             "numpy_keys": torch.from_numpy(keys.astype(np.int64)), "numpy_pos": int(pos), "numpy_has_gauss": int(has_gauss),
             "numpy_cached": float(cached), "python_version": int(ver), "python_keys": torch.tensor(pk, dtype=torch.int64),
             "python_gauss": gauss}
@@ -129,7 +129,8 @@ def restore_extras(ckpt, trainer, steps_per_epoch):
     rs = ckpt.get("rng_state")
     if rs is not None:
         torch.set_rng_state(rs["torch"])
-        torch.cuda.set_rng_state(rs["cuda"])
+        if rs.get("cuda") is not None and torch.cuda.is_available():
+            torch.cuda.set_rng_state(rs["cuda"])
         np.random.set_state(("MT19937", rs["numpy_keys"].numpy().astype(np.uint32), rs["numpy_pos"], rs["numpy_has_gauss"],
                              rs["numpy_cached"]))
         random.setstate((rs["python_version"], tuple(int(x) for x in rs["python_keys"]), rs["python_gauss"]))

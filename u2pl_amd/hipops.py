@@ -190,8 +190,10 @@ def reliability_split(logits_low, size, label_l, label_u_aug, out_hw, percents, 
     nspec = len(percents)
     if fused is None:
         # the persistent kernel owns the GPU for its two device-wide barriers: not when several ranks share one device
-        fused = (os.environ.get("U2PL_NO_FUSED_SPLIT") is None
+        fused = (os.environ.get("U2PL_NO_FUSED_SPLIT") is None and not _SPLIT_WATCH["disabled"]
                  and int(os.environ.get("LOCAL_WORLD_SIZE", "1")) <= torch.cuda.device_count())
+    if _SPLIT_WATCH["pending"]:
+        poll_split()
     ok = (fused and C in (19, 21) and nspec in (1, 3) and h >= 2 and w >= 2 and H - 1 == 4 * (h - 1) and W - 1 == 4 * (w - 1)
           and H <= 1024 and W <= 1024 and hm <= H and wm <= W and 0 <= ignore <= 255)
     if ok:
@@ -228,14 +230,58 @@ def reliability_split(logits_low, size, label_l, label_u_aug, out_hw, percents, 
                 lbits=lbits, nkept=ws[2:3], err=ws[3:4])
 
 
+_SPLIT_WATCH = {"pending": [], "disabled": False}
+
+
+def _split_failed(rs):
+    """a device-wide barrier of the persistent split timed out: its outputs are undefined AND the grow-only barrier
+    counters of the reused workspace are inconsistent (later launches could pass barriers early).  Drop every cached
+    workspace (a fresh zeroed one is built on the next call), route this process to the multi-launch path from now on,
+    and fail the step loudly."""
+    _RF_WS.clear()
+    _SPLIT_WATCH["disabled"] = True
+    _SPLIT_WATCH["pending"] = []
+    raise _lib.HipError("u2pl_reliability_fused: device-wide barrier timed out (GPU shared with another workload?): the "
+                        "results of that step are undefined.  Later calls in this process use the multi-launch path "
+                        "(same as U2PL_NO_FUSED_SPLIT=1).")
+
+
 def check_split(rs):
     """the persistent split kernel gives up (error word set, results undefined) when its blocks could not all become
-    resident within ~0.5 s -- e.g. another process occupying the GPU.  Called where the step synchronises anyway."""
+    resident within ~0.5 s -- e.g. another process occupying the GPU.  Blocking read: call it where the step
+    synchronises with the host anyway (the contrastive branch); otherwise use watch_split()."""
     err = rs.get("err") if isinstance(rs, dict) else None
     if err is not None and int(err) != 0:
-        err.zero_()
-        raise _lib.HipError("u2pl_reliability_fused: device-wide barrier timed out (GPU shared with another workload?); "
-                            "set U2PL_NO_FUSED_SPLIT=1 to use the multi-launch path")
+        _split_failed(rs)
+
+
+def watch_split(rs):
+    """check_split() for steps WITHOUT a host synchronisation (configs without trainer.contrastive are valid upstream):
+    the error word is copied to pinned host memory behind the kernel (no stall) and examined by poll_split() at the
+    next call / next step, when the copy has long completed."""
+    err = rs.get("err") if isinstance(rs, dict) else None
+    if err is None:
+        return
+    host = torch.empty(1, dtype=torch.int32).pin_memory()
+    host.copy_(err, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _SPLIT_WATCH["pending"].append((host, ev))
+    poll_split()
+
+
+def poll_split(block=False):
+    """examine the error words whose copies have completed (all of them when block=True; the oldest one is waited for
+    once more than two steps are outstanding, so a failure is reported at most two steps late)"""
+    pend = _SPLIT_WATCH["pending"]
+    while pend:
+        host, ev = pend[0]
+        if not (block or len(pend) > 2 or ev.query()):
+            break
+        ev.synchronize()
+        pend.pop(0)
+        if int(host[0]) != 0:
+            _split_failed(None)
 
 
 # --------------------------------------------------------------------------- cross entropy

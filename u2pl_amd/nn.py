@@ -22,6 +22,8 @@ from . import _lib
 from ._lib import HipError, call, query
 
 _CL = torch.channels_last
+# collectives issued by this process since the last reset (bench.py reports them per step)
+COMM_STATS = {"syncbn_allreduce": 0, "bucket_allreduce": 0}
 
 
 # ------------------------------------------------------------------ layout helpers
@@ -360,6 +362,7 @@ class _BNFn(torch.autograd.Function):
             if sync:
                 sums[2 * C] = float(M)
                 dist.all_reduce(sums, group=mod.group)
+                COMM_STATS["syncbn_allreduce"] += 1
                 count = float(M * _world())  # equal per-rank shapes (drop_last loaders)
             mean = torch.empty(C, dtype=torch.float32, device=dev)
             invstd = torch.empty(C, dtype=torch.float32, device=dev)
@@ -402,6 +405,7 @@ class _BNFn(torch.autograd.Function):
                 call("u2pl_sums_to_f32", sums, C, 1.0, 0, dbeta)
         if sync and training:
             dist.all_reduce(sums, group=ctx.group)
+            COMM_STATS["syncbn_allreduce"] += 1
         dx = new_act(N, C, H, W, dev) if ctx.needs_input_grad[0] else None
         dres = new_act(N, C, H, W, dev) if has_res and ctx.needs_input_grad[3] else None
         if dx is not None:
@@ -777,17 +781,25 @@ class ParamArena:
             self._works = [None] * len(self.buckets)
             self._next = len(self.buckets) - 1
             if self.grad.is_cuda:
-                ws = _WGRAD["stream"]
-                self._streams = tuple(x for x in (torch.cuda.current_stream(), ws) if x is not None)
+                # the stream the step (and therefore autograd's backward) runs on; the weight-gradient side stream is
+                # looked up LIVE in _launch -- it is created lazily by the first conv backward, i.e. after this call
+                self._streams = (torch.cuda.current_stream(),)
+
+    def _producer_streams(self):
+        """every stream that may still be writing into the gradient arena: the step's stream (BN / bias gradients,
+        autograd's accumulations) and the weight-gradient side stream, if it exists by now"""
+        ws = _WGRAD["stream"]
+        return tuple(self._streams) + ((ws,) if ws is not None else ())
 
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         if self.grad.is_cuda:       # the bucket's producers ran on the main stream (BN, bias) and on the wgrad side stream
             cur = torch.cuda.current_stream()
-            for st in self._streams:
+            for st in self._producer_streams():
                 if st != cur:
                     cur.wait_stream(st)
         self._works[b] = dist.all_reduce(self.grad[lo:hi], async_op=True)
+        COMM_STATS["bucket_allreduce"] += 1
 
     def mark_ready(self, pidx):
         if _world() <= 1 or not self.buckets or os.environ.get("U2PL_NO_BUCKET_OVERLAP") is not None:

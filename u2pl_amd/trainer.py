@@ -162,6 +162,7 @@ class SemiTrainer:
                    for m in self.lr_mult]
         self.cur_iter += 1
         self.last_lr = lrs[0]
+        self.last_lrs = list(lrs)      # per group (encoder, decoder[, aux]): the cosine schedule is affine, not linear, in base_lr * mult
         return lrs
 
     # -- torch.optim.SGD.state_dict() layout in the reference's group order (train_semi.py:100-110,214; utils.py:622-625)
@@ -172,9 +173,9 @@ class SemiTrainer:
 
     def optimizer_state_dict(self):
         m = self.lr_mult
-        mult = [m[0]] + ([m[2]] if len(m) > 2 else []) + [m[1]]
-        lr = getattr(self, "last_lr", self.base_lr)
-        return sgd_state_dict(self._ref_groups(), [lr * k / m[0] for k in mult], self.momentum, self.weight_decay,
+        lrs = getattr(self, "last_lrs", None) or [self.base_lr * k for k in m]    # before the first step: the base lrs
+        ref_lrs = [lrs[0]] + ([lrs[2]] if len(m) > 2 else []) + [lrs[1]]            # reference group order: encoder, aux, decoder
+        return sgd_state_dict(self._ref_groups(), ref_lrs, self.momentum, self.weight_decay,
                               self.arena.momentum_view, self.arena.steps > 0)
 
     def load_optimizer_state_dict(self, sd):
@@ -317,9 +318,10 @@ class SemiTrainer:
                 # Q5: value = cross-rank mean, gradient = local / world
                 contra_loss = contra_local * (float(ccfg.get("loss_weight", 1)) / _world())
             else:
+                H.watch_split(rs)     # no host sync on this path: the error word is examined one step later (non-blocking)
                 contra_loss = H.zero_times_sum(rep_all)
         if debug is not None and epoch >= self.sup_only_epoch:
-            debug.update(label_u=label_u_aug, target_u=target_u, entropy=ent, thr=thr)
+            debug.update(label_u=label_u_aug, target_u=target_u, entropy=ent, thr=thr, pred_u_large=pred_u_large.detach())
             if ccfg:
                 debug.update(low_mask=low_mask, high_mask=high_mask, lbits=lbits)
         loss = sup_loss + unsup_loss + contra_loss
@@ -355,7 +357,7 @@ class SupTrainer:
             groups.append(list(model.auxor.parameters()))
             self.lr_mult.append(times)
         self.arena = K.ParamArena(groups)
-        self.cur_iter, self.last_lr = 0, self.base_lr
+        self.cur_iter, self.last_lr, self.last_lrs = 0, self.base_lr, None
         self.use_aux = "aux_loss" in cfg["net"].keys()
 
     _init_schedule = SemiTrainer._init_schedule

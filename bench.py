@@ -164,9 +164,17 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    from u2pl_amd import nn as KN
+    from u2pl_amd import hipops as HO
+    rccl_ranks = None
     if world > 1:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                      # an ACTUAL collective on the process group: the ranks it reached
+        rccl_ranks = int(ones.item())
         dist.barrier()
     torch.cuda.synchronize()
+    comm0 = dict(KN.COMM_STATS)
+    route0 = HO.split_route_stats()
     t0 = time.perf_counter()
     for i in range(args.steps):
         meters = step(args.warmup + i)
@@ -182,14 +190,47 @@ def main():
     ms = dt / args.steps * 1e3
     imgs = world * 2 * args.batch
     value = imgs / (ms / 1e3)
+    comm = {k: (KN.COMM_STATS[k] - comm0[k]) / args.steps for k in comm0}
+    route1 = HO.split_route_stats()
     from u2pl_amd import roofline as RL
+
+    def timed_steps(n, first):
+        """n more steps, bracketed like the timed region (diagnostic lines below: not the headline)"""
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for i in range(n):
+            step(first + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tb = torch.tensor([time.perf_counter() - ta], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        return float(tb) / n * 1e3
+
+    diag = {}
+    if world > 1:
+        # exposed communication of the bucketed gradient all-reduce: the same steps with every bucket launched AFTER backward
+        os.environ["U2PL_NO_BUCKET_OVERLAP"] = "1"
+        diag["ms_per_step_no_bucket_overlap"] = round(timed_steps(3, args.warmup + args.steps), 3)
+        del os.environ["U2PL_NO_BUCKET_OVERLAP"]
+        diag["comm_exposed_ms"] = round(diag["ms_per_step_no_bucket_overlap"] - ms, 3)
 
     # the roofline leg runs ONE extra (un-timed) step with per-call HIP events; it contains the step's
     # collectives, so every rank executes it
     roof = RL.measure(trainer, batches[0], args, ms)
     if world > 1:
         dist.barrier()
-    from u2pl_amd import nn as KN
+    if not args.no_calibrate:
+        # the timed steps ran at lr 1e-6 (see above); ONE step at the configuration's lr 0.01 on the still calibrated state
+        # shows that the scalar does not change the time of a step (the step after it would see collapsed pseudo-labels)
+        trainer.base_lr = cfg["trainer"]["optimizer"]["kwargs"]["lr"]
+        diag["ms_step_lr0.01"] = round(timed_steps(1, 0), 3)
+        trainer.base_lr = 1e-6
     wt = KN.CONV_ALGO["wino"]
     conv_algo = ("student: bf16-operand implicit GEMM on v_mfma_f32_32x32x16_bf16 (fwd, dgrad, wgrad; direct, no Winograd); "
                  "teacher: fp32 as in the headline" if args.bf16 else
@@ -214,7 +255,12 @@ def main():
                                    "contrastive bank 30000x256 pre-filled (BASELINE configs[2]/[3])",
                        "global_batch": imgs, "parallelism": f"dp{world}", "conv_algo": conv_algo},
             "losses_last_step": [round(float(x), 5) for x in meters.cpu()],
+            # collectives issued per step by this rank (0 at N = 1: SyncBatchNorm exchanges only happen under a process group)
+            "syncbn_collectives_per_step": comm["syncbn_allreduce"], "bucket_allreduces_per_step": comm["bucket_allreduce"],
+            "rccl_ranks": rccl_ranks,
+            "split_launches_timed": route1[0] - route0[0], "split_second_barrier_launches_timed": route1[1] - route0[1],
         }
+        out.update(diag)
         out.update(roof)
         if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N=1 only (the checker's port, never the product)
             from oracle import step_ref
@@ -222,6 +268,9 @@ def main():
             ref_t = os.path.join(ROOT, "profiles", "r02_cpu_reference_timing.json")
             if os.path.exists(ref_t):
                 rt = json.load(open(ref_t))
+                if rt.get("port_images_per_s") and rt.get("reference_images_per_s"):
+                    # bridge between the two CPU numbers: port / reference on the SAME machine (build container)
+                    out["cpu_baseline"]["port_over_reference"] = round(rt["port_images_per_s"] / rt["reference_images_per_s"], 3)
                 out["cpu_baseline"]["reference_train_in_build_container"] = {
                     "images_per_s": round(rt["reference_images_per_s"], 5), "cores": rt["cores"],
                     "note": "the reference's own train_semi.train() through oracle/ref_shim.py, 1 warm-up + 2 timed steps, "

@@ -97,6 +97,15 @@ size_t u2pl_proto_workspace_bytes(long P, int C, int D);
 int u2pl_class_prototypes(const float* rows, long ld, int D, const int* idx, long cap, const unsigned* counts,
                           int C, long P, void* workspace, float* proto, const unsigned* lowbits,
                           hipStream_t stream);
+/* loss_helper.py:80-154 in THREE launches (classify + per-block counts; prototype streaming; ordered compaction write with
+ * in-block offsets + list lengths merged with the ordered prototype finish): same outputs as u2pl_contra_classify +
+ * u2pl_compact_lists + u2pl_class_prototypes.  rows: teacher features, row r at rows + r*ld. */
+size_t u2pl_contra_phase1_workspace_bytes(long P, int C, int D);
+int u2pl_contra_phase1(const float* prob, long sn, long sc, long sp, const unsigned* lbits, const float* low_mask,
+                       const float* high_mask, int N2, int num_labeled, int C, int h, int w, float thr_p, float thr_n,
+                       int low_rank, int high_rank, const float* rows, long ld, int D, unsigned* abits, unsigned* lowbits,
+                       unsigned* nbits, int* idx, long cap, unsigned* counts, float* proto, void* workspace,
+                       hipStream_t stream);
 /* keys = rep_teacher[negative_mask]: loss_helper.py:142 */
 int u2pl_gather_rows_f32(const float* rows, long ld, int D, const int* list, long n, float* out,
                          hipStream_t stream);
@@ -284,13 +293,21 @@ int u2pl_ema_update_f32(float* t, const float* s, long n, float decay, float one
  * array of percentiles/100 in float32.  workspace (u2pl_reliability_fused_workspace_bytes(G) bytes) is zeroed ONCE and
  * reused; epoch = number of earlier launches on it (barrier counters grow monotonically, totals alternate by parity);
  * thresholds are left in workspace words 16..18 (float bits), #kept in word 2.  G = power of two <= #CUs, <= 256.
+ * cand: u2pl_reliability_fused_cand_floats(B*H*W, G) floats of scratch.  Every block publishes its entropies sorted by
+ * histogram bin, so the members of the bins that hold the ranks are gathered after ONE device-wide barrier; only when
+ * those bins hold more values than fit in LDS (all-equal entropies, heavy ties) a second barrier is used (workspace word
+ * 4 counts launches, word 5 those that needed it).  flags bit 0: put an agent-scope release / acquire fence pair around
+ * the barrier (the published data are written through and read past the L1 already: off by default).
  * Returns 1001 when the shape is not covered (fall back to entropy_up + select + reliability_apply). */
+/* kernel launches issued by this library so far (host counter; bench.py: kernel launches per step vs C-ABI calls) */
+size_t u2pl_kernel_launches(void);
 size_t u2pl_reliability_fused_workspace_bytes(int G);
+size_t u2pl_reliability_fused_cand_floats(long n_px, int G);
 int u2pl_reliability_fused(const float* logits_low, long sn, long sc, long sh, long sw, int B, int C, int h, int w,
                            int H, int W, const long long* label_u, const long long* label_l, int ignore, int nspec,
                            const float* q32_host, int negative_high_entropy, int hm, int wm, float* entropy,
                            long long* target_u, float* low_mask, float* high_mask, unsigned* lbits,
-                           unsigned* workspace, float* cand, int G, unsigned epoch, hipStream_t stream);
+                           unsigned* workspace, float* cand, int G, unsigned epoch, int flags, hipStream_t stream);
 /* generate_unsup_data(mode="cutmix"): augmentation.py:498-541 */
 int u2pl_cutmix_f32(const float* img, const long long* label, const float* conf, const int* boxes_dev, int B, int C,
                     int H, int W, float* out_img, long long* out_label, float* out_conf, hipStream_t stream);

@@ -306,6 +306,53 @@ def test_infonce_rejects_non_positive_temperature():
             _lib.call("u2pl_infonce_f32", z, 1, z, 64, 64, 4, 4, bad, z, z, z, None, None, None)
 
 
+@pytest.mark.parametrize("s,C,B,layout", [(193, 19, 2, "nhwc"), (193, 19, 2, "nchw"), (129, 21, 4, "nhwc"), (17, 19, 2, "nhwc"), (9, 21, 3, "nchw")])
+def test_contra_phase1_three_launch_form_equals_five_launch_sequence(s, C, B, layout):
+    """u2pl_contra_phase1 (LDS-staged classify; compaction write with in-block offsets merged with the prototype finish)
+    against u2pl_contra_classify + u2pl_compact_lists + u2pl_class_prototypes: class bitmasks, list lengths, the ordered
+    pixel lists and the prototypes are BIT-identical, at BASELINE sizes (769^2 / 513^2 maps) and tiny ones (fewer write
+    blocks than count rows), for row-contiguous (fast classify) and planar probabilities, with the label_onehot
+    batch-slot-0 layout (only images 0 and B carry class bits)."""
+    H = hip()
+    D = 256
+    g = torch.Generator(device=DEV).manual_seed(s * C + B)
+    N2 = 2 * B
+    prob = torch.softmax(torch.randn(N2, C, s, s, device=DEV, generator=g) * 2.5, 1)
+    if layout == "nhwc":
+        prob = prob.contiguous(memory_format=torch.channels_last)
+        pstr = (prob.stride(0), prob.stride(1), prob.stride(3))
+    else:
+        pstr = (C * s * s, s * s, 1)
+    rep_t = torch.randn(N2 * s * s, D, device=DEV, generator=g)
+    lbits = torch.zeros((N2, s, s), dtype=torch.int32, device=DEV)
+    lab = torch.randint(0, C, (2, 2, s, s), device=DEV, generator=g)
+    for k, n in enumerate((0, B)):      # Q0: slot 0 of each half holds the union over the batch
+        lbits[n] = ((1 << lab[k, 0]) | (1 << lab[k, 1])).to(torch.int32)
+    lbits[0, :2] = 0
+    low = (torch.rand(N2, 1, s, s, device=DEV, generator=g) < 0.45).float()
+    high = (torch.rand(N2, 1, s, s, device=DEV, generator=g) < 0.3).float()
+    cfg = dict(CONTRA_CFG, current_class_threshold=0.2)
+    outs = []
+    for fused in (True, False):
+        H.PHASE1_FUSED = fused
+        try:
+            ph = H.contra_phase1(rep_t, D, D, prob, pstr, lbits, low.contiguous(), high.contiguous(), B, C, s, s, cfg)
+        finally:
+            H.PHASE1_FUSED = True
+        torch.cuda.synchronize()
+        outs.append(ph)
+    a, b = outs
+    ca, cb = a.counts.cpu().numpy(), b.counts.cpu().numpy()
+    assert np.array_equal(ca[:, :C], cb[:, :C]) and ca[0, :C].sum() > 0 and ca[2, :C].sum() > 0, (ca, cb)
+    for kind in (0, 2):
+        for c in range(C):
+            n = int(ca[kind, c])
+            assert torch.equal(a.idx[kind, c, :n], b.idx[kind, c, :n]), (kind, c)
+            if n > 1:
+                assert bool((a.idx[kind, c, 1:n] > a.idx[kind, c, :n - 1]).all())      # ascending pixel order
+    assert torch.equal(a.proto.view(torch.int32), b.proto.view(torch.int32))
+
+
 def test_contra_single_class_returns_zero_with_zero_grads():
     from u2pl_amd.utils.loss_helper import compute_contra_memobank_loss
     H = hip()
@@ -548,6 +595,49 @@ def test_fused_reliability_split_full_size_equals_unfused(case):
         assert torch.equal(f2["entropy"].view(torch.int32), f["entropy"].view(torch.int32))
         assert torch.equal(f2["target_u"], f["target_u"]) and torch.equal(f2["low_mask"], f["low_mask"])
         assert torch.equal(f2["high_mask"], f["high_mask"]) and torch.equal(f2["lbits"], f["lbits"])
+
+
+def test_fused_split_single_barrier_gather_is_exact_on_a_reused_workspace():
+    """The persistent split publishes every block's entropies sorted by histogram bin and gathers the members of the
+    rank bins after ONE device-wide barrier (a second one only when those bins overflow LDS).  All cross-block data sit
+    at the same addresses launch after launch, so a reader that saw a stale copy (an XCD's L2 line from an earlier
+    launch) would return the PREVIOUS input's order statistics: three different inputs are cycled on one workspace and
+    every launch is compared bit for bit with the five-launch path and with np.percentile of its own entropy map;
+    the route counters in the workspace (words 4 / 5) must show that the degenerate input, and only it, took the
+    two-barrier route."""
+    H = hip()
+    B, C, S = 2, 19, 769
+    s = (S - 1) // 4 + 1
+    g = torch.Generator(device=DEV).manual_seed(11)
+    base = (torch.randn(B, C, s, s, device=DEV, generator=g) * 3).contiguous(memory_format=torch.channels_last)
+    other = (torch.randn(B, C, s, s, device=DEV, generator=g) * 5).contiguous(memory_format=torch.channels_last)
+    const = (torch.zeros_like(base) + torch.arange(C, device=DEV).view(1, C, 1, 1) * 0.1).contiguous(memory_format=torch.channels_last)
+    lab_u = torch.randint(0, C, (B, S, S), device=DEV, generator=g)
+    lab_l = torch.randint(0, C, (B, S, S), device=DEV, generator=g)
+    lab_l[:, :8] = 255
+    lab_cut = lab_u.clone()
+    lab_cut[0, 200:420, 100:700] = 255
+    cases = {"a": (base, lab_u, [80.0, 20.0, 80.0]), "b": (other, lab_u, [80.0, 20.0, 80.0]),
+             "c": (base * 1.7, lab_cut, [83.5, 11.0, 89.0]), "const": (const, lab_u, [80.0, 20.0, 80.0]),
+             "ign": (base, torch.full_like(lab_u, 255), [80.0, 20.0, 80.0]), "one": (other, lab_u, [73.0])}
+    want = {}
+    for k, (low, lu, pcts) in cases.items():
+        u = H.reliability_split(low, (S, S), lab_l, lu, (s, s), pcts, fused=False)
+        want[k] = {kk: (v.clone() if torch.is_tensor(v) else v) for kk, v in u.items()}
+    order = ["a", "b", "a", "c", "b", "const", "a", "ign", "b", "one", "c", "a", "a", "const", "b"]
+    for k in order:
+        low, lu, pcts = cases[k]
+        h0 = H.split_route_stats()
+        f = H.reliability_split(low, (S, S), lab_l, lu, (s, s), pcts, fused=True)
+        assert "nkept" in f
+        keep = {kk: (v.clone() if torch.is_tensor(v) else v) for kk, v in f.items()}
+        h1 = H.split_route_stats()
+        assert h1[0] - h0[0] == 1 and h1[1] - h0[1] == (1 if k == "const" else 0), (k, h0, h1)
+        assert int(keep["err"]) == 0
+        if k != "const":      # (all-equal entropies: one rounding step moves every pixel across the threshold)
+            _split_equal(keep, want[k], len(pcts))
+        if k != "ign":
+            _self_consistent(keep, lu, pcts, (s, s))
 
 
 # ------------------------------------------------------------------ row-sparse ordered InfoNCE gradient

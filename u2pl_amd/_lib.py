@@ -100,6 +100,12 @@ def stream_ptr():
     return torch._C._cuda_getCurrentRawStream(_DEV[0])
 
 
+# Host-side ledger of side-stream work that the step's main stream has not been ordered behind yet ("teacher": the two
+# teacher passes, "wgrad": weight-gradient kernels, "buckets": in-flight gradient all-reduces).  The persistent
+# reliability split needs every CU for its device-wide barrier: hipops.reliability_split asserts that the ledger is
+# empty when it launches, i.e. that by stream order no other kernel of this process can be resident.
+SIDE_WORK = set()
+
 PROFILE = None  # when a list: (name, args, start_event, end_event) per call (bench.py roofline leg)
 _FN = {}
 
@@ -115,12 +121,14 @@ def call(name, *args):
         import torch
 
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0 = lib().cdll.u2pl_kernel_launches()
         e0.record()
         rc = fn(*conv, stream_ptr())
         e1.record()
         # (fn, converted args, the tensors themselves) let the roofline leg re-issue the launch later: the references keep
-        # every buffer of the profiled step alive until then
-        PROFILE.append((name, tuple(a if isinstance(a, (int, float)) else None for a in args), e0, e1, fn, conv, args))
+        # every buffer of the profiled step alive until then; last field: kernel launches this entry point issued
+        PROFILE.append((name, tuple(a if isinstance(a, (int, float)) else None for a in args), e0, e1, fn, conv, args,
+                        lib().cdll.u2pl_kernel_launches() - k0))
     else:
         rc = fn(*conv, stream_ptr())
     if rc != 0:

@@ -13,6 +13,16 @@
 
 #define U2PL_EINVAL 1001  // bad argument (reported before any launch)
 
+// every kernel launch of the library goes through this macro: u2pl_kernel_launches() lets the bench report kernel
+// launches per step next to the C-ABI calls per step (an entry point may issue several launches: tile planner bodies
+// and tails, split-K reduces, Winograd component batches)
+extern unsigned long long u2pl_kernel_launch_count;
+#define U2PL_LAUNCH(...)                        \
+    do {                                        \
+        ++u2pl_kernel_launch_count;             \
+        hipLaunchKernelGGL(__VA_ARGS__);        \
+    } while (0)
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int grid_for(long n, int block, int max_blocks = 256 * 16) {
     long g = (n + block - 1) / block;

@@ -20,6 +20,7 @@
 // ---------------------------------------------------------------------------
 #define MAXC 32
 #define CP_PIX 256          // pixels per block of the classify / compaction kernels (one per thread)
+#define PF_MAXBLK 4096      // prototype partial blocks a finish can order
 // The classify kernel also counts, per block of CP_PIX pixels, the members of every (kind, class) list:
 // blk[(kind*32 + c) * nblk + b]   (kinds: 0 = anchor, 1 = low-valid, 2 = negative)
 __global__ __launch_bounds__(CP_PIX) void k_contra_classify(
@@ -72,6 +73,81 @@ __global__ __launch_bounds__(CP_PIX) void k_contra_classify(
     if (threadIdx.x < 3 * MAXC) blk[(long)threadIdx.x * nblk + blockIdx.x] = cnt[threadIdx.x];
 }
 
+// Fast form for the layout the trainer produces (probabilities as contiguous [pixel][C] rows, C odd): a block's 256 rows
+// are ONE contiguous span of 256 * C floats, staged into LDS with coalesced 16-byte loads (the strided form issues C
+// dword loads per thread whose lanes sit 4C bytes apart: ~5x the memory instructions), and read back with stride C (odd:
+// conflict-free).  Blocks whose pixels carry no label bits (images 1 .. B-1 and B+1 .. under quirk Q0) only write zeros.
+// Same arithmetic and outputs as k_contra_classify.
+__global__ __launch_bounds__(CP_PIX) void k_contra_classify_rows(
+    const float* __restrict__ prob, const unsigned* __restrict__ lbits, const float* __restrict__ low_mask,
+    const float* __restrict__ high_mask, int N2, int num_labeled, int C, long hw, float thr_p, float thr_n, int low_rank,
+    int high_rank, unsigned* __restrict__ abits, unsigned* __restrict__ lowbits, unsigned* __restrict__ nbits,
+    unsigned* __restrict__ blk, int nblk) {
+    __shared__ __attribute__((aligned(16))) float rows[CP_PIX * MAXC];
+    __shared__ unsigned cnt[3 * MAXC];
+    __shared__ int any_s;
+    if (threadIdx.x < 3 * MAXC) cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) any_s = 0;
+    __syncthreads();
+    const long total = (long)N2 * hw;
+    const long p0 = blockIdx.x * (long)CP_PIX, p = p0 + threadIdx.x;
+    const unsigned lb = p < total ? lbits[p] : 0u;
+    if (__ballot(lb != 0) && (threadIdx.x & 63) == 0) any_s = 1;
+    __syncthreads();
+    if (!any_s) {        // block-uniform
+        if (p < total) { abits[p] = 0; lowbits[p] = 0; nbits[p] = 0; }
+        if (blk && threadIdx.x < 3 * MAXC) blk[(long)threadIdx.x * nblk + blockIdx.x] = 0;
+        return;
+    }
+    {
+        const long npx = min((long)CP_PIX, total - p0);
+        const int nfl = (int)(npx * C);
+        const float* src = prob + p0 * C;             // 16-byte aligned: p0 is a multiple of 256
+        for (int i = threadIdx.x * 4; i < nfl; i += CP_PIX * 4) {
+            if (i + 3 < nfl) *(float4*)(rows + i) = *(const float4*)(src + i);
+            else for (int k = i; k < nfl; ++k) rows[k] = src[k];
+        }
+    }
+    const bool lo = p < total && lb != 0 && low_mask[p] != 0.f, hi = p < total && lb != 0 && high_mask[p] != 0.f;
+    __syncthreads();
+    if (p < total) {
+        const long n = p / hw;
+        unsigned a = 0, l = 0, ng = 0;
+        if (lb != 0) {
+            const float* b = rows + threadIdx.x * C;
+            float pr[MAXC];
+#pragma unroll
+            for (int j = 0; j < MAXC; ++j) pr[j] = j < C ? b[j] : -1.f;
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const bool has = (i < C) && ((lb >> i) & 1u);
+                if (!has) continue;
+                const float pi = pr[i];
+                int rank = 0;
+#pragma unroll
+                for (int j = 0; j < MAXC; ++j) rank += (pr[j] > pi) || (pr[j] == pi && j < i);
+                bool cmask = n < num_labeled ? (rank < low_rank && !has) : (rank >= low_rank && rank < high_rank);
+                if (has && lo) {
+                    l |= 1u << i;
+                    if (pi > thr_p) a |= 1u << i;
+                }
+                if (has && hi && pi < thr_n && cmask) ng |= 1u << i;
+            }
+        }
+        abits[p] = a;
+        lowbits[p] = l;
+        nbits[p] = ng;
+        if (blk) {
+            for (unsigned x = a; x; x &= x - 1) atomicAdd(&cnt[0 * MAXC + __ffs(x) - 1], 1u);
+            for (unsigned x = l; x; x &= x - 1) atomicAdd(&cnt[1 * MAXC + __ffs(x) - 1], 1u);
+            for (unsigned x = ng; x; x &= x - 1) atomicAdd(&cnt[2 * MAXC + __ffs(x) - 1], 1u);
+        }
+    }
+    if (!blk) return;
+    __syncthreads();
+    if (threadIdx.x < 3 * MAXC) blk[(long)threadIdx.x * nblk + blockIdx.x] = cnt[threadIdx.x];
+}
+
 U2PL_API int u2pl_contra_classify(const float* prob, long sn, long sc, long sp, const unsigned* lbits,
                                   const float* low_mask, const float* high_mask, int N2, int num_labeled,
                                   int C, int h, int w, float thr_p, float thr_n, int low_rank,
@@ -81,7 +157,12 @@ U2PL_API int u2pl_contra_classify(const float* prob, long sn, long sc, long sp, 
     long total = (long)N2 * h * w;
     if (total <= 0) return 0;
     const int nblk = cdiv(total, CP_PIX);
-    hipLaunchKernelGGL(k_contra_classify, dim3(nblk), dim3(CP_PIX), 0, stream, prob, sn, sc, sp, lbits, low_mask,
+    if (sc == 1 && sp == C && sn == (long)h * w * C && (C & 1) && ((uintptr_t)prob & 15) == 0)
+        U2PL_LAUNCH(k_contra_classify_rows, dim3(nblk), dim3(CP_PIX), 0, stream, prob, lbits, low_mask, high_mask, N2,
+                           num_labeled, C, (long)h * w, thr_p, thr_n, low_rank, high_rank, abits, lowbits, nbits,
+                           (unsigned*)compact_workspace, nblk);
+    else
+    U2PL_LAUNCH(k_contra_classify, dim3(nblk), dim3(CP_PIX), 0, stream, prob, sn, sc, sp, lbits, low_mask,
                        high_mask, N2, num_labeled, C, (long)h * w, thr_p, thr_n, low_rank, high_rank, abits,
                        lowbits, nbits, (unsigned*)compact_workspace, nblk);
     U2PL_LAUNCH_CHECK();
@@ -198,6 +279,146 @@ __global__ __launch_bounds__(CP_PIX) void k_compact_write(const unsigned* __rest
         }
 }
 
+// ---------------------------------------------------------------------------
+// Phase-1 tail in ONE launch (1024-thread blocks, two roles by block index):
+//   blocks [0, nwb): ordered compaction write of 1024 pixels each.  The exclusive offset of a (kind, class) list in front
+//     of this block is summed HERE from the classify kernel's raw per-256-pixel counts (one wave per list that is present
+//     in the block, ~10 coalesced loads per lane), so the separate scan launch is gone; block i < 96 also publishes the
+//     total of count row i (the list lengths the host reads back).
+//   blocks [nwb, nwb + C * D/64): the ordered double-precision finish of the class prototypes (k_proto_finish's body; the
+//     class's member count is summed from the same raw counts, the finish does not wait for the totals above).
+// The two roles are independent; merging them removes two launch boundaries from the chain in front of the step's one
+// host synchronisation.
+// ---------------------------------------------------------------------------
+#define P1_T 1024
+__device__ __forceinline__ unsigned p1_row_sum(const unsigned* __restrict__ row, int n, int lane) {   // one wave: sum of row[0..n)
+    unsigned acc = 0;
+    for (int i = lane; i < n; i += 64) acc += row[i];
+    return wave_sum_u(acc);
+}
+__global__ __launch_bounds__(P1_T) void k_phase1_tail(const unsigned* __restrict__ b0, const unsigned* __restrict__ b2, long P,
+                                                      const unsigned* __restrict__ blk, int nblk, int* __restrict__ idx, long cap,
+                                                      unsigned* __restrict__ counts, int nwb,
+                                                      const float* __restrict__ partial, int D, int npb, int C,
+                                                      const unsigned* __restrict__ flags, float* __restrict__ proto) {
+    __shared__ unsigned wcnt[16][2 * MAXC];      // write role: per-wave counts -> exclusive offsets
+    __shared__ unsigned base_s[2 * MAXC];        // write role: list offset in front of this block
+    __shared__ unsigned pres_s[2];
+    __shared__ double sh[16][64];                // finish role
+    __shared__ int act[PF_MAXBLK];
+    __shared__ int wtot[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if ((int)blockIdx.x < nwb) {
+        // ------------------------------------------------------------ compaction write
+        const long p = blockIdx.x * (long)P1_T + t;
+        unsigned v[2];
+        v[0] = p < P ? b0[p] : 0;
+        v[1] = p < P ? b2[p] : 0;
+        if (t < 2 * MAXC) {
+#pragma unroll
+            for (int w2 = 0; w2 < 16; ++w2) wcnt[w2][t] = 0;
+            base_s[t] = 0;
+        }
+        if (t < 2) pres_s[t] = 0;
+        __syncthreads();
+        unsigned pres[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            pres[k] = wave_or_uniform(v[k]);
+            for (unsigned x = pres[k]; x; x &= x - 1) {
+                const int c = __ffs(x) - 1;
+                const unsigned long long m = __ballot((v[k] >> c) & 1u);
+                if (lane == 0) wcnt[wave][k * MAXC + c] = (unsigned)__popcll(m);
+            }
+            if (lane == 0 && pres[k]) atomicOr(&pres_s[k], pres[k]);
+        }
+        __syncthreads();
+        {   // offsets in front of this block: list r of the block's present lists is summed by wave (r mod 16)
+            const int first = blockIdx.x * (P1_T / CP_PIX);          // count rows are per CP_PIX pixels
+            int r = 0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                for (unsigned x = pres_s[k]; x; x &= x - 1, ++r) {
+                    if ((r & 15) != wave) continue;
+                    const int c = __ffs(x) - 1;
+                    const unsigned sum = p1_row_sum(blk + ((long)(2 * k) * MAXC + c) * nblk, first, lane);
+                    if (lane == 0) base_s[k * MAXC + c] = sum;
+                }
+        }
+        for (int r = blockIdx.x * 16 + wave; r < 3 * MAXC; r += nwb * 16) {   // list lengths (all three kinds) for the host / the InfoNCE jobs
+            const unsigned sum = p1_row_sum(blk + (long)r * nblk, nblk, lane);
+            if (lane == 0) counts[r] = sum;
+        }
+        __syncthreads();
+        if (t < 2 * MAXC) {
+            unsigned run = base_s[t];
+#pragma unroll
+            for (int w2 = 0; w2 < 16; ++w2) {
+                const unsigned tmp = wcnt[w2][t];
+                wcnt[w2][t] = run;
+                run += tmp;
+            }
+        }
+        __syncthreads();
+        const unsigned long long lt = lanemask_lt();
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            for (unsigned x = pres[k]; x; x &= x - 1) {
+                const int c = __ffs(x) - 1;
+                const bool on = (v[k] >> c) & 1u;
+                const unsigned long long m = __ballot(on);
+                if (on) {
+                    const unsigned pos = wcnt[wave][k * MAXC + c] + (unsigned)__popcll(m & lt);
+                    idx[((long)(2 * k) * MAXC + c) * cap + pos] = (int)p;
+                }
+            }
+        return;
+    }
+    // ---------------------------------------------------------------- prototype finish (ordered, double precision)
+    const int fb = blockIdx.x - nwb;
+    const int ndc = (D + 63) / 64;
+    const int c = fb / ndc, cl = lane, rg = wave;
+    const int d = (fb % ndc) * 64 + cl;
+    int basei = 0;
+    for (int bb0 = 0; bb0 < npb; bb0 += P1_T) {
+        const int bb = bb0 + t;
+        const bool on = bb < npb && flags[bb] != 0;
+        const unsigned long long m = __ballot(on);
+        if (cl == 0) wtot[rg] = __popcll(m);
+        __syncthreads();
+        int off = basei;
+        for (int w2 = 0; w2 < rg; ++w2) off += wtot[w2];
+        if (on) act[off + __popcll(m & (cl ? (~0ull >> (64 - cl)) : 0ull))] = bb;
+        int tot = 0;
+        for (int w2 = 0; w2 < 16; ++w2) tot += wtot[w2];
+        basei += tot;
+        __syncthreads();
+    }
+    const int n_act = basei;
+    const unsigned n = p1_row_sum(blk + ((long)1 * MAXC + c) * nblk, nblk, lane);     // members of class c (every wave sums it)
+    double acc = 0.0;
+    if (d < D) {
+        const float* pp = partial + (long)c * D + d;
+        int i = rg;
+        for (; i + 7 * 16 < n_act; i += 8 * 16) {
+            float vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = pp[(long)act[i + 16 * u] * C * D];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (double)vv[u];
+        }
+        for (; i < n_act; i += 16) acc += (double)pp[(long)act[i] * C * D];
+    }
+    sh[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0 && d < D) {
+        double tsum = 0.0;
+#pragma unroll
+        for (int gq = 0; gq < 16; ++gq) tsum += sh[gq][cl];
+        proto[(long)c * D + d] = n ? (float)(tsum / (double)n) : __uint_as_float(0x7fc00000u);
+    }
+}
+
 U2PL_API size_t u2pl_compact_workspace_bytes(long P) {
     return (size_t)cdiv(P, CP_PIX) * 3 * MAXC * sizeof(unsigned);
 }
@@ -211,12 +432,12 @@ U2PL_API int u2pl_compact_lists(const unsigned* abits, const unsigned* lowbits, 
     int nblk = cdiv(P, CP_PIX);
     unsigned* blk = (unsigned*)workspace;
     if (!counted) {
-        hipLaunchKernelGGL(k_compact_count, dim3(nblk), dim3(CP_PIX), 0, stream, abits, lowbits, nbits, P, blk, nblk);
+        U2PL_LAUNCH(k_compact_count, dim3(nblk), dim3(CP_PIX), 0, stream, abits, lowbits, nbits, P, blk, nblk);
         U2PL_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_compact_scan, dim3(3 * MAXC), dim3(256), 0, stream, blk, nblk, counts);
+    U2PL_LAUNCH(k_compact_scan, dim3(3 * MAXC), dim3(256), 0, stream, blk, nblk, counts);
     U2PL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_compact_write, dim3(nblk), dim3(CP_PIX), 0, stream, abits, nbits, P, blk, nblk, idx, cap);
+    U2PL_LAUNCH(k_compact_write, dim3(nblk), dim3(CP_PIX), 0, stream, abits, nbits, P, blk, nblk, idx, cap);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -329,7 +550,6 @@ __global__ __launch_bounds__(256, 2) void k_proto_stream(const float* __restrict
 }
 // grid (C, D/64), 1024 threads: 64 channels x 16 row groups; the flagged blocks are first compacted (in
 // ascending order) into an LDS list so that the partial loads are independent (8 in flight per thread)
-#define PF_MAXBLK 4096
 __global__ __launch_bounds__(1024) void k_proto_finish(const float* __restrict__ partial, int D,
                                                        const unsigned* __restrict__ counts, int nblk, int C,
                                                        const unsigned* __restrict__ flags, float* __restrict__ proto) {
@@ -401,7 +621,7 @@ U2PL_API int u2pl_class_prototypes(const float* rows, long ld, int D, const int*
     case CT: {                                                                                                   \
         static bool set_##CT = false;                                                                            \
         if (!set_##CT) { (void)hipFuncSetAttribute((const void*)k_proto_stream<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * CT * 256 * 4)); set_##CT = true; } \
-        hipLaunchKernelGGL(k_proto_stream<CT>, dim3(nblk), dim3(256), lds, stream, rows, ld, D, lowbits, P, partial, flags, (unsigned)rb); \
+        U2PL_LAUNCH(k_proto_stream<CT>, dim3(nblk), dim3(256), lds, stream, rows, ld, D, lowbits, P, partial, flags, (unsigned)rb); \
     } break;
     switch (C) {
         PROTO_CASE(19) PROTO_CASE(21) PROTO_CASE(32)
@@ -409,7 +629,50 @@ U2PL_API int u2pl_class_prototypes(const float* rows, long ld, int D, const int*
     }
 #undef PROTO_CASE
     U2PL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_proto_finish, dim3(C, cdiv(D, 64)), dim3(1024), 0, stream, partial, D, counts, nblk, C, flags, proto);
+    U2PL_LAUNCH(k_proto_finish, dim3(C, cdiv(D, 64)), dim3(1024), 0, stream, partial, D, counts, nblk, C, flags, proto);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+// Phase 1 of compute_contra_memobank_loss (loss_helper.py:80-154) as THREE launches: classify (+ per-block list counts),
+// prototype streaming, and the merged tail (ordered compaction write with in-block offsets + list lengths || ordered
+// prototype finish).  Same outputs as u2pl_contra_classify + u2pl_compact_lists + u2pl_class_prototypes (five launches).
+U2PL_API size_t u2pl_contra_phase1_workspace_bytes(long P, int C, int D) {
+    return ((u2pl_compact_workspace_bytes(P) + 255) & ~(size_t)255) + u2pl_proto_workspace_bytes(P, C, D);
+}
+U2PL_API int u2pl_contra_phase1(const float* prob, long sn, long sc, long sp, const unsigned* lbits, const float* low_mask,
+                                const float* high_mask, int N2, int num_labeled, int C, int h, int w, float thr_p,
+                                float thr_n, int low_rank, int high_rank, const float* rows, long ld, int D,
+                                unsigned* abits, unsigned* lowbits, unsigned* nbits, int* idx, long cap, unsigned* counts,
+                                float* proto, void* workspace, hipStream_t stream) {
+    const long P = (long)N2 * h * w;
+    if (C > MAXC || P <= 0) return U2PL_EINVAL;
+    const int npb = proto_blocks(P);
+    const long rb = ((P - 1) * ld + D) * 4;
+    if (D % 4 || D > 256 || npb > PF_MAXBLK || rb >= (1L << 31) || !(C == 19 || C == 21 || C == 32)) return U2PL_EINVAL;
+    int rc = u2pl_contra_classify(prob, sn, sc, sp, lbits, low_mask, high_mask, N2, num_labeled, C, h, w, thr_p, thr_n,
+                                  low_rank, high_rank, abits, lowbits, nbits, workspace, stream);
+    if (rc) return rc;
+    const unsigned* blk = (const unsigned*)workspace;
+    const int nblk = cdiv(P, CP_PIX);
+    float* partial = (float*)((char*)workspace + ((u2pl_compact_workspace_bytes(P) + 255) & ~(size_t)255));
+    unsigned* flags = (unsigned*)(partial + (size_t)npb * C * D);
+    const size_t lds = (size_t)4 * C * D * sizeof(float);
+#define P1_PROTO(CT)                                                                                             \
+    case CT: {                                                                                                   \
+        static bool set_##CT = false;                                                                            \
+        if (!set_##CT) { (void)hipFuncSetAttribute((const void*)k_proto_stream<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * CT * 256 * 4)); set_##CT = true; } \
+        U2PL_LAUNCH(k_proto_stream<CT>, dim3(npb), dim3(256), lds, stream, rows, ld, D, lowbits, P, partial, flags, (unsigned)rb); \
+    } break;
+    switch (C) {
+        P1_PROTO(19) P1_PROTO(21) P1_PROTO(32)
+        default: return U2PL_EINVAL;
+    }
+#undef P1_PROTO
+    U2PL_LAUNCH_CHECK();
+    const int nwb = cdiv(P, P1_T);
+    U2PL_LAUNCH(k_phase1_tail, dim3(nwb + C * cdiv(D, 64)), dim3(P1_T), 0, stream, abits, nbits, P, blk, nblk, idx, cap,
+                       counts, nwb, partial, D, npb, C, flags, proto);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -434,7 +697,7 @@ U2PL_API int u2pl_gather_rows_f32(const float* rows, long ld, int D, const int* 
                                   hipStream_t stream) {
     if (D % 4) return U2PL_EINVAL;
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(n * (D / 4), 256)), dim3(256), 0, stream, rows, ld, D, list, n, out);
+    U2PL_LAUNCH(k_gather_rows, dim3(grid_for(n * (D / 4), 256)), dim3(256), 0, stream, rows, ld, D, list, n, out);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -479,7 +742,7 @@ U2PL_API int u2pl_bank_append_multi_f32(const long long* desc_dev, int nclass, i
     if (D % 4) return U2PL_EINVAL;
     if (nclass <= 0 || max_new <= 0) return 0;
     dim3 grid(grid_for(max_new * (D / 4), 256, 64), nclass);
-    hipLaunchKernelGGL(k_bank_append_multi, grid, dim3(256), 0, stream, desc_dev, D, ld);
+    U2PL_LAUNCH(k_bank_append_multi, grid, dim3(256), 0, stream, desc_dev, D, ld);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -489,7 +752,7 @@ U2PL_API int u2pl_bank_append_f32(float* bank, long cap, long tail, int D, const
     if (D % 4 || cap <= 0) return U2PL_EINVAL;
     if (n_new <= 0) return 0;
     long skip = n_new > cap ? n_new - cap : 0;
-    hipLaunchKernelGGL(k_bank_append, dim3(grid_for((n_new - skip) * (D / 4), 256)), dim3(256), 0, stream, bank,
+    U2PL_LAUNCH(k_bank_append, dim3(grid_for((n_new - skip) * (D / 4), 256)), dim3(256), 0, stream, bank,
                        cap, tail, D, rows, ld, list, n_new, skip);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -683,10 +946,10 @@ U2PL_API int u2pl_infonce_f32(const void* jobs_dev, int njobs, const float* rep,
 #define NCE_ARGS grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next, seg_len
 #define NCE_LAUNCH(V)                                                                    \
     if (online) {                                                                        \
-        if (K <= 64) hipLaunchKernelGGL((k_infonce<V, true, true>), NCE_ARGS);           \
-        else hipLaunchKernelGGL((k_infonce<V, false, true>), NCE_ARGS);                  \
-    } else if (K <= 64) hipLaunchKernelGGL((k_infonce<V, true>), NCE_ARGS);              \
-    else hipLaunchKernelGGL((k_infonce<V, false>), NCE_ARGS);
+        if (K <= 64) U2PL_LAUNCH((k_infonce<V, true, true>), NCE_ARGS);           \
+        else U2PL_LAUNCH((k_infonce<V, false, true>), NCE_ARGS);                  \
+    } else if (K <= 64) U2PL_LAUNCH((k_infonce<V, true>), NCE_ARGS);              \
+    else U2PL_LAUNCH((k_infonce<V, false>), NCE_ARGS);
     switch (D) {
         case 64: NCE_LAUNCH(1) break;
         case 128: NCE_LAUNCH(2) break;
@@ -719,7 +982,7 @@ __global__ __launch_bounds__(1024) void k_infonce_reduce(const float* __restrict
 }
 U2PL_API int u2pl_infonce_reduce_f32(const float* loss_q, int njobs, int Q, float inv_valid_seg, float* loss,
                                      hipStream_t stream) {
-    hipLaunchKernelGGL(k_infonce_reduce, dim3(1), dim3(1024), 0, stream, loss_q, njobs, Q, inv_valid_seg, loss);
+    U2PL_LAUNCH(k_infonce_reduce, dim3(1), dim3(1024), 0, stream, loss_q, njobs, Q, inv_valid_seg, loss);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -774,7 +1037,7 @@ U2PL_API int u2pl_scatter_rows_ordered_f32(float* dst, long ld, int D, const int
                                            long n, const float* gout_dev, float scale, hipStream_t stream) {
     if (n <= 0) return 0;
     if (D % 4 || D > 256) return U2PL_EINVAL;
-    hipLaunchKernelGGL(k_scatter_rows_ordered, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, ld, D, pix, next, head, order,
+    U2PL_LAUNCH(k_scatter_rows_ordered, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, ld, D, pix, next, head, order,
                        seg_pos, seg_len, src, (int)n, gout_dev, scale);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -788,7 +1051,7 @@ __global__ void k_zero_rows(float* __restrict__ dst, long ld, int D, const int* 
 U2PL_API int u2pl_zero_rows_f32(float* dst, long ld, int D, const int* pix, long n, hipStream_t stream) {
     if (n <= 0) return 0;
     if (D % 4) return U2PL_EINVAL;
-    hipLaunchKernelGGL(k_zero_rows, dim3(grid_for(n * (D / 4), 256)), dim3(256), 0, stream, dst, ld, D, pix, n);
+    U2PL_LAUNCH(k_zero_rows, dim3(grid_for(n * (D / 4), 256)), dim3(256), 0, stream, dst, ld, D, pix, n);
     U2PL_LAUNCH_CHECK();
     return 0;
 }

@@ -333,7 +333,7 @@ static int launch_igemm(const float* x, long ldx, const float* w, const float* b
     const long wb = (long)g.Cout * g.R * g.S * g.Cin * 4;
     if (xb >= (1L << 31) || wb >= (1L << 31)) return U2PL_EINVAL;
     dim3 grid((unsigned)cdiv(m_end - m_begin, BM), (unsigned)cdiv(g.Cout, BN), (unsigned)batch);
-    hipLaunchKernelGGL((k_conv_igemm<TM, TN, WM, BF>), grid, dim3(128 * WM), lds, stream, x, ldx, w, bias, y, ldy, g, (unsigned)xb,
+    U2PL_LAUNCH((k_conv_igemm<TM, TN, WM, BF>), grid, dim3(128 * WM), lds, stream, x, ldx, w, bias, y, ldy, g, (unsigned)xb,
                        (unsigned)wb, m_begin, m_end, stats, pivot, zx, zw, zy, ep);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -504,7 +504,7 @@ __global__ void k_weight_transpose(const float* __restrict__ w, float* __restric
 }
 U2PL_API int u2pl_weight_transpose_f32(const float* w, float* wt, int Cout, int RS, int Cin, hipStream_t stream) {
     dim3 grid(cdiv(Cin, 32), cdiv(Cout, 32), RS);
-    hipLaunchKernelGGL(k_weight_transpose, grid, dim3(32, 8), 0, stream, w, wt, Cout, RS, Cin);
+    U2PL_LAUNCH(k_weight_transpose, grid, dim3(32, 8), 0, stream, w, wt, Cout, RS, Cin);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -830,7 +830,7 @@ static int launch_wgrad(const float* dy, long lddy, const float* x, long ldx, fl
     const long xb = (((long)g.N * g.Hin * g.Win - 1) * ldx + g.Cin) * 4;
     if (dyb >= (1L << 31) || xb >= (1L << 31)) return U2PL_EINVAL;
     dim3 grid((unsigned)(ctiles * g.R * g.S), (unsigned)cdiv(g.Cout, BM), (unsigned)nsplit);
-    hipLaunchKernelGGL((k_conv_wgrad<TM, TN, WM>), grid, dim3(128 * WM), lds, stream, dy, lddy, x, ldx, part, g, ctiles, cps,
+    U2PL_LAUNCH((k_conv_wgrad<TM, TN, WM>), grid, dim3(128 * WM), lds, stream, dy, lddy, x, ldx, part, g, ctiles, cps,
                        (unsigned)dyb, (unsigned)xb, zdy, zx);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -856,7 +856,7 @@ U2PL_API int u2pl_conv2d_wgrad_f32(const float* dy, long lddy, const float* x, l
     else rc = launch_wgrad<1, 1>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
     if (rc) return rc;
     const long wsz = (long)Cout * R * S * Cin;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(grid_for(wsz / 4, 256)), dim3(256), 0, stream, part, wsz, ns, accumulate, dw);
+    U2PL_LAUNCH(k_wgrad_reduce, dim3(grid_for(wsz / 4, 256)), dim3(256), 0, stream, part, wsz, ns, accumulate, dw);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -870,7 +870,7 @@ static int launch_wgrad_bf16(const float* dy, long lddy, const float* x, long ld
     const long xb = (((long)g.N * g.Hin * g.Win - 1) * ldx + g.Cin) * 4;
     if (dyb >= (1L << 31) || xb >= (1L << 31)) return U2PL_EINVAL;
     dim3 grid((unsigned)(ctiles * g.R * g.S), (unsigned)cdiv(g.Cout, BM), (unsigned)nsplit);
-    hipLaunchKernelGGL((k_conv_wgrad_bf16<TM, TN>), grid, dim3(256), lds, stream, dy, lddy, x, ldx, part, g, ctiles, cps,
+    U2PL_LAUNCH((k_conv_wgrad_bf16<TM, TN>), grid, dim3(256), lds, stream, dy, lddy, x, ldx, part, g, ctiles, cps,
                        (unsigned)dyb, (unsigned)xb);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -893,7 +893,7 @@ U2PL_API int u2pl_conv2d_wgrad_bf16op_f32(const float* dy, long lddy, const floa
     else rc = launch_wgrad_bf16<1, 1>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
     if (rc) return rc;
     const long wsz = (long)Cout * R * S * Cin;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(grid_for(wsz / 4, 256)), dim3(256), 0, stream, part, wsz, ns, accumulate, dw);
+    U2PL_LAUNCH(k_wgrad_reduce, dim3(grid_for(wsz / 4, 256)), dim3(256), 0, stream, part, wsz, ns, accumulate, dw);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -960,7 +960,7 @@ U2PL_API int u2pl_im2col_f32(const float* x, long ldx, float* col, int Kp, int N
                              int Hout, int Wout, int R, int S, int stride, int pad, int dil, hipStream_t stream) {
     ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, 0, R, S, stride, -pad, -pad, dil, 0};
     const long total = (long)N * Hout * Wout * Kp;
-    hipLaunchKernelGGL(k_im2col, dim3(grid_for(total, 256, 1 << 16)), dim3(256), 0, stream, x, ldx, col, g, Kp);
+    U2PL_LAUNCH(k_im2col, dim3(grid_for(total, 256, 1 << 16)), dim3(256), 0, stream, x, ldx, col, g, Kp);
     U2PL_LAUNCH_CHECK();
     return 0;
 }

@@ -5,6 +5,9 @@
 #include "common.h"
 #include "u2pl_hip.h"
 
+unsigned long long u2pl_kernel_launch_count = 0;
+U2PL_API size_t u2pl_kernel_launches(void) { return (size_t)u2pl_kernel_launch_count; }
+
 // per-pixel log-softmax pick; block partial sums in double -> partial[2*blk+{0,1}]
 __global__ void k_ce_fwd(const float* __restrict__ z, const long long* __restrict__ target, int ignore, int N,
                          int C, long HW, double* __restrict__ partial, const float* __restrict__ cw) {
@@ -68,10 +71,10 @@ U2PL_API int u2pl_ce_fwd_f32(const float* logits, const long long* target, int i
     long total = (long)N * H * W;
     if (total <= 0) return U2PL_EINVAL;
     int nblk = grid_for(total, 256, CE_BLOCKS);
-    hipLaunchKernelGGL(k_ce_fwd, dim3(nblk), dim3(256), 0, stream, logits, target, ignore, N, C, (long)H * W, (double*)workspace,
+    U2PL_LAUNCH(k_ce_fwd, dim3(nblk), dim3(256), 0, stream, logits, target, ignore, N, C, (long)H * W, (double*)workspace,
                        (const float*)nullptr);
     U2PL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_ce_finish, dim3(1), dim3(256), 0, stream, (const double*)workspace, nblk, (double)total, unsup_weight, out3);
+    U2PL_LAUNCH(k_ce_finish, dim3(1), dim3(256), 0, stream, (const double*)workspace, nblk, (double)total, unsup_weight, out3);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -82,10 +85,10 @@ U2PL_API int u2pl_ce_fwd_weighted_f32(const float* logits, const long long* targ
     long total = (long)N * H * W;
     if (total <= 0 || !class_weight) return U2PL_EINVAL;
     int nblk = grid_for(total, 256, CE_BLOCKS);
-    hipLaunchKernelGGL(k_ce_fwd, dim3(nblk), dim3(256), 0, stream, logits, target, ignore, N, C, (long)H * W, (double*)workspace,
+    U2PL_LAUNCH(k_ce_fwd, dim3(nblk), dim3(256), 0, stream, logits, target, ignore, N, C, (long)H * W, (double*)workspace,
                        class_weight);
     U2PL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_ce_finish, dim3(1), dim3(256), 0, stream, (const double*)workspace, nblk, (double)total, 0, out3);
+    U2PL_LAUNCH(k_ce_finish, dim3(1), dim3(256), 0, stream, (const double*)workspace, nblk, (double)total, 0, out3);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -122,7 +125,7 @@ U2PL_API int u2pl_ce_bwd_f32(const float* logits, const long long* target, int i
                              hipStream_t stream) {
     long total = (long)N * H * W;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_ce_bwd, dim3(grid_for(total, 256)), dim3(256), 0, stream, logits, target, ignore, N, C,
+    U2PL_LAUNCH(k_ce_bwd, dim3(grid_for(total, 256)), dim3(256), 0, stream, logits, target, ignore, N, C,
                        (long)H * W, out3_dev, gout_dev, gmul, grad, (const float*)nullptr);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -132,7 +135,7 @@ U2PL_API int u2pl_ce_bwd_weighted_f32(const float* logits, const long long* targ
                                       float gmul, float* grad, hipStream_t stream) {
     long total = (long)N * H * W;
     if (total <= 0 || !class_weight) return U2PL_EINVAL;
-    hipLaunchKernelGGL(k_ce_bwd, dim3(grid_for(total, 256)), dim3(256), 0, stream, logits, target, ignore, N, C,
+    U2PL_LAUNCH(k_ce_bwd, dim3(grid_for(total, 256)), dim3(256), 0, stream, logits, target, ignore, N, C,
                        (long)H * W, out3_dev, gout_dev, gmul, grad, class_weight);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -172,7 +175,7 @@ U2PL_API int u2pl_ohem_prob_f32(const float* logits, const long long* target, in
                                 int W, float* mask_prob, unsigned* nvalid, hipStream_t stream) {
     long total = (long)N * H * W;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_ohem_prob, dim3(grid_for(total, 256, 512)), dim3(256), 0, stream, logits, target, ignore, N,
+    U2PL_LAUNCH(k_ohem_prob, dim3(grid_for(total, 256, 512)), dim3(256), 0, stream, logits, target, ignore, N,
                        C, (long)H * W, mask_prob, nvalid);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -191,7 +194,7 @@ __global__ void k_ohem_apply(const float* __restrict__ mp, const unsigned* __res
 U2PL_API int u2pl_ohem_apply_i64(const float* mask_prob, const unsigned* thr_bits, const long long* target,
                                  int ignore, long n, long long* kept_target, hipStream_t stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_ohem_apply, dim3(grid_for(n, 256)), dim3(256), 0, stream, mask_prob, thr_bits, target, ignore, n, kept_target);
+    U2PL_LAUNCH(k_ohem_apply, dim3(grid_for(n, 256)), dim3(256), 0, stream, mask_prob, thr_bits, target, ignore, n, kept_target);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -232,7 +235,7 @@ U2PL_API int u2pl_confusion_hist_f32(const float* logits, const long long* targe
                                      int W, long long* hist3c, hipStream_t stream) {
     const long total = (long)N * H * W;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_confusion, dim3(grid_for(total, 256, 512)), dim3(256), 3 * C * sizeof(unsigned), stream, logits,
+    U2PL_LAUNCH(k_confusion, dim3(grid_for(total, 256, 512)), dim3(256), 3 * C * sizeof(unsigned), stream, logits,
                        target, ignore, N, C, (long)H * W, (unsigned long long*)hist3c);
     U2PL_LAUNCH_CHECK();
     return 0;

@@ -136,16 +136,16 @@ template <class Op>
 static int run_colreduce(Op op, long Mseg, int nseg, int C, void* ws, double* out, hipStream_t stream) {
     if (C % 4 || Mseg <= 0) return U2PL_EINVAL;
     const int nblk = colreduce_blocks(Mseg);
-    hipLaunchKernelGGL((k_colreduce_partial<Op>), dim3(nblk, nseg, cdiv(C / 4, 64)), dim3(256), 0, stream, op, Mseg, C, (float*)ws);
+    U2PL_LAUNCH((k_colreduce_partial<Op>), dim3(nblk, nseg, cdiv(C / 4, 64)), dim3(256), 0, stream, op, Mseg, C, (float*)ws);
     U2PL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_colreduce_final, dim3(cdiv(2 * C, 64), nseg), dim3(1024), 0, stream, (const float*)ws, nblk, C, out);
+    U2PL_LAUNCH(k_colreduce_final, dim3(cdiv(2 * C, 64), nseg), dim3(1024), 0, stream, (const float*)ws, nblk, C, out);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
 
 // ordered finish of externally produced partials (conv epilogue statistics): [nblk][2][C] float -> double [2][C]
 U2PL_API int u2pl_colreduce_finish_f32(const float* partial, int nblk, int C, double* sums, hipStream_t stream) {
-    hipLaunchKernelGGL(k_colreduce_final, dim3(cdiv(2 * C, 64), 1), dim3(1024), 0, stream, partial, nblk, C, sums);
+    U2PL_LAUNCH(k_colreduce_final, dim3(cdiv(2 * C, 64), 1), dim3(1024), 0, stream, partial, nblk, C, sums);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -171,7 +171,7 @@ __global__ void k_bn_stats_small(const float* __restrict__ x, long ld, int M, in
 U2PL_API int u2pl_bn_stats_f32(const float* x, long ld, long M, int C, const float* pivot, void* workspace,
                                double* sums, hipStream_t stream) {
     if (M <= 64) {
-        hipLaunchKernelGGL(k_bn_stats_small, dim3(cdiv(C, 64)), dim3(64), 0, stream, x, ld, (int)M, C, pivot, sums);
+        U2PL_LAUNCH(k_bn_stats_small, dim3(cdiv(C, 64)), dim3(64), 0, stream, x, ld, (int)M, C, pivot, sums);
         U2PL_LAUNCH_CHECK();
         return 0;
     }
@@ -215,7 +215,7 @@ __global__ void k_bn_finalize(const double* __restrict__ sums, double count, con
 U2PL_API int u2pl_bn_finalize_f32(const double* sums, double count, const float* pivot, int C, float eps,
                                   float momentum, float* mean, float* invstd, float* running_mean,
                                   float* running_var, hipStream_t stream) {
-    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, stream, sums, count, pivot, C, eps, momentum,
+    U2PL_LAUNCH(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, stream, sums, count, pivot, C, eps, momentum,
                        mean, invstd, running_mean, running_var);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -226,7 +226,7 @@ __global__ void k_bn_eval_prep(const float* __restrict__ rv, int C, float eps, f
         invstd[c] = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
 }
 U2PL_API int u2pl_bn_eval_invstd_f32(const float* running_var, int C, float eps, float* invstd, hipStream_t stream) {
-    hipLaunchKernelGGL(k_bn_eval_prep, dim3(cdiv(C, 256)), dim3(256), 0, stream, running_var, C, eps, invstd);
+    U2PL_LAUNCH(k_bn_eval_prep, dim3(cdiv(C, 256)), dim3(256), 0, stream, running_var, C, eps, invstd);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -257,7 +257,7 @@ U2PL_API int u2pl_bn_apply_f32(const float* x, long ldx, const float* mean, cons
                                const float* beta, const float* res, long ldr, int relu, const float* drop,
                                long rows_per_image, float* y, long ldy, long M, int C, hipStream_t stream) {
     if (C % 4) return U2PL_EINVAL;
-    hipLaunchKernelGGL(k_bn_apply, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, x, ldx, mean, invstd, gamma,
+    U2PL_LAUNCH(k_bn_apply, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, x, ldx, mean, invstd, gamma,
                        beta, res, ldr, relu, drop, rows_per_image, y, ldy, M, C);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -307,7 +307,7 @@ U2PL_API int u2pl_bn_bwd_apply_f32(const float* dy, long lddy, const float* x, l
                                    long rows_per_image, const double* sums, double count, float* dx, long lddx,
                                    float* dres, long lddr, long M, int C, hipStream_t stream) {
     if (C % 4) return U2PL_EINVAL;
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, dy, lddy, x, ldx, y, ldy,
+    U2PL_LAUNCH(k_bn_bwd_apply, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, dy, lddy, x, ldx, y, ldy,
                        mean, invstd, gamma, drop, rows_per_image, sums, count, dx, lddx, dres, lddr, M, C);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -318,7 +318,7 @@ __global__ void k_sums_to_f32(const double* __restrict__ s, int n, float scale, 
         out[i] = (accumulate ? out[i] : 0.f) + (float)(s[i] * (double)scale);
 }
 U2PL_API int u2pl_sums_to_f32(const double* sums, int n, float scale, int accumulate, float* out, hipStream_t stream) {
-    hipLaunchKernelGGL(k_sums_to_f32, dim3(cdiv(n, 256)), dim3(256), 0, stream, sums, n, scale, accumulate, out);
+    U2PL_LAUNCH(k_sums_to_f32, dim3(cdiv(n, 256)), dim3(256), 0, stream, sums, n, scale, accumulate, out);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -361,7 +361,7 @@ __global__ void k_maxpool_fwd(const float* __restrict__ x, long ldx, int N, int 
 U2PL_API int u2pl_maxpool3s2_fwd_f32(const float* x, long ldx, int N, int H, int W, int C, int Ho, int Wo, float* y,
                                      long ldy, unsigned char* tap, hipStream_t stream) {
     if (C % 4) return U2PL_EINVAL;
-    hipLaunchKernelGGL(k_maxpool_fwd, dim3(grid_for((long)N * Ho * Wo * (C / 4), 256)), dim3(256), 0, stream, x, ldx, N, H,
+    U2PL_LAUNCH(k_maxpool_fwd, dim3(grid_for((long)N * Ho * Wo * (C / 4), 256)), dim3(256), 0, stream, x, ldx, N, H,
                        W, C, Ho, Wo, y, ldy, tap);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -401,7 +401,7 @@ __global__ void k_maxpool_bwd(const float* __restrict__ dy, long lddy, const uns
 }
 U2PL_API int u2pl_maxpool3s2_bwd_f32(const float* dy, long lddy, const unsigned char* tap, int N, int H, int W, int C,
                                      int Ho, int Wo, float* dx, long lddx, hipStream_t stream) {
-    hipLaunchKernelGGL(k_maxpool_bwd, dim3(grid_for((long)N * H * W * (C / 4), 256)), dim3(256), 0, stream, dy, lddy, tap, N,
+    U2PL_LAUNCH(k_maxpool_bwd, dim3(grid_for((long)N * H * W * (C / 4), 256)), dim3(256), 0, stream, dy, lddy, tap, N,
                        H, W, C, Ho, Wo, dx, lddx);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -428,7 +428,7 @@ U2PL_API int u2pl_copy_rows_f32(const float* src, long lds, float* dst, long ldd
                                 hipStream_t stream) {
     if (C % 4) return U2PL_EINVAL;
     if (M <= 0) return 0;
-    hipLaunchKernelGGL(k_copy_rows, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, src, lds, dst, ldd, M, C, accumulate);
+    U2PL_LAUNCH(k_copy_rows, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, src, lds, dst, ldd, M, C, accumulate);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -443,7 +443,7 @@ __global__ void k_copy_cols(const float* __restrict__ src, long lds, float* __re
 }
 U2PL_API int u2pl_copy_cols_f32(const float* src, long lds, float* dst, long ldd, long M, int C, hipStream_t stream) {
     if (M <= 0) return 0;
-    hipLaunchKernelGGL(k_copy_cols, dim3(grid_for(M * C, 256)), dim3(256), 0, stream, src, lds, dst, ldd, M, C);
+    U2PL_LAUNCH(k_copy_cols, dim3(grid_for(M * C, 256)), dim3(256), 0, stream, src, lds, dst, ldd, M, C);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -462,7 +462,7 @@ __global__ void k_broadcast_rows(const float* __restrict__ v, long ldv, float sc
 U2PL_API int u2pl_broadcast_rows_f32(const float* v, long ldv, float scale, float* dst, long ldd, long rows_per_image,
                                      long M, int C, hipStream_t stream) {
     if (C % 4) return U2PL_EINVAL;
-    hipLaunchKernelGGL(k_broadcast_rows, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, v, ldv, scale, dst, ldd,
+    U2PL_LAUNCH(k_broadcast_rows, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, v, ldv, scale, dst, ldd,
                        rows_per_image, M, C);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -496,7 +496,7 @@ __global__ void k_bilinear_rows_fwd(const float* __restrict__ x, long ldx, int N
 U2PL_API int u2pl_bilinear_rows_fwd_f32(const float* x, long ldx, int N, int h, int w, int C, int H, int W, float* y,
                                         long ldy, hipStream_t stream) {
     if (C % 4) return U2PL_EINVAL;
-    hipLaunchKernelGGL(k_bilinear_rows_fwd, dim3(grid_for((long)N * H * W * (C / 4), 256)), dim3(256), 0, stream, x, ldx, N, h,
+    U2PL_LAUNCH(k_bilinear_rows_fwd, dim3(grid_for((long)N * H * W * (C / 4), 256)), dim3(256), 0, stream, x, ldx, N, h,
                        w, C, H, W, ac_scale_host(h, H), ac_scale_host(w, W), y, ldy);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -534,7 +534,7 @@ __global__ void k_bilinear_rows_bwd(const float* __restrict__ dy, long lddy, int
 U2PL_API int u2pl_bilinear_rows_bwd_f32(const float* dy, long lddy, int N, int h, int w, int C, int H, int W, float* dx,
                                         long lddx, hipStream_t stream) {
     if (C % 4) return U2PL_EINVAL;
-    hipLaunchKernelGGL(k_bilinear_rows_bwd, dim3(grid_for((long)N * h * w * (C / 4), 256)), dim3(256), 0, stream, dy, lddy, N,
+    U2PL_LAUNCH(k_bilinear_rows_bwd, dim3(grid_for((long)N * h * w * (C / 4), 256)), dim3(256), 0, stream, dy, lddy, N,
                        h, w, C, H, W, ac_scale_host(h, H), ac_scale_host(w, W), dx, lddx);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -554,7 +554,7 @@ __global__ void k_softmax_rows(const float* __restrict__ x, long ldx, float* __r
     }
 }
 U2PL_API int u2pl_softmax_rows_f32(const float* x, long ldx, float* y, long ldy, long M, int C, hipStream_t stream) {
-    hipLaunchKernelGGL(k_softmax_rows, dim3(grid_for(M, 256)), dim3(256), 0, stream, x, ldx, y, ldy, M, C);
+    U2PL_LAUNCH(k_softmax_rows, dim3(grid_for(M, 256)), dim3(256), 0, stream, x, ldx, y, ldy, M, C);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -580,7 +580,7 @@ U2PL_API int u2pl_sgd_step_f32(float* p, const float* g, float* buf, long n, lon
                                float lr2, float momentum, float weight_decay, int first, float grad_scale,
                                hipStream_t stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_sgd, dim3(grid_for(n, 256)), dim3(256), 0, stream, p, g, buf, n, b1, b2, lr0, lr1, lr2, momentum,
+    U2PL_LAUNCH(k_sgd, dim3(grid_for(n, 256)), dim3(256), 0, stream, p, g, buf, n, b1, b2, lr0, lr1, lr2, momentum,
                        weight_decay, first, grad_scale);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -592,7 +592,7 @@ __global__ void k_ema(float* __restrict__ t, const float* __restrict__ s, long n
 U2PL_API int u2pl_ema_update_f32(float* t, const float* s, long n, float decay, float one_minus_decay,
                                  hipStream_t stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_ema, dim3(grid_for(n, 256)), dim3(256), 0, stream, t, s, n, decay, one_minus_decay);
+    U2PL_LAUNCH(k_ema, dim3(grid_for(n, 256)), dim3(256), 0, stream, t, s, n, decay, one_minus_decay);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void k_dense_small(const float* __restrict__ x
 U2PL_API int u2pl_dense_small_f32(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, int M,
                                   int K, int Cout, hipStream_t stream) {
     if (M < 1 || M > DENSE_MAXM || K % 4) return U2PL_EINVAL;
-    hipLaunchKernelGGL(k_dense_small, dim3(cdiv(Cout, 4)), dim3(256), 0, stream, x, ldx, w, bias, y, ldy, M, K, Cout);
+    U2PL_LAUNCH(k_dense_small, dim3(cdiv(Cout, 4)), dim3(256), 0, stream, x, ldx, w, bias, y, ldy, M, K, Cout);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -663,7 +663,7 @@ __global__ void k_cutmix(const float* __restrict__ img, const long long* __restr
 U2PL_API int u2pl_cutmix_f32(const float* img, const long long* label, const float* conf, const int* boxes_dev, int B,
                              int C, int H, int W, float* out_img, long long* out_label, float* out_conf,
                              hipStream_t stream) {
-    hipLaunchKernelGGL(k_cutmix, dim3(grid_for((long)B * H * W, 256)), dim3(256), 0, stream, img, label, conf, boxes_dev, B, C,
+    U2PL_LAUNCH(k_cutmix, dim3(grid_for((long)B * H * W, 256)), dim3(256), 0, stream, img, label, conf, boxes_dev, B, C,
                        H, W, out_img, out_label, out_conf);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -708,7 +708,7 @@ U2PL_API int u2pl_strong_aug_f32(const float* img, const long long* label, const
                                  long long* out_label, float* out_conf, hipStream_t stream) {
     if (mode != 1 && mode != 2) return 1;
     if ((mode == 1 && !boxes_dev) || (mode == 2 && !sel_dev)) return 1;
-    hipLaunchKernelGGL(k_strong_aug, dim3(grid_for((long)B * H * W, 256)), dim3(256), 0, stream, img, label, conf, boxes_dev,
+    U2PL_LAUNCH(k_strong_aug, dim3(grid_for((long)B * H * W, 256)), dim3(256), 0, stream, img, label, conf, boxes_dev,
                        sel_dev, mode, B, C, H, W, out_img, out_label, out_conf);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -729,7 +729,7 @@ __global__ void k_label_presence(const long long* __restrict__ lab, long HW, uns
 U2PL_API int u2pl_label_presence_i64(const long long* label, int B, long HW, unsigned long long* bits, hipStream_t stream) {
     long nb = (HW + 255) / 256;
     if (nb > 256) nb = 256;
-    hipLaunchKernelGGL(k_label_presence, dim3((unsigned)nb, B), dim3(256), 0, stream, label, HW, bits);
+    U2PL_LAUNCH(k_label_presence, dim3((unsigned)nb, B), dim3(256), 0, stream, label, HW, bits);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -755,7 +755,7 @@ U2PL_API int u2pl_window_accumulate_f32(float* pred, float* count, int C, int H,
     if (h0 < 0 || w0 < 0 || h0 + hc > H || w0 + wc > W) return U2PL_EINVAL;
     const long total = (long)C * hc * wc;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_window_acc, dim3(grid_for(total, 256)), dim3(256), 0, stream, pred, count, C, H, W, src, h0, w0, hc, wc);
+    U2PL_LAUNCH(k_window_acc, dim3(grid_for(total, 256)), dim3(256), 0, stream, pred, count, C, H, W, src, h0, w0, hc, wc);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -767,7 +767,7 @@ __global__ void k_window_div(float* __restrict__ pred, const float* __restrict__
 U2PL_API int u2pl_window_normalize_f32(float* pred, const float* count, int C, int H, int W, hipStream_t stream) {
     const long total = (long)C * H * W;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_window_div, dim3(grid_for(total, 256)), dim3(256), 0, stream, pred, count, C, (long)H * W);
+    U2PL_LAUNCH(k_window_div, dim3(grid_for(total, 256)), dim3(256), 0, stream, pred, count, C, (long)H * W);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -848,7 +848,7 @@ U2PL_API int u2pl_augment_u8_f32(const unsigned char* img, const unsigned char* 
     const long total = (long)B * Sh * Sw;
     if (total <= 0) return 0;
     // mean / std are HOST pointers (three floats each): they travel as kernel arguments
-    hipLaunchKernelGGL(k_augment, dim3(grid_for(total, 256)), dim3(256), 0, stream, img, lab, params, B, H, W, Sh, Sw,
+    U2PL_LAUNCH(k_augment, dim3(grid_for(total, 256)), dim3(256), 0, stream, img, lab, params, B, H, W, Sh, Sw,
                        mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], out_img, out_lab);
     U2PL_LAUNCH_CHECK();
     return 0;

@@ -42,7 +42,7 @@ U2PL_API int u2pl_bilinear_up_f32(const float* in, long sn, long sc, long sh, lo
                                   int h, int w, float* out, int H, int W, hipStream_t stream) {
     if (N <= 0 || C <= 0) return 0;
     long total = (long)N * H * W;
-    hipLaunchKernelGGL(k_bilinear_up, dim3(grid_for(total, 256)), dim3(256), 0, stream, in, sn, sc, sh,
+    U2PL_LAUNCH(k_bilinear_up, dim3(grid_for(total, 256)), dim3(256), 0, stream, in, sn, sc, sh,
                        sw, N, C, h, w, out, H, W, ac_scale_host(h, H), ac_scale_host(w, W));
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -91,7 +91,7 @@ U2PL_API int u2pl_bilinear_up_bwd_f32(const float* gout, int N, int C, int H, in
                                       long sc, long sh, long sw, int h, int w, hipStream_t stream) {
     if (N <= 0 || C <= 0) return 0;
     long total = (long)N * C * h * w;
-    hipLaunchKernelGGL(k_bilinear_up_bwd, dim3(grid_for(total, 256, 1 << 20)), dim3(256), 0, stream, gout, N, C, H,
+    U2PL_LAUNCH(k_bilinear_up_bwd, dim3(grid_for(total, 256, 1 << 20)), dim3(256), 0, stream, gout, N, C, H,
                        W, gin, sn, sc, sh, sw, h, w, ac_scale_host(h, H), ac_scale_host(w, W));
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -124,7 +124,7 @@ U2PL_API int u2pl_pseudo_label_f32(const float* logits, int N, int C, int H, int
                                    long long* label, hipStream_t stream) {
     long total = (long)N * H * W;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_pseudo_label, dim3(grid_for(total, 256)), dim3(256), 0, stream, logits, N, C,
+    U2PL_LAUNCH(k_pseudo_label, dim3(grid_for(total, 256)), dim3(256), 0, stream, logits, N, C,
                        (long)H * W, conf, label);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -183,7 +183,7 @@ U2PL_API int u2pl_entropy_f32(const float* logits, const long long* label, int i
                               int W, float* entropy, unsigned* ws, hipStream_t stream) {
     long total = (long)N * H * W;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_entropy, dim3(grid_for(total, 256, 512)), dim3(256), 0, stream, logits, label, ignore,
+    U2PL_LAUNCH(k_entropy, dim3(grid_for(total, 256, 512)), dim3(256), 0, stream, logits, label, ignore,
                        N, C, (long)H * W, entropy, ws);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -429,16 +429,16 @@ U2PL_API int u2pl_entropy_up_f32(const float* in, long sn, long sc, long sh, lon
             const long ncell8 = (long)N * h * w;
             dim3 lg(grid_for(ncell8, 64, 2048)), lb(256);
             if (C == 19)
-                hipLaunchKernelGGL(k_entropy_up_cell_lds<19>, lg, lb, 0, stream, in, sn, sc, sh, sw, N, h, w, H, W, sy, sx, label, ignore, entropy, ws);
+                U2PL_LAUNCH(k_entropy_up_cell_lds<19>, lg, lb, 0, stream, in, sn, sc, sh, sw, N, h, w, H, W, sy, sx, label, ignore, entropy, ws);
             else
-                hipLaunchKernelGGL(k_entropy_up_cell_lds<21>, lg, lb, 0, stream, in, sn, sc, sh, sw, N, h, w, H, W, sy, sx, label, ignore, entropy, ws);
+                U2PL_LAUNCH(k_entropy_up_cell_lds<21>, lg, lb, 0, stream, in, sn, sc, sh, sw, N, h, w, H, W, sy, sx, label, ignore, entropy, ws);
             U2PL_LAUNCH_CHECK();
             return 0;
         }
         const long nwork = (long)N * h * w * (4 / ry);
         dim3 cgrid(grid_for(nwork, 64, 8192)), cblock(64);
 #define ENT_CASE(CC, RR)                                                                                       \
-    hipLaunchKernelGGL((k_entropy_up_cell<4, CC, RR>), cgrid, cblock, 0, stream, in, sn, sc, sh, sw, N, h, w, H, W, sy, \
+    U2PL_LAUNCH((k_entropy_up_cell<4, CC, RR>), cgrid, cblock, 0, stream, in, sn, sc, sh, sw, N, h, w, H, W, sy, \
                        sx, label, ignore, entropy, ws)
         if (C == 19) { if (ry == 1) ENT_CASE(19, 1); else if (ry == 2) ENT_CASE(19, 2); else ENT_CASE(19, 4); }
         else { if (ry == 1) ENT_CASE(21, 1); else if (ry == 2) ENT_CASE(21, 2); else ENT_CASE(21, 4); }
@@ -447,11 +447,11 @@ U2PL_API int u2pl_entropy_up_f32(const float* in, long sn, long sc, long sh, lon
         return 0;
     }
     if (C == 19)
-        hipLaunchKernelGGL(k_entropy_up<19>, grid, block, 0, stream, in, sn, sc, sh, sw, N, C, h, w, H, W, sy, sx, label, ignore, entropy, ws);
+        U2PL_LAUNCH(k_entropy_up<19>, grid, block, 0, stream, in, sn, sc, sh, sw, N, C, h, w, H, W, sy, sx, label, ignore, entropy, ws);
     else if (C == 21)
-        hipLaunchKernelGGL(k_entropy_up<21>, grid, block, 0, stream, in, sn, sc, sh, sw, N, C, h, w, H, W, sy, sx, label, ignore, entropy, ws);
+        U2PL_LAUNCH(k_entropy_up<21>, grid, block, 0, stream, in, sn, sc, sh, sw, N, C, h, w, H, W, sy, sx, label, ignore, entropy, ws);
     else
-        hipLaunchKernelGGL(k_entropy_up<0>, grid, block, 0, stream, in, sn, sc, sh, sw, N, C, h, w, H, W, sy, sx, label, ignore, entropy, ws);
+        U2PL_LAUNCH(k_entropy_up<0>, grid, block, 0, stream, in, sn, sc, sh, sw, N, C, h, w, H, W, sy, sx, label, ignore, entropy, ws);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -476,7 +476,7 @@ __global__ void k_apply_drop(const float* __restrict__ ent, const unsigned* __re
 U2PL_API int u2pl_apply_drop_i64(const float* entropy, const unsigned* thr_bits, long long* target,
                                  int ignore, long n, unsigned* nkept, hipStream_t stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_apply_drop, dim3(grid_for(n, 256, 512)), dim3(256), 0, stream, entropy, thr_bits,
+    U2PL_LAUNCH(k_apply_drop, dim3(grid_for(n, 256, 512)), dim3(256), 0, stream, entropy, thr_bits,
                        target, ignore, n, nkept);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -581,7 +581,7 @@ U2PL_API int u2pl_reliability_apply(const float* entropy, const unsigned* thr_bi
                                     float* high_mask, unsigned* lbits, hipStream_t stream) {
     const long total = (long)B * H * W + (long)2 * B * h * w;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_reliability_apply, dim3(grid_for(total, 256, 1024)), dim3(256), 0, stream, entropy, thr_bits, label_l,
+    U2PL_LAUNCH(k_reliability_apply, dim3(grid_for(total, 256, 1024)), dim3(256), 0, stream, entropy, thr_bits, label_l,
                        label_u, ignore, B, H, W, h, w, (float)H / (float)h, (float)W / (float)w, negative_high_entropy,
                        target_u, nkept, low_mask, high_mask, lbits);
     U2PL_LAUNCH_CHECK();
@@ -596,7 +596,7 @@ U2PL_API int u2pl_reliability_masks(const float* entropy, const unsigned* thr_lo
     long total = (long)2 * B * h * w;
     if (total <= 0) return 0;
     float ny = (float)H / (float)h, nx = (float)W / (float)w;
-    hipLaunchKernelGGL(k_reliability_masks, dim3(grid_for(total, 256)), dim3(256), 0, stream, entropy,
+    U2PL_LAUNCH(k_reliability_masks, dim3(grid_for(total, 256)), dim3(256), 0, stream, entropy,
                        thr_lo_bits, thr_hi_bits, label_l, label_u, ignore, B, H, W, h, w, ny, nx,
                        negative_high_entropy, low_mask, high_mask, lbits);
     U2PL_LAUNCH_CHECK();
@@ -628,7 +628,7 @@ U2PL_API int u2pl_pack_class_bits(const long long* onehot, int N, int C, int h, 
     if (C > 32) return U2PL_EINVAL;
     long total = (long)N * h * w;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_pack_bits, dim3(grid_for(total, 256)), dim3(256), 0, stream, onehot, N, C, (long)h * w, bits);
+    U2PL_LAUNCH(k_pack_bits, dim3(grid_for(total, 256)), dim3(256), 0, stream, onehot, N, C, (long)h * w, bits);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -636,7 +636,7 @@ U2PL_API int u2pl_unpack_class_bits(const unsigned* bits, int N, int C, int h, i
                                     hipStream_t stream) {
     long total = (long)N * C * h * w;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_unpack_bits, dim3(grid_for(total, 256)), dim3(256), 0, stream, bits, N, C, (long)h * w, onehot);
+    U2PL_LAUNCH(k_unpack_bits, dim3(grid_for(total, 256)), dim3(256), 0, stream, bits, N, C, (long)h * w, onehot);
     U2PL_LAUNCH_CHECK();
     return 0;
 }

@@ -255,14 +255,14 @@ U2PL_API int u2pl_select_f32(const float* values, long n, int nspec, const int* 
     if (nspec < 1 || 2 * nspec > MAXS) return U2PL_EINVAL;
     const int grid = grid_for(n / 4 + 1, 256, 256);   // one block per CU: fewer histogram flushes
     if (!hist0_done) {
-        hipLaunchKernelGGL(k_sel_hist0, dim3(grid), dim3(256), 0, stream, values, n, ws);
+        U2PL_LAUNCH(k_sel_hist0, dim3(grid), dim3(256), 0, stream, values, n, ws);
         U2PL_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_sel_pass<1>, dim3(grid), dim3(256), 0, stream, values, n, nspec, spec_kind, q32, kparam, ws);
+    U2PL_LAUNCH(k_sel_pass<1>, dim3(grid), dim3(256), 0, stream, values, n, nspec, spec_kind, q32, kparam, ws);
     U2PL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sel_pass<2>, dim3(grid), dim3(256), 0, stream, values, n, nspec, spec_kind, q32, kparam, ws);
+    U2PL_LAUNCH(k_sel_pass<2>, dim3(grid), dim3(256), 0, stream, values, n, nspec, spec_kind, q32, kparam, ws);
     U2PL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sel_finish, dim3(1), dim3(256), 0, stream, nspec, spec_kind, q32, kparam, fparam, ws);
+    U2PL_LAUNCH(k_sel_finish, dim3(1), dim3(256), 0, stream, nspec, spec_kind, q32, kparam, fparam, ws);
     U2PL_LAUNCH_CHECK();
     return 0;
 }

@@ -448,8 +448,8 @@ U2PL_API int u2pl_wino_input_f32(const float* x, long ldx, int N, int H, int W, 
     if (xb >= (1L << 31)) return U2PL_EINVAL;
     const long total = g.tiles * (C / 4);
     const dim3 grid((unsigned)cdiv(total, 256)), block(256);
-    if (mt == 4) hipLaunchKernelGGL(k_wino_input<4>, grid, block, 0, stream, x, ldx, (unsigned)xb, g, V);
-    else hipLaunchKernelGGL(k_wino_input<2>, grid, block, 0, stream, x, ldx, (unsigned)xb, g, V);
+    if (mt == 4) U2PL_LAUNCH(k_wino_input<4>, grid, block, 0, stream, x, ldx, (unsigned)xb, g, V);
+    else U2PL_LAUNCH(k_wino_input<2>, grid, block, 0, stream, x, ldx, (unsigned)xb, g, V);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -457,8 +457,8 @@ U2PL_API int u2pl_wino_input_f32(const float* x, long ldx, int N, int H, int W, 
 U2PL_API int u2pl_wino_weight_f32(const float* w, int O, int C, int transposed, int mt, float* U, hipStream_t stream) {
     if (mt != 2 && mt != 4) return U2PL_EINVAL;
     const dim3 grid((unsigned)cdiv((long)O * C, 256)), block(256);
-    if (mt == 4) hipLaunchKernelGGL(k_wino_weight<4>, grid, block, 0, stream, w, O, C, transposed, U);
-    else hipLaunchKernelGGL(k_wino_weight<2>, grid, block, 0, stream, w, O, C, transposed, U);
+    if (mt == 4) U2PL_LAUNCH(k_wino_weight<4>, grid, block, 0, stream, w, O, C, transposed, U);
+    else U2PL_LAUNCH(k_wino_weight<2>, grid, block, 0, stream, w, O, C, transposed, U);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -470,8 +470,8 @@ static int run_wino_output(const float* Mb, int N, int H, int W, int O, int dil,
     if (stats_partial && (O / 4 > 256 || (O & 3))) return U2PL_EINVAL;
     const long total = g.tiles * (O / 4);
     const unsigned nblk = stats_partial ? (unsigned)u2pl_wino_stat_blocks(g.tiles, O) : (unsigned)cdiv(total, 256);
-    if (mt == 4) hipLaunchKernelGGL(k_wino_output<4>, dim3(nblk), dim3(256), 0, stream, Mb, g, O, bias, y, ldy, stats_partial, pivot, epi);
-    else hipLaunchKernelGGL(k_wino_output<2>, dim3(nblk), dim3(256), 0, stream, Mb, g, O, bias, y, ldy, stats_partial, pivot, epi);
+    if (mt == 4) U2PL_LAUNCH(k_wino_output<4>, dim3(nblk), dim3(256), 0, stream, Mb, g, O, bias, y, ldy, stats_partial, pivot, epi);
+    else U2PL_LAUNCH(k_wino_output<2>, dim3(nblk), dim3(256), 0, stream, Mb, g, O, bias, y, ldy, stats_partial, pivot, epi);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -498,8 +498,8 @@ U2PL_API int u2pl_wino_gy_f32(const float* gy, long ldg, int N, int H, int W, in
     if (gb >= (1L << 31)) return U2PL_EINVAL;
     const long total = g.tiles * (O / 4);
     const dim3 grid((unsigned)cdiv(total, 256)), block(256);
-    if (mt == 4) hipLaunchKernelGGL(k_wino_gy<4>, grid, block, 0, stream, gy, ldg, (unsigned)gb, g, Mg);
-    else hipLaunchKernelGGL(k_wino_gy<2>, grid, block, 0, stream, gy, ldg, (unsigned)gb, g, Mg);
+    if (mt == 4) U2PL_LAUNCH(k_wino_gy<4>, grid, block, 0, stream, gy, ldg, (unsigned)gb, g, Mg);
+    else U2PL_LAUNCH(k_wino_gy<2>, grid, block, 0, stream, gy, ldg, (unsigned)gb, g, Mg);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -509,8 +509,8 @@ U2PL_API int u2pl_wino_wgrad_finish_f32(const float* part, int nsplit, int O, in
     if (mt != 2 && mt != 4) return U2PL_EINVAL;
     if (C % 4) return U2PL_EINVAL;
     const dim3 grid((unsigned)cdiv((long)O * (C / 4), 256)), block(256);
-    if (mt == 4) hipLaunchKernelGGL(k_wino_wgrad_finish<4>, grid, block, 0, stream, part, nsplit, O, C, accumulate, dw);
-    else hipLaunchKernelGGL(k_wino_wgrad_finish<2>, grid, block, 0, stream, part, nsplit, O, C, accumulate, dw);
+    if (mt == 4) U2PL_LAUNCH(k_wino_wgrad_finish<4>, grid, block, 0, stream, part, nsplit, O, C, accumulate, dw);
+    else U2PL_LAUNCH(k_wino_wgrad_finish<2>, grid, block, 0, stream, part, nsplit, O, C, accumulate, dw);
     U2PL_LAUNCH_CHECK();
     return 0;
 }

@@ -2,6 +2,8 @@
 
 Everything numeric happens in libu2pl_hip.so; torch supplies device memory,
 the current HIP stream and the autograd tape (torch.autograd.Function)."""
+import os
+
 import numpy as np
 import torch
 
@@ -164,15 +166,28 @@ def _rf_workspace(device, n_px):
     import torch.cuda as tc
     key = (str(device), tc.current_stream().cuda_stream)
     ent = _RF_WS.get(key)
-    if ent is None or ent[2].numel() < n_px:
+    if ent is None or ent[4] < n_px:
         cus = torch.cuda.get_device_properties(device).multi_processor_count
         G = 256
         while G > cus:
             G //= 2
         ws = torch.zeros(query("u2pl_reliability_fused_workspace_bytes", G) // 4, dtype=torch.int32, device=device)
-        cand = torch.empty(n_px, dtype=torch.float32, device=device)
-        ent = _RF_WS[key] = [G, ws, cand, 0]
+        cand = torch.empty(query("u2pl_reliability_fused_cand_floats", n_px, G), dtype=torch.float32, device=device)
+        ent = _RF_WS[key] = [G, ws, cand, 0, n_px]
     return ent
+
+
+RF_FLAGS = int(os.environ.get("U2PL_RF_FENCES", "0")) & 1     # bit 0: fence pair around the split's barrier (csrc/relfused.hip)
+
+
+def split_route_stats():
+    """(launches, launches that needed the second device-wide barrier) of the persistent split on every workspace of this
+    process (device-to-host read: call it outside the timed region)"""
+    tot = big = 0
+    for slot in _RF_WS.values():
+        w = slot[1][4:6].cpu()
+        tot, big = tot + int(w[0]), big + int(w[1])
+    return tot, big
 
 
 def reliability_split(logits_low, size, label_l, label_u_aug, out_hw, percents, negative_high_entropy=True, ignore=255,
@@ -214,6 +229,10 @@ def reliability_split(logits_low, size, label_l, label_u_aug, out_hw, percents, 
             low = high = lbits = None
         return dict(entropy=ent, thr=thr, target_u=target, low_mask=low, high_mask=high, lbits=lbits)
     _chk_cuda(logits_low, label_l, label_u_aug)
+    if _lib.SIDE_WORK:
+        # the device-wide barrier needs all G blocks resident: every side stream of this process must have been joined
+        # (stream order then guarantees that none of its kernels can still occupy a CU when this one starts)
+        raise _lib.HipError("u2pl_reliability_fused launched with un-joined side-stream work: %s" % sorted(_lib.SIDE_WORK))
     q32 = np.array([percentile_q32(p) for p in percents], dtype=np.float32)
     ent = torch.empty((B, H, W), dtype=torch.float32, device=dev)
     target = torch.empty((B, H, W), dtype=torch.int64, device=dev)
@@ -224,7 +243,7 @@ def reliability_split(logits_low, size, label_l, label_u_aug, out_hw, percents, 
         lbits = torch.empty((2 * B, hm, wm), dtype=torch.int32, device=dev)
     call("u2pl_reliability_fused", _f32c(logits_low), *_strides_nchw(logits_low), B, C, h, w, H, W, label_u_aug.contiguous(),
          label_l.contiguous(), int(ignore), nspec, q32.ctypes.data, int(bool(negative_high_entropy)), hm, wm, ent, target,
-         low, high, lbits, ws, cand, G, slot[3] & 0x3FFFFFF)
+         low, high, lbits, ws, cand, G, slot[3] & 0x3FFFFFF, RF_FLAGS)
     slot[3] += 1
     return dict(entropy=ent, thr=ws[16:16 + nspec].view(torch.float32), target_u=target, low_mask=low, high_mask=high,
                 lbits=lbits, nkept=ws[2:3], err=ws[3:4])
@@ -477,22 +496,30 @@ def contra_phase1(rep_teacher_rows, ld, D, prob, prob_strides, lbits, low_mask, 
     abits = torch.empty(P, dtype=torch.int32, device=dev)
     lowbits = torch.empty(P, dtype=torch.int32, device=dev)
     nbits = torch.empty(P, dtype=torch.int32, device=dev)
-    work = torch.empty(query("u2pl_compact_workspace_bytes", P), dtype=torch.uint8, device=dev)
-    call("u2pl_contra_classify", prob, *prob_strides, lbits, low_mask, high_mask, N2, num_labeled, C, h, w,
-         float(cfg["current_class_threshold"]), float(cfg["current_class_negative_threshold"]),
-         int(cfg["low_rank"]), int(cfg["high_rank"]), abits, lowbits, nbits, work)
     out = ContraPhase1()
     out.cap = P
     out.idx = torch.empty((3, MAXC, P), dtype=torch.int32, device=dev)
     out.counts = torch.empty((3, MAXC), dtype=torch.int32, device=dev)
-    call("u2pl_compact_lists", abits, lowbits, nbits, P, C, work, out.idx, P, out.counts, 1)
-    pw = torch.empty(query("u2pl_proto_workspace_bytes", P, C, D), dtype=torch.uint8, device=dev)
     out.proto = torch.empty((C, D), dtype=torch.float32, device=dev)
-    call("u2pl_class_prototypes", rep_teacher_rows, ld, D, out.idx, P, out.counts, C, P, pw, out.proto, lowbits)
+    args = (float(cfg["current_class_threshold"]), float(cfg["current_class_negative_threshold"]), int(cfg["low_rank"]),
+            int(cfg["high_rank"]))
+    if PHASE1_FUSED and C in (19, 21, 32) and D % 4 == 0 and D <= 256:
+        # three launches: classify, prototype streaming, merged tail (compaction write + list lengths || prototype finish)
+        work = torch.empty(query("u2pl_contra_phase1_workspace_bytes", P, C, D), dtype=torch.uint8, device=dev)
+        call("u2pl_contra_phase1", prob, *prob_strides, lbits, low_mask, high_mask, N2, num_labeled, C, h, w, *args,
+             rep_teacher_rows, ld, D, abits, lowbits, nbits, out.idx, P, out.counts, out.proto, work)
+    else:
+        work = torch.empty(query("u2pl_compact_workspace_bytes", P), dtype=torch.uint8, device=dev)
+        call("u2pl_contra_classify", prob, *prob_strides, lbits, low_mask, high_mask, N2, num_labeled, C, h, w, *args, abits,
+             lowbits, nbits, work)
+        call("u2pl_compact_lists", abits, lowbits, nbits, P, C, work, out.idx, P, out.counts, 1)
+        pw = torch.empty(query("u2pl_proto_workspace_bytes", P, C, D), dtype=torch.uint8, device=dev)
+        call("u2pl_class_prototypes", rep_teacher_rows, ld, D, out.idx, P, out.counts, C, P, pw, out.proto, lowbits)
     out.counts_host = None
     return out
 
 
+PHASE1_FUSED = os.environ.get("U2PL_PHASE1_UNFUSED") is None     # False: the five-launch sequence (kept as the cross-check)
 _NCE_STATE = {}
 
 

@@ -74,6 +74,7 @@ def wgrad_stream_sync():
     _WGRAD["queued"] = False
     if _WGRAD["stream"] is not None:
         torch.cuda.current_stream().wait_stream(_WGRAD["stream"])
+    _lib.SIDE_WORK.discard("wgrad")
 
 
 def _queue_wgrad_join():
@@ -237,6 +238,7 @@ class _ConvFn(torch.autograd.Function):
         side = _wgrad_stream() if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) else None
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
+            _lib.SIDE_WORK.add("wgrad")
             for t_ in (gy, x, col):
                 if t_ is not None:
                     t_.record_stream(side)
@@ -799,6 +801,7 @@ class ParamArena:
                 if st != cur:
                     cur.wait_stream(st)
         self._works[b] = dist.all_reduce(self.grad[lo:hi], async_op=True)
+        _lib.SIDE_WORK.add("buckets")
         COMM_STATS["bucket_allreduce"] += 1
 
     def mark_ready(self, pidx):
@@ -825,6 +828,7 @@ class ParamArena:
             self._next -= 1
         for w in self._works:
             w.wait()
+        _lib.SIDE_WORK.discard("buckets")
 
     def sgd_step(self, lrs, momentum, weight_decay, grad_scale=1.0):
         """torch.optim.SGD(momentum, weight_decay) semantics with per-group lr."""

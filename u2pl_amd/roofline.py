@@ -43,11 +43,12 @@ def profile_step(step_fn):
         _lib.PROFILE = None
     agg, shapes = {}, {}
     agg["_dense"] = replay_dense(rec)
-    for name, args, e0, e1 in [r[:4] for r in rec]:
-        d = agg.setdefault(name, dict(ms=0.0, calls=0, flops=0.0))
+    for name, args, e0, e1, nk in [r[:4] + (r[7],) for r in rec]:
+        d = agg.setdefault(name, dict(ms=0.0, calls=0, flops=0.0, kernels=0))
         ms = e0.elapsed_time(e1)
         d["ms"] += ms
         d["calls"] += 1
+        d["kernels"] += nk
         if name == "u2pl_wgrad_batched_f32":
             d["flops"] += _conv_flops(name, args)
         elif name == "u2pl_gemm_batched_f32":
@@ -148,6 +149,28 @@ def replay_hbm_group(reps=10):
     return out
 
 
+def split_phase_table():
+    """mean time of block 0 in every phase of the persistent reliability split over all launches of this process (stamps
+    the kernel keeps in its workspace: csrc/relfused.hip), microseconds"""
+    from . import hipops as H
+    names = [(10, "A_entropy_hist"), (11, "P_scan_prefix_totals"), (12, "P_counting_sort"), (13, "P_run_stores"), (1, "P_drain"),
+             (2, "barrier"), (14, "C_totals_scan"), (15, "C_ranks_bins_lists"), (16, "G_prefix_pairs"), (17, "G_block_prefix"),
+             (3, "G_members"), (8, "D_sync"), (9, "D_select"), (5, "D_thresholds"), (6, "apply"), (7, "end")]
+    out = {}
+    for slot in H._RF_WS.values():
+        acc = slot[1][7168:7200].cpu().numpy().astype("int64")
+        if acc[31] <= 0:
+            continue
+        prev = 0.0
+        for k, nm in names:
+            cur = acc[k] / acc[31]
+            out[nm] = round((cur - prev) / 100.0, 2)
+            prev = cur
+        out["launches"] = int(acc[31])
+        break
+    return out
+
+
 def hbm_algorithmic_bytes(B, C, H, W, h, w, D, stats):
     """entropy+reliability 4C+24 B/pixel + low-res outputs; contrastive with
     the Q0 skip (only images {0,B} referenced) from the measured counts."""
@@ -187,12 +210,14 @@ def measure(trainer, batch, args, ms_per_step):
     ig = [x for x in ig if x]
     if ig:
         fl, t_ev, n = sum(x["flops"] for x in ig), sum(x["ms"] for x in ig), sum(x["calls"] for x in ig)
+        nker = sum(x["kernels"] for x in ig)
         t = dense.get("igemm", t_ev)      # sustained-load time (dense replay); the gapped per-call events read shorter
         ach = fl / (t * 1e-3) / 1e12
         out["roofline"] = {"kernel": "k_conv_igemm (direct conv fwd [+BN-stat / eval-BN epilogue] + dgrad, and the batched Winograd component GEMMs; fp32 MFMA, executed FLOPs)", "bound": "mfma",
                            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                           "launches_per_step": n, "avg_launch_ms": round(t / n, 4),
+                           "abi_calls_per_step": n, "kernel_launches_per_step": nker, "avg_launch_ms": round(t / max(nker, 1), 4),
+                           "avg_abi_call_ms": round(t / n, 4),
                            "executed_tflop_per_step": round(fl / 1e12, 3), "ms_per_step": round(t, 2),
                            "ms_per_step_gapped_events": round(t_ev, 2),
                            "method": "all launches of the group re-issued back to back behind a spinning kernel, one HIP-event "
@@ -217,19 +242,22 @@ def measure(trainer, batch, args, ms_per_step):
         ach = fl / (t * 1e-3) / 1e12
         out["roofline_bf16"] = {"kernel": "k_conv_igemm<BF> / k_conv_wgrad_bf16 (student fwd + dgrad + wgrad, bf16 operands, fp32 accumulate)",
                                 "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None, "launches_per_step": n,
+                                "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None, "abi_calls_per_step": n,
+                                "kernel_launches_per_step": sum(x["kernels"] for x in bfs),
                                 "ms_per_step": round(t, 2), "executed_tflop_per_step": round(fl / 1e12, 3),
                                 "note": "fp32 activations / weights are read from HBM and rounded on the way into LDS: these "
                                         "launches are HBM / LDS bound long before the 2.5 PFLOP/s matrix-core peak"}
     wgs = [x for x in (agg.get("u2pl_conv2d_wgrad_f32"), agg.get("u2pl_wgrad_batched_f32")) if x]
-    wg = dict(flops=sum(x["flops"] for x in wgs), ms=sum(x["ms"] for x in wgs), calls=sum(x["calls"] for x in wgs)) if wgs else None
+    wg = dict(flops=sum(x["flops"] for x in wgs), ms=sum(x["ms"] for x in wgs), calls=sum(x["calls"] for x in wgs),
+              kernels=sum(x["kernels"] for x in wgs)) if wgs else None
     if wg:
         wg["ms"] = dense.get("wgrad", wg["ms"])
         ach = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
         out["roofline_wgrad"] = {"kernel": "k_conv_wgrad (direct, + ordered slab reduce; and the batched Winograd component products; executed FLOPs)", "bound": "mfma",
                                  "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                  "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                                 "launches_per_step": wg["calls"], "ms_per_step": round(wg["ms"], 2)}
+                                 "abi_calls_per_step": wg["calls"], "kernel_launches_per_step": wg["kernels"],
+                                 "ms_per_step": round(wg["ms"], 2)}
     B, H, W = ll.shape
     C = trainer.num_classes
     h, w = (H - 1) // 4 + 1, (W - 1) // 4 + 1
@@ -253,23 +281,29 @@ def measure(trainer, batch, args, ms_per_step):
                                "algorithmic_MB": round((rel_b + con_b) / 1e6, 1), "reliability_us": round(t_rel * 1e3, 1),
                                "contrastive_us": round(t_con * 1e3, 1), "stats": dict(LH.LAST_STATS),
                                "stages_us": {k: round(v, 1) for k, v in replay.items()},
-                               "per_call_event_us": per_call,
+                               "per_call_event_us": per_call, "split_phases_us_block0": split_phase_table(),
                                "method": "each stage re-issued 10x on the last step's tensors behind a spinning kernel, one "
                                          "HIP-event pair per stage (per-call event pairs, kept in per_call_event_us, add "
                                          "~20 us of marker packets to 5-30 us kernels)"}
     # HBM traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections) cannot be collected from
     # inside this process: the value below is a STATIC record of the PMC passes committed under profiles/ (with the
     # commit they were taken at), not a measurement of this run
-    tj = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_traffic.json")
+    import glob
+    pdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    tjs = sorted(glob.glob(os.path.join(pdir, "r[0-9][0-9]_traffic.json")))
+    tj = tjs[-1] if tjs else ""
     if os.path.exists(tj) and "roofline" in out:
         import json
         tr = json.load(open(tj))
         out["roofline"]["traffic"] = tr.get("k_conv_igemm_bytes_per_launch")
-        out["roofline"]["traffic_source"] = "static: profiles/r02_traffic.json (rocprofv3 PMC passes at commit %s), not measured in this run" % tr.get("commit", "?")
+        out["roofline"]["traffic_source"] = "static: profiles/%s (rocprofv3 PMC passes at commit %s), not measured in this run" % (
+            os.path.basename(tj), tr.get("commit", "?"))
         if "roofline_hbm" in out and tr.get("hbm_group_bytes_per_step") is not None:
             out["roofline_hbm"]["traffic"] = tr["hbm_group_bytes_per_step"]
             out["roofline_hbm"]["traffic_source"] = out["roofline"]["traffic_source"]
     top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]
+    out["abi_calls_per_step"] = sum(v["calls"] for v in agg.values())
+    out["kernel_launches_per_step"] = sum(v["kernels"] for v in agg.values())
     out["kernel_ms_per_step"] = {k: round(v["ms"], 2) for k, v in top}
     out["kernel_ms_total_profiled"] = round(sum(v["ms"] for v in agg.values()), 2)
     return out

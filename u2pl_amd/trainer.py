@@ -224,6 +224,8 @@ class SemiTrainer:
             main = torch.cuda.current_stream()
             side = self._side_stream()
             side.wait_stream(main)
+            if side is not main:
+                K._lib.SIDE_WORK.add("teacher")
             # Both teacher passes run on a SIDE HIP stream, concurrently with the student forward (they do not
             # depend on it): their memory-bound BN passes and kernel tails fill the bubbles of the student's
             # MFMA-bound convs.  Results and RNG draw order are unchanged.
@@ -283,6 +285,7 @@ class SemiTrainer:
             else:
                 sup_loss = self.sup_loss_fn(pred_l_large, label_l.clone())
             main.wait_stream(side)
+            K._lib.SIDE_WORK.discard("teacher")
             if side is not main:
                 for t_ in (pred_all_t, rep_all_t, prob_all_t, label_u_aug, conf_u):
                     t_.record_stream(main)   # allocated on the side stream, consumed on the main stream

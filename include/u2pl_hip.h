@@ -123,6 +123,13 @@ size_t u2pl_infonce_job_bytes(void);
 int u2pl_infonce_f32(const void* jobs_dev, int njobs, const float* rep, long ld, int D, int Q, int K,
                      float temp, float* loss_q, float* ganchor, int* anchor_pix, int* head, int* next,
                      const int* seg_len, hipStream_t stream);
+/* u2pl_infonce_f32 + u2pl_infonce_reduce_f32 (+ u2pl_zero_rows_f32 of the rows the previous step's backward wrote: zero_*)
+ * in ONE launch.  workspace: u2pl_infonce_fused_workspace_bytes bytes, zeroed once by the caller and reused.  Q % 4 == 0. */
+size_t u2pl_infonce_fused_workspace_bytes(int njobs, int Q);
+int u2pl_infonce_fused_f32(const void* jobs_dev, int njobs, const float* rep, long ld, int D, int Q, int K, float temp,
+                           float* loss_q, float* ganchor, int* anchor_pix, int* head, int* next, const int* seg_len,
+                           float* zero_dst, long zero_ld, const int* zero_pix, long zero_n, void* workspace,
+                           float inv_valid_seg, float* loss, hipStream_t stream);
 int u2pl_infonce_reduce_f32(const float* loss_q, int njobs, int Q, float inv_valid_seg, float* loss,
                             hipStream_t stream);
 /* d loss / d rep (loss_helper.py:205-230 backward) without a dense zero fill and without float atomics: dst is a

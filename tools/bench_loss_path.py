@@ -78,7 +78,7 @@ def main():
     res["ce_fwd_bwd_us"] = timeit(ce)
     crit = LH.CriterionOhem(0.0, thresh=0.7, min_kept=100000)
     res["ohem_fwd_bwd_us"] = timeit(lambda: crit(pred, label_l).backward())
-    prob = torch.softmax(low, 1)
+    prob = torch.softmax(low, 1).contiguous(memory_format=torch.channels_last)      # (the trainer's probabilities are channels-last rows)
     bank = H.DeviceMemoryBank(C, [50000] + [30000] * (C - 1), D, DEV)
     for c in range(C):
         bank.load_logical(c, torch.randn(bank.cap[c], D, device=DEV, generator=g))

@@ -114,24 +114,23 @@ __global__ __launch_bounds__(CP_PIX) void k_contra_classify_rows(
         const long n = p / hw;
         unsigned a = 0, l = 0, ng = 0;
         if (lb != 0) {
+            // only the classes in the pixel's label bits (1-2 of C) need a rank: a loop over the SET bits with the row read
+            // from LDS, instead of C unrolled rank computations that a wave executes whenever any of its lanes has the bit
             const float* b = rows + threadIdx.x * C;
-            float pr[MAXC];
-#pragma unroll
-            for (int j = 0; j < MAXC; ++j) pr[j] = j < C ? b[j] : -1.f;
-#pragma unroll
-            for (int i = 0; i < MAXC; ++i) {
-                const bool has = (i < C) && ((lb >> i) & 1u);
-                if (!has) continue;
-                const float pi = pr[i];
+            for (unsigned x = lb & ((C < 32 ? (1u << C) : 0u) - 1u); x; x &= x - 1u) {
+                const int i = __ffs(x) - 1;
+                const float pi = b[i];
                 int rank = 0;
-#pragma unroll
-                for (int j = 0; j < MAXC; ++j) rank += (pr[j] > pi) || (pr[j] == pi && j < i);
-                bool cmask = n < num_labeled ? (rank < low_rank && !has) : (rank >= low_rank && rank < high_rank);
-                if (has && lo) {
+                for (int j = 0; j < C; ++j) {
+                    const float pj = b[j];
+                    rank += (pj > pi) || (pj == pi && j < i);
+                }
+                const bool cmask = n < num_labeled ? false : (rank >= low_rank && rank < high_rank);    // (labeled: rank < low_rank && !has == false)
+                if (lo) {
                     l |= 1u << i;
                     if (pi > thr_p) a |= 1u << i;
                 }
-                if (has && hi && pi < thr_n && cmask) ng |= 1u << i;
+                if (hi && pi < thr_n && cmask) ng |= 1u << i;
             }
         }
         abits[p] = a;
@@ -292,8 +291,16 @@ __global__ __launch_bounds__(CP_PIX) void k_compact_write(const unsigned* __rest
 // ---------------------------------------------------------------------------
 #define P1_T 1024
 __device__ __forceinline__ unsigned p1_row_sum(const unsigned* __restrict__ row, int n, int lane) {   // one wave: sum of row[0..n)
+    // 16 independent loads in flight per lane (a plain `acc += row[i]` loop is issued one load per round trip: ten serial
+    // L2 latencies for the 583 count rows of a 769^2 step)
     unsigned acc = 0;
-    for (int i = lane; i < n; i += 64) acc += row[i];
+    for (int i0 = 0; i0 < n; i0 += 16 * 64) {
+        unsigned v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int i = i0 + u * 64 + lane; v[u] = i < n ? row[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+    }
     return wave_sum_u(acc);
 }
 __global__ __launch_bounds__(P1_T) void k_phase1_tail(const unsigned* __restrict__ b0, const unsigned* __restrict__ b2, long P,
@@ -457,19 +464,20 @@ U2PL_API int u2pl_compact_lists(const unsigned* abits, const unsigned* lowbits, 
 // are combined through LDS in a fixed order => deterministic.  Blocks without members only write flag 0.
 // Then an ordered double-precision finish over the flagged blocks.
 // ---------------------------------------------------------------------------
-#define PR_BLOCKS 512
+#define PR_BLOCKS 256          // x PR_WPB waves: one 8-wave block per CU (the register file admits two waves per SIMD either way;
+#define PR_WPB 8               // eight waves per block halve the number -- and the bytes -- of the block partials the finish reads)
 template <int CT>
-__global__ __launch_bounds__(256, 2) void k_proto_stream(const float* __restrict__ rows, long ld, int D,
+__global__ __launch_bounds__(64 * PR_WPB, 2) void k_proto_stream(const float* __restrict__ rows, long ld, int D,
                                                          const unsigned* __restrict__ lowbits, long P,
                                                          float* __restrict__ partial, unsigned* __restrict__ flags,
                                                          unsigned rows_bytes) {
-    extern __shared__ float red[];   // [4][CT][D]
+    extern __shared__ float red[];   // [4][CT][D]: waves 4..7 hand their sums to waves 0..3, whose four sums are then combined
     __shared__ int any_s;
     // (readfirstlane: the wave index is uniform, which keeps every row base in scalar registers -- a row load is then
     // "scalar base + per-lane offset" and needs no address VGPRs that could alias a load still in flight)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long NW = (long)gridDim.x * 4;                 // waves of the launch (host: P <= 128 * NW)
-    const long W = (long)blockIdx.x * 4 + wave;          // this wave streams pixels W + NW * j, j = 0 .. 127
+    const long NW = (long)gridDim.x * PR_WPB;            // waves of the launch (host: P <= 128 * NW)
+    const long W = (long)blockIdx.x * PR_WPB + wave;     // this wave streams pixels W + NW * j, j = 0 .. 127
     const long pa = W + NW * lane, pb = W + NW * (64 + lane);   // lane j holds the class bits of pixels j and 64 + j
     const unsigned bits0 = pa < P ? lowbits[pa] : 0u;
     const unsigned bits1 = pb < P ? lowbits[pb] : 0u;
@@ -532,7 +540,20 @@ __global__ __launch_bounds__(256, 2) void k_proto_stream(const float* __restrict
     }
 #undef PROTO_FETCH
 #undef PROTO_ACC
-    if (act) {
+    if (act && wave >= 4) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) *(float4*)(red + ((long)(wave - 4) * CT + c) * D + d) = acc[c];
+    }
+    __syncthreads();
+    if (act && wave < 4) {      // fixed order: (wave w) + (wave w + 4), then the four-way combine below
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const float4 o = *(const float4*)(red + ((long)wave * CT + c) * D + d);
+            acc[c].x += o.x; acc[c].y += o.y; acc[c].z += o.z; acc[c].w += o.w;
+        }
+    }
+    __syncthreads();
+    if (act && wave < 4) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) *(float4*)(red + ((long)wave * CT + c) * D + d) = acc[c];
     }
@@ -599,7 +620,7 @@ __global__ __launch_bounds__(1024) void k_proto_finish(const float* __restrict__
 }
 
 static int proto_blocks(long P) {   // fixed one-round grid; grows only so that a wave never owns more than 128 pixels
-    const long need = (P + 511) / 512;
+    const long need = (P + 128 * PR_WPB - 1) / (128 * PR_WPB);
     return (int)(need > PR_BLOCKS ? need : PR_BLOCKS);
 }
 U2PL_API size_t u2pl_proto_workspace_bytes(long P, int C, int D) {
@@ -621,7 +642,7 @@ U2PL_API int u2pl_class_prototypes(const float* rows, long ld, int D, const int*
     case CT: {                                                                                                   \
         static bool set_##CT = false;                                                                            \
         if (!set_##CT) { (void)hipFuncSetAttribute((const void*)k_proto_stream<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * CT * 256 * 4)); set_##CT = true; } \
-        U2PL_LAUNCH(k_proto_stream<CT>, dim3(nblk), dim3(256), lds, stream, rows, ld, D, lowbits, P, partial, flags, (unsigned)rb); \
+        U2PL_LAUNCH(k_proto_stream<CT>, dim3(nblk), dim3(64 * PR_WPB), lds, stream, rows, ld, D, lowbits, P, partial, flags, (unsigned)rb); \
     } break;
     switch (C) {
         PROTO_CASE(19) PROTO_CASE(21) PROTO_CASE(32)
@@ -662,7 +683,7 @@ U2PL_API int u2pl_contra_phase1(const float* prob, long sn, long sc, long sp, co
     case CT: {                                                                                                   \
         static bool set_##CT = false;                                                                            \
         if (!set_##CT) { (void)hipFuncSetAttribute((const void*)k_proto_stream<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * CT * 256 * 4)); set_##CT = true; } \
-        U2PL_LAUNCH(k_proto_stream<CT>, dim3(npb), dim3(256), lds, stream, rows, ld, D, lowbits, P, partial, flags, (unsigned)rb); \
+        U2PL_LAUNCH(k_proto_stream<CT>, dim3(npb), dim3(64 * PR_WPB), lds, stream, rows, ld, D, lowbits, P, partial, flags, (unsigned)rb); \
     } break;
     switch (C) {
         P1_PROTO(19) P1_PROTO(21) P1_PROTO(32)
@@ -729,11 +750,14 @@ __global__ void k_bank_append_multi(const long long* __restrict__ desc, int D, l
     const long skip = n_new > cap ? n_new - cap : 0;
     const int D4 = D >> 2;
     const long total = (n_new - skip) * D4;
+    // (the grid covers every float4 of the largest class in ONE pass: index load -> row load -> store is two dependent
+    // round trips per element, a grid-stride loop of 3-4 elements per thread made it seven)
     for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const long j = skip + t / D4;
         const int dd = (int)(t % D4);
         const long src = list ? (long)list[j] : j;
-        const long slot = (tail + j) % cap;
+        long slot = tail + j;                 // tail < cap, j < n_new: at most a few wraps (one unless n_new > cap)
+        slot = slot >= cap ? slot % cap : slot;
         ((float4*)bank)[slot * D4 + dd] = *(const float4*)(rows + src * ld + 4 * dd);
     }
 }
@@ -741,7 +765,7 @@ U2PL_API int u2pl_bank_append_multi_f32(const long long* desc_dev, int nclass, i
                                         hipStream_t stream) {
     if (D % 4) return U2PL_EINVAL;
     if (nclass <= 0 || max_new <= 0) return 0;
-    dim3 grid(grid_for(max_new * (D / 4), 256, 64), nclass);
+    dim3 grid(grid_for(max_new * (D / 4), 256, 2048), nclass);
     U2PL_LAUNCH(k_bank_append_multi, grid, dim3(256), 0, stream, desc_dev, D, ld);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -784,15 +808,37 @@ struct NceJob {
 // so far is carried across the four-row batches and the accumulators are rescaled when it grows (one more exp and
 // three more multiplies per batch).
 #define NCE_FIXED_SHIFT_MAX 80.0f
+// Work folded into the InfoNCE launch (u2pl_infonce_fused_f32; all pointers NULL: plain u2pl_infonce_f32):
+//   zero_*: the rows of the persistent row-sparse gradient buffer that the PREVIOUS step's backward wrote are cleared
+//     here, one row per wave at the top of the kernel (their consumer finished a step ago) -- instead of a launch of
+//     u2pl_zero_rows_f32 in front of the ordered scatter;
+//   partial / ticket / loss: the loss reduction (u2pl_infonce_reduce_f32) in the same launch: every block publishes the
+//     sum of its four anchors (write-through store), takes a ticket (32 shards, then one top counter: ~40 same-address
+//     atomics in a row instead of 1216), and the block that completes the top counter adds the 1216 partials in a fixed
+//     order (bit-reproducible) and writes the loss.  The counters are left at zero for the next launch.
+struct NceExtra {
+    float* zero_dst; long zero_ld; const int* zero_pix; long zero_n;
+    float* partial; unsigned* ticket; float* loss; double scale;
+};
+__device__ __forceinline__ void nce_ld4(const float* p0, const float* p1, const float* p2, const float* p3, float (&v)[4]) {
+    // four independent loads past the L1 (sc1), waited for once (chains of atomic loads are issued two per round trip)
+    asm volatile("global_load_dword %0, %4, off sc1\n\tglobal_load_dword %1, %5, off sc1\n\t"
+                 "global_load_dword %2, %6, off sc1\n\tglobal_load_dword %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+}
 template <int VPL, bool PRE, bool ONLINE = false>  // floats per lane = D / 64
 __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restrict__ rep, long ld, int D,
                           int Q, int K, float inv_temp, float* __restrict__ loss_q,
                           float* __restrict__ ganchor, int* __restrict__ anchor_pix, int* __restrict__ head,
-                          int* __restrict__ next, const int* __restrict__ seg_len) {
+                          int* __restrict__ next, const int* __restrict__ seg_len, NceExtra X) {
     const int job = blockIdx.y;
     const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (q >= Q) return;
+    // (the index of the stale row this wave clears is requested now and used at the very end: off the critical path)
+    const long zw = ((long)job * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int zpix = -1;
+    if (X.zero_dst && zw < X.zero_n) zpix = ldg(X.zero_pix + zw);
+    if (q >= Q) return;      // (never taken on the fused path: the host requires Q % 4 == 0 there)
     const NceJob J = jobs[job];
     // Two dependent address chains start here: anchor = rep[cand[idx_a[q]]] (three loads deep) and the sampled bank rows
     // bank[slot(idx_n[q][j])] (two deep).  Both index loads are issued back to back, and the first four feature rows are
@@ -914,6 +960,48 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
         process4(fb, j0 + 4);
     }
     const float lse = shift + logf(s);
+    if (X.partial) {
+        __shared__ float sl[4];
+        __shared__ unsigned s_last;
+        if (lane == 0) sl[threadIdx.x >> 6] = lse - l0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned gb = (unsigned)job * gridDim.x + blockIdx.x, nb = gridDim.x * gridDim.y;
+            __hip_atomic_store(X.partial + gb, (sl[0] + sl[1]) + (sl[2] + sl[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // written through before the ticket
+            const unsigned sh = gb & 31u, nsh = (nb - sh + 31u) / 32u, nshards = nb < 32u ? nb : 32u;
+            unsigned last = 0;
+            if (atomicAdd(X.ticket + 1 + sh, 1u) == nsh - 1u) {
+                __hip_atomic_store(X.ticket + 1 + sh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (atomicAdd(X.ticket, 1u) == nshards - 1u) {
+                    __hip_atomic_store(X.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last = 1;
+                }
+            }
+            s_last = last;
+        }
+        __syncthreads();
+        if (s_last) {      // every partial has been written through: add them in a fixed order
+            __shared__ double sred[256];
+            const int nb = gridDim.x * gridDim.y;
+            double acc = 0.0;
+            for (int i0 = 0; i0 < nb; i0 += 4 * 256) {
+                float v[4];
+                const int i = i0 + threadIdx.x;
+                nce_ld4(X.partial + min(i, nb - 1), X.partial + min(i + 256, nb - 1), X.partial + min(i + 512, nb - 1),
+                        X.partial + min(i + 768, nb - 1), v);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc += i + 256 * u < nb ? (double)v[u] : 0.0;
+            }
+            sred[threadIdx.x] = acc;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if ((int)threadIdx.x < o) sred[threadIdx.x] += sred[threadIdx.x + o];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) *X.loss = (float)(sred[0] * X.scale);
+        }
+    }
     if (lane == 0) {
         const int e = job * Q + q;
         loss_q[e] = lse - l0;
@@ -931,11 +1019,44 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
 #pragma unroll
     for (int i = 0; i < VPL; ++i)
         g[i] = inv_temp * ((acc[i] * inv_s - f0h[i]) - cosbar * ah[i]) * na;
+    if (X.zero_dst) {      // stale gradient rows of the previous step: one 1 KiB row per wave (D <= 256: 16 bytes per lane)
+        const long nw = (long)gridDim.x * gridDim.y * (blockDim.x >> 6);
+        if (zpix >= 0 && lane * 4 < D) *(float4*)(X.zero_dst + (long)zpix * X.zero_ld + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (long r = zw + nw; r < X.zero_n; r += nw)       // (more stale rows than waves: only when the previous step had more jobs)
+            if (lane * 4 < D) *(float4*)(X.zero_dst + (long)X.zero_pix[r] * X.zero_ld + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
+static int nce_launch(const void* jobs_dev, int njobs, const float* rep, long ld, int D, int Q, int K, float temp,
+                      float* loss_q, float* ganchor, int* anchor_pix, int* head, int* next, const int* seg_len, NceExtra X,
+                      hipStream_t stream);
 U2PL_API int u2pl_infonce_f32(const void* jobs_dev, int njobs, const float* rep, long ld, int D, int Q, int K,
                               float temp, float* loss_q, float* ganchor, int* anchor_pix, int* head, int* next,
                               const int* seg_len, hipStream_t stream) {
+    NceExtra X = {};
+    return nce_launch(jobs_dev, njobs, rep, ld, D, Q, K, temp, loss_q, ganchor, anchor_pix, head, next, seg_len, X, stream);
+}
+// u2pl_infonce_f32 + u2pl_infonce_reduce_f32 + (optionally) u2pl_zero_rows_f32 of the previous step's rows in ONE launch.
+// workspace: u2pl_infonce_fused_workspace_bytes(njobs, Q) bytes, zeroed ONCE by the caller and reused (the kernel leaves
+// its ticket counters at zero).  zero_dst == NULL or zero_n == 0: nothing to clear.  Q % 4 != 0 -> U2PL_EINVAL (use the
+// separate entry points).  *loss = sum of all per-anchor losses * inv_valid_seg / Q (loss_helper.py:228-233).
+U2PL_API size_t u2pl_infonce_fused_workspace_bytes(int njobs, int Q) { return ((size_t)njobs * (Q / 4 + 1) + 64) * sizeof(float); }
+U2PL_API int u2pl_infonce_fused_f32(const void* jobs_dev, int njobs, const float* rep, long ld, int D, int Q, int K,
+                                    float temp, float* loss_q, float* ganchor, int* anchor_pix, int* head, int* next,
+                                    const int* seg_len, float* zero_dst, long zero_ld, const int* zero_pix, long zero_n,
+                                    void* workspace, float inv_valid_seg, float* loss, hipStream_t stream) {
+    if (Q % 4 || !workspace || !loss || D > 256) return U2PL_EINVAL;
+    NceExtra X = {};
+    if (zero_dst && zero_pix && zero_n > 0) { X.zero_dst = zero_dst; X.zero_ld = zero_ld; X.zero_pix = zero_pix; X.zero_n = zero_n; }
+    X.ticket = (unsigned*)workspace;                  // [0] top counter, [1..32] shard counters
+    X.partial = (float*)workspace + 64;
+    X.loss = loss;
+    X.scale = (double)inv_valid_seg / (double)Q;
+    return nce_launch(jobs_dev, njobs, rep, ld, D, Q, K, temp, loss_q, ganchor, anchor_pix, head, next, seg_len, X, stream);
+}
+static int nce_launch(const void* jobs_dev, int njobs, const float* rep, long ld, int D, int Q, int K, float temp,
+                      float* loss_q, float* ganchor, int* anchor_pix, int* head, int* next, const int* seg_len, NceExtra X,
+                      hipStream_t stream) {
     if (head && (!next || !seg_len)) return U2PL_EINVAL;
     if (njobs <= 0) return 0;
     dim3 grid(cdiv(Q, 4), njobs), block(256);
@@ -943,7 +1064,7 @@ U2PL_API int u2pl_infonce_f32(const void* jobs_dev, int njobs, const float* rep,
     const float it = 1.0f / temp;
     if (!(temp > 0.f)) return U2PL_EINVAL;
     const bool online = 2.0f * it > NCE_FIXED_SHIFT_MAX;      // see k_infonce: the fixed shift would underflow
-#define NCE_ARGS grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next, seg_len
+#define NCE_ARGS grid, block, 0, stream, jobs, rep, ld, D, Q, K, it, loss_q, ganchor, anchor_pix, head, next, seg_len, X
 #define NCE_LAUNCH(V)                                                                    \
     if (online) {                                                                        \
         if (K <= 64) U2PL_LAUNCH((k_infonce<V, true, true>), NCE_ARGS);           \

@@ -94,6 +94,25 @@ __device__ __forceinline__ int rf_bin(float e, float scale) {
     return 1025 + (b < 1022 ? b : 1022);
 }
 
+// Key range of histogram bin b >= 1 (order-preserving keys of the non-negative floats of the bin): [*lo, *lo + 2^*nb).
+// Log-linear bins are exact ranges of bit patterns; the linear bins get conservative edges (2e-6 of slack on entropies
+// <= ln C: far below a bin's width, far above the rounding of rf_bin's subtract-multiply).  A key outside the returned
+// range is detected by the caller, which then takes the generic selection.
+__device__ __forceinline__ void rf_bin_key_range(unsigned b, float scale, unsigned& lo, unsigned& nb) {
+    if (b <= 1024u) {
+        lo = 0xB4800000u + ((b - 1u) << 17);
+        nb = 17;
+        return;
+    }
+    const float inv = 1.0f / scale;
+    const float j = (float)(b - 1025u);
+    const float e_lo = fmaxf(0.015625f + j * inv - 2e-6f, 0.0f);
+    const float e_hi = b >= 2047u ? 8.0f : 0.015625f + (j + 1.0f) * inv + 2e-6f;
+    lo = f32_key(e_lo);
+    const unsigned range = f32_key(e_hi) - lo;
+    nb = range ? 32u - (unsigned)__clz(range) : 1u;
+}
+
 // Device-wide barrier of a persistent launch whose blocks are all co-resident (gridDim.x <= #CUs, one block per CU).
 // The spin is bounded (~seconds): if some block could not become resident the kernel gives up loudly (error word set,
 // results undefined) instead of hanging the GPU.
@@ -171,12 +190,24 @@ __device__ __forceinline__ void rf_ld2x8(const unsigned* base, long stride, rf_u
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
                  : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7) : "memory");
 }
+__device__ __forceinline__ void rf_ld1x12(const unsigned* const (&p)[12], unsigned (&v)[12]) {
+    asm volatile("global_load_dword %0, %12, off sc1\n\tglobal_load_dword %1, %13, off sc1\n\t"
+                 "global_load_dword %2, %14, off sc1\n\tglobal_load_dword %3, %15, off sc1\n\t"
+                 "global_load_dword %4, %16, off sc1\n\tglobal_load_dword %5, %17, off sc1\n\t"
+                 "global_load_dword %6, %18, off sc1\n\tglobal_load_dword %7, %19, off sc1\n\t"
+                 "global_load_dword %8, %20, off sc1\n\tglobal_load_dword %9, %21, off sc1\n\t"
+                 "global_load_dword %10, %22, off sc1\n\tglobal_load_dword %11, %23, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+                   "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11])
+                 : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]), "v"(p[8]), "v"(p[9]),
+                   "v"(p[10]), "v"(p[11]) : "memory");
+}
 __device__ __forceinline__ void rf_st16(void* p, rf_u4 v) {      // (drained by rf_drain_stores() before the barrier)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");   // (s_nop: the data registers of a wide store must not be rewritten in the next slot)
 }
 __device__ __forceinline__ void rf_st8(void* p, unsigned lo, unsigned hi) {
     rf_u2 v; v[0] = lo; v[1] = hi;
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void rf_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 struct RfShared {
@@ -194,6 +225,10 @@ struct RfShared {
     int twin[RF_MAXSLOT];                // slot -> first slot with the same order statistic
     unsigned ncand;
     unsigned ptot[32];                   // gather: totals of the 64-pair groups (prefix over blocks of the per-list counts)
+    // selection fused with the gather: key range of every list (bin edges), first-digit results, the collected sub-buckets
+    unsigned lmn[RF_MAXSLOT], lnb[RF_MAXSLOT], lsh[RF_MAXSLOT];     // list: smallest key, key bits, first-digit shift
+    unsigned sd0[RF_MAXSLOT], sk1[RF_MAXSLOT], scount[RF_MAXSLOT];  // slot: first digit, rank inside it, collected keys
+    int bad;
 };
 
 // exclusive scan of the 2048-bin histogram: thread t owns bins 2t, 2t+1; returns the exclusive prefix of bin 2t
@@ -785,8 +820,7 @@ __global__ __launch_bounds__(RF_T, 1) void k_reliability_fused(RfArgs A) {
         for (int k = 0; k < 8; ++k) { h0 += q[k][0]; h1 += q[k][1]; }
     }
     if (b < 8) {   // the OTHER parity's totals belong to the previous launch, which has completed: clear them for the next one
-        rf_st8(ws + RFW_TOT + ((1 - (A.epoch & 1u)) * 8u + (unsigned)b) * RF_BINS + 2 * t, 0u, 0u);
-        rf_drain_stores();
+        rf_st8(ws + RFW_TOT + ((1 - (A.epoch & 1u)) * 8u + (unsigned)b) * RF_BINS + 2 * t, 0u, 0u);     // (completes by the end of the kernel)
     }
     const unsigned ex = rf_scan2048(S, h0, h1);           // (one block barrier inside; S.wsum = the 16 wave totals)
     unsigned nvalid = 0;
@@ -841,8 +875,19 @@ __global__ __launch_bounds__(RF_T, 1) void k_reliability_fused(RfArgs A) {
             if ((lm >> u) & 1ull) { total += cu; if (u < first) off += cu; }
         }
         if (sl < RF_MAXSLOT) { S.sdl[sl] = on ? dlist : 0; S.twin[sl] = twin; }
-        if (leader) { S.dbin[dlist] = mybin; S.doff[dlist] = off; S.dcnt[dlist] = mycnt; S.dblk[dlist] = 0; S.dbase[dlist] = 0; }
-        if (lane == 0) { S.nd = __popcll(lm); S.ncand = total; }
+        if (leader) {
+            S.dbin[dlist] = mybin; S.doff[dlist] = off; S.dcnt[dlist] = mycnt; S.dblk[dlist] = 0; S.dbase[dlist] = 0;
+            unsigned klo = 0, knb = 32;
+            if (mybin >= 1u) rf_bin_key_range(mybin, A.bin_scale, klo, knb);
+            S.lmn[dlist] = klo; S.lnb[dlist] = knb; S.lsh[dlist] = knb > 9u ? knb - 9u : 0u;
+        }
+        if (sl < RF_MAXSLOT) S.scount[sl] = 0;
+        if (lane == 0) {
+            S.nd = __popcll(lm); S.ncand = total;
+            // bin 0 (negative / denormal-small entropies: no bounded key range) or > 27 key bits: generic selection
+            S.bad = 0;
+        }
+        if (leader && (mybin == 0u || S.lnb[dlist] > 27u)) S.bad = 1;
     }
     __syncthreads();
     const int nd = S.nd;
@@ -850,6 +895,7 @@ __global__ __launch_bounds__(RF_T, 1) void k_reliability_fused(RfArgs A) {
     rf_stamp(ws, 15);
     const bool big = ncand > (unsigned)RF_CAP;      // the same totals everywhere: every block takes the same route
     unsigned* lkeys = (unsigned*)dyn;
+    bool done = false;               // the order statistics were selected by the form fused with the gather
     if (!big) {
         // ------------------------------------------------------------ G: the members of the selected bins, straight out of
         // the blocks' sorted runs.  Two prefix words per (list, block) give offset and count; a block-wide exclusive scan
@@ -858,6 +904,11 @@ __global__ __launch_bounds__(RF_T, 1) void k_reliability_fused(RfArgs A) {
         unsigned* offL = (unsigned*)dyn;                  // [RF_MAXSLOT][256] offset of bin X in block sb's run
         unsigned* pfxL = offL + RF_MAXSLOT * 256;         // [RF_MAXSLOT][256] exclusive prefix over blocks of the counts
         lkeys = pfxL + RF_MAXSLOT * 256;
+        unsigned* hist0 = lkeys + RF_CAP;                 // [RF_MAXSLOT][512] first-digit histogram of every list
+        unsigned* small = hist0 + RF_MAXSLOT * 512;       // [RF_MAXSLOT][512] keys of the sub-bucket that holds a slot's rank
+        unsigned* mark = small + RF_MAXSLOT * 512;        // [RF_MAXSLOT][512] slots that want the keys of a (list, first digit)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { hist0[t + i * RF_T] = 0u; mark[t + i * RF_T] = 0u; }
         const unsigned* slab0 = ws + RFW_SLAB;
         const int np = nd * G;
         const int pa = t, pb = t + RF_T;                   // nd * G <= 6 * 256: at most two pairs per thread
@@ -891,34 +942,118 @@ __global__ __launch_bounds__(RF_T, 1) void k_reliability_fused(RfArgs A) {
         }
         __syncthreads();
         rf_stamp(ws, 17);
-        for (unsigned base = 0; base < ncand; base += 8u * RF_T) {
-            const unsigned* ad[8];
-            unsigned val[8];
+        // member i of the flat candidate list = i-th element of the concatenated per-block segments.  Thread t takes the K
+        // CONSECUTIVE members [t K, t K + K) (K = ceil(ncand / 1024) <= 12): one binary search for the first of them, the
+        // others by walking the (list, block) segments forward -- every instruction here is executed by 16 waves, a search
+        // per member cost 4 us.  All (<= 12) loads of a thread are independent and go out in ONE waited batch; the keys
+        // stay in registers for the selection, which starts right here: every key adds its first digit (top 9 bits of its
+        // offset inside the bin's key range) to its list's histogram.
+        const unsigned* ad[12];
+        unsigned val[12], kd = 0;                          // kd: list index of key j, 3 bits each
+        const unsigned K = (ncand + RF_T - 1) / RF_T;
+        const unsigned i0 = (unsigned)t * K;
+        {
+            int d = 0, sb = 0;
+            unsigned r = 0, dn = 0, seg0 = 0, seg1 = 0;    // r: index inside list d (dn members); block sb holds [seg0, seg1)
+            auto seg_end = [&](int dd, int bb, unsigned n_) -> unsigned { return bb + 1 < G ? pfxL[dd * 256 + bb + 1] : n_; };
+            if (i0 < ncand) {
+                for (int dd = 1; dd < nd; ++dd) d = i0 >= S.doff[dd] ? dd : d;
+                r = i0 - S.doff[d]; dn = S.dcnt[d];
+                int lo = 0, hi = G;                        // largest block sb with prefix[sb] <= r (it has a member: r < prefix[sb + 1])
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (pfxL[d * 256 + mid] <= r) lo = mid; else hi = mid;
+                }
+                sb = lo; seg0 = pfxL[d * 256 + sb]; seg1 = seg_end(d, sb, dn);
+            }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned i = base + (unsigned)j * RF_T + t;
+            for (int j = 0; j < 12; ++j) {
                 ad[j] = (const unsigned*)A.cand;
-                if (i < ncand) {
-                    int d = 0;
-                    for (int dd = 1; dd < nd; ++dd) d = i >= S.doff[dd] ? dd : d;
-                    const unsigned r = i - S.doff[d];
-                    int lo = 0, hi = G;                    // largest block sb with prefix[sb] <= r (it has a member: r < prefix[sb + 1])
-                    while (hi - lo > 1) {
-                        const int mid = (lo + hi) >> 1;
-                        if (pfxL[d * 256 + mid] <= r) lo = mid; else hi = mid;
-                    }
-                    ad[j] = (const unsigned*)A.cand + (size_t)lo * RF_PXMAX + offL[d * 256 + lo] + (r - pfxL[d * 256 + lo]);
+                if ((unsigned)j < K && i0 + j < ncand) {   // (K is block-uniform)
+                    ad[j] = (const unsigned*)A.cand + (size_t)sb * RF_PXMAX + offL[d * 256 + sb] + (r - seg0);
+                    kd |= (unsigned)d << (3 * j);
+                    ++r;
+                    if (r == dn && d + 1 < nd) { ++d; r = 0; dn = S.dcnt[d]; sb = 0; seg0 = 0; seg1 = seg_end(d, 0, dn); }
+                    while (r >= seg1 && sb + 1 < G) { ++sb; seg0 = seg1; seg1 = seg_end(d, sb, dn); }
                 }
             }
-            rf_ld1x8(ad, val);
+        }
+        rf_ld1x12(ad, val);
+        const bool fast = S.bad == 0;                      // block-uniform (set with the list table)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned i = base + (unsigned)j * RF_T + t;
-                if (i < ncand) lkeys[i] = f32_key(__uint_as_float(val[j]));
+        for (int j = 0; j < 12; ++j) {
+            const unsigned i = i0 + j;
+            val[j] = f32_key(__uint_as_float(val[j]));
+            if ((unsigned)j < K && i < ncand) {
+                lkeys[i] = val[j];                         // (the generic selection forms read the keys from LDS)
+                if (fast) {
+                    const int d = (kd >> (3 * j)) & 7;
+                    const unsigned rel = val[j] - S.lmn[d];
+                    if (rel >> S.lnb[d]) S.bad = 1;        // outside the bin's key range (never observed): generic selection
+                    else atomicAdd(&hist0[d * 512 + (rel >> S.lsh[d])], 1u);
+                }
             }
         }
         rf_stamp(ws, 3);
         rf_stamp(ws, 4);
+        __syncthreads();
+        rf_stamp(ws, 8);
+        if (fast && S.bad == 0) {
+            // ---------------------------------------------------------------- D (fused): first digit of every order statistic
+            // from its list's histogram (one wave per slot), then the keys of that sub-bucket (n / 512 of the list on
+            // average) are collected and the statistic is selected among them by one wave: 3 block barriers, no key re-reads
+            if (wave < nslot && nvalid && S.twin[wave] == wave) {
+                const int d = S.sdl[wave];
+                unsigned k = S.srin[wave];
+                const uint4 ha = *(const uint4*)(hist0 + d * 512 + lane * 8), hb = *(const uint4*)(hist0 + d * 512 + lane * 8 + 4);
+                const unsigned h[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+                unsigned loc = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) loc += h[q];
+                unsigned x = loc;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned u = __shfl_up(x, o, 64);
+                    if (lane >= o) x += u;
+                }
+                const unsigned exl = x - loc;
+                if (k >= exl && k < x) {                   // exactly one lane
+                    unsigned run = exl, dig = 0, kk = 0;
+                    bool got = false;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (!got && k < run + h[q]) { dig = lane * 8 + q; kk = k - run; got = true; }
+                        run += h[q];
+                    }
+                    S.sd0[wave] = dig; S.sk1[wave] = kk;
+                    atomicOr(&mark[d * 512 + dig], 1u << wave);      // which slots want the keys of this (list, digit)
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                if ((unsigned)j < K && i0 + j < ncand) {
+                    const int d = (kd >> (3 * j)) & 7;
+                    const unsigned dig = (val[j] - S.lmn[d]) >> S.lsh[d];
+                    for (unsigned m = mark[d * 512 + dig]; m; m &= m - 1u) {      // (one key in 512 gets past this read)
+                        const int sl = __ffs(m) - 1;
+                        const unsigned pos = atomicAdd(&S.scount[sl], 1u);
+                        if (pos < 512u) small[sl * 512 + pos] = val[j];
+                    }
+                }
+            }
+            __syncthreads();
+            bool over = false;
+            for (int sl = 0; sl < nslot; ++sl) over = over || (S.twin[sl] == sl && S.scount[sl] > 512u);
+            if (!over || !nvalid) {
+                if (wave < nslot && nvalid && S.twin[wave] == wave) {
+                    const unsigned key = rf_wave_select_reg(S.whist[wave], small + wave * 512, S.scount[wave], S.sk1[wave]);
+                    if (lane == 0) S.skey[wave] = key;
+                }
+                done = true;
+            }
+            // (a sub-bucket of more than 512 keys -- heavy ties: the generic selection below)
+        }
     } else {
     // ---------------------------------------------------------------- degenerate route (more candidates than LDS holds):
     // my offset inside each list = what the blocks before me put there: bin counts from the published prefixes
@@ -953,28 +1088,28 @@ __global__ __launch_bounds__(RF_T, 1) void k_reliability_fused(RfArgs A) {
     }
     // ---------------------------------------------------------------- phase D: exact selection in LDS, thresholds
     if (!big) {
-        // the usual case (~10^3 candidates per list, gathered into LDS above): all order statistics selected concurrently
-        __syncthreads();
-        rf_stamp(ws, 8);
-        bool small = true, fits = true;
-        for (int d = 0; d < nd; ++d) { small = small && S.dcnt[d] <= 64u * RF_KW; fits = fits && S.dcnt[d] <= 128u * RF_KREG; }
-        if (small) {
-            // one wave per order statistic, keys in registers, no block barriers
-            if (wave < nslot && nvalid && S.twin[wave] == wave) {
-                const int d = S.sdl[wave];
-                const unsigned key = rf_wave_select_reg(S.whist[wave], lkeys + S.doff[d], S.dcnt[d], S.srin[wave]);
-                if (lane == 0) S.skey[wave] = key;
-            }
-        } else if (fits) {
-            rf_block_select(S, lkeys, nslot, nvalid != 0);
-        } else if (wave < nslot && nvalid) {          // a long list: one wave per slot streaming it from LDS
-            int same = -1;
-            for (int u = 0; u < wave; ++u)
-                if (S.sbin[u] == S.sbin[wave] && S.srin[u] == S.srin[wave]) { same = u; break; }
-            if (same < 0) {
-                const int d = S.sdl[wave];
-                const unsigned kk = rf_wave_select(S.whist[wave], lkeys + S.doff[d], S.dcnt[d], S.srin[wave]);
-                if (lane == 0) S.skey[wave] = kk;
+        if (!done) {
+            // generic forms on the keys in LDS (lists whose rank sub-bucket overflowed, keys outside a bin's nominal range)
+            __syncthreads();
+            bool small_l = true, fits = true;
+            for (int d = 0; d < nd; ++d) { small_l = small_l && S.dcnt[d] <= 64u * RF_KW; fits = fits && S.dcnt[d] <= 128u * RF_KREG; }
+            if (small_l) {
+                if (wave < nslot && nvalid && S.twin[wave] == wave) {
+                    const int d = S.sdl[wave];
+                    const unsigned key = rf_wave_select_reg(S.whist[wave], lkeys + S.doff[d], S.dcnt[d], S.srin[wave]);
+                    if (lane == 0) S.skey[wave] = key;
+                }
+            } else if (fits) {
+                rf_block_select(S, lkeys, nslot, nvalid != 0);
+            } else if (wave < nslot && nvalid) {          // a long list: one wave per slot streaming it from LDS
+                int same = -1;
+                for (int u = 0; u < wave; ++u)
+                    if (S.sbin[u] == S.sbin[wave] && S.srin[u] == S.srin[wave]) { same = u; break; }
+                if (same < 0) {
+                    const int d = S.sdl[wave];
+                    const unsigned kk = rf_wave_select(S.whist[wave], lkeys + S.doff[d], S.dcnt[d], S.srin[wave]);
+                    if (lane == 0) S.skey[wave] = kk;
+                }
             }
         }
         __syncthreads();
@@ -1031,7 +1166,7 @@ __global__ __launch_bounds__(RF_T, 1) void k_reliability_fused(RfArgs A) {
     rf_stamp(ws, 5);
     const float tdrop = thr3[0], tlo = thr3[1], thi = thr3[2];
     {   // #kept first (registers only): its block reduction must not sit behind the completion of the stores below
-        const unsigned ign8 = (unsigned)A.ignore & 255u;
+        const unsigned ign8 = (unsigned)A.ignore & 255u;      // (label bytes: the ignore value's low byte marks ignored pixels)
         unsigned kept = 0;
 #pragma unroll
         for (int it = 0; it < RF_NIT; ++it) {
@@ -1051,32 +1186,54 @@ __global__ __launch_bounds__(RF_T, 1) void k_reliability_fused(RfArgs A) {
             if (tk) atomicAdd(ws + RFW_NKEPT, tk);
         }
     }
-    auto apply = [&](int pb, int a, float e, unsigned lb) {
-        const int n = pb >> 20, oy = (pb >> 10) & 1023, ox = (pb & 1023) + a;
-        const long p = ((long)n * A.H + oy) * A.W + ox;
-        long long l = (long long)lb;
-        if (l == (long long)(A.ignore & 255)) l = A.ignore;
-        if (e >= tdrop && l != A.ignore) l = A.ignore;
-        A.ent[p] = e;            // (stored here, not in phase A: keeps the L2 clean for the barrier's write-back)
-        A.target_u[p] = l;
-        if (A.nspec > 1) {
-            const int ly = S.invy[oy], lx = S.invx[ox];
-            if (ly >= 0 && lx >= 0) {
-                const long q = ((long)(A.B + n) * A.hm + ly) * A.wm + lx;
-                A.low_mask[q] = e <= tlo ? 1.f : 0.f;
-                A.high_mask[q] = A.neg_high ? (e >= thi ? 1.f : 0.f) : 1.f;
-            }
+    // (32-bit index arithmetic hoisted per 4-pixel item, and ONE 16-byte store for an item's four entropies / two for its
+    // four targets: the phase is store-issue bound -- 22 narrow stores per thread took 4 us)
+    const unsigned ign8 = (unsigned)A.ignore & 255u;
+    struct __attribute__((packed, aligned(4))) F4 { float v[4]; };
+    struct __attribute__((packed, aligned(8))) L2 { long long v[2]; };
+    auto target_of = [&](float e, unsigned lb) -> long long { return (lb != ign8 && !(e >= tdrop)) ? (long long)lb : (long long)A.ignore; };
+    auto masks = [&](float e, int lq) {
+        if (lq >= 0) {
+            A.low_mask[lq] = e <= tlo ? 1.f : 0.f;
+            A.high_mask[lq] = A.neg_high ? (e >= thi ? 1.f : 0.f) : 1.f;
         }
     };
 #pragma unroll
     for (int it = 0; it < RF_NIT; ++it) {
         if (pbase[it] < 0) continue;
-        const int nx = min(4, A.W - (pbase[it] & 1023));
+        const int n = pbase[it] >> 20, oy = (pbase[it] >> 10) & 1023, ox0 = pbase[it] & 1023;
+        const int nx = min(4, A.W - ox0);
+        const unsigned p0 = ((unsigned)n * A.H + oy) * A.W + ox0;
+        const int ly = A.nspec > 1 ? (int)S.invy[oy] : -1;
+        const int lrow = ly >= 0 ? ((A.B + n) * A.hm + ly) * A.wm : -1;
+        if (nx == 4) {
+            F4 ev; L2 t0, t1;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-            if (a < nx) apply(pbase[it], a, er[it][a], (labr[it] >> (8 * a)) & 255u);
+            for (int a = 0; a < 4; ++a) ev.v[a] = er[it][a];
+            t0.v[0] = target_of(er[it][0], labr[it] & 255u); t0.v[1] = target_of(er[it][1], (labr[it] >> 8) & 255u);
+            t1.v[0] = target_of(er[it][2], (labr[it] >> 16) & 255u); t1.v[1] = target_of(er[it][3], (labr[it] >> 24) & 255u);
+            *(F4*)(A.ent + p0) = ev;
+            *(L2*)(A.target_u + p0) = t0;
+            *(L2*)(A.target_u + p0 + 2) = t1;
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                if (a < nx) { A.ent[p0 + a] = er[it][a]; A.target_u[p0 + a] = target_of(er[it][a], (labr[it] >> (8 * a)) & 255u); }
+        }
+        if (lrow >= 0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                if (a < nx) { const int lx = (int)S.invx[ox0 + a]; masks(er[it][a], lx >= 0 ? lrow + lx : -1); }
+        }
     }
-    if (pb1 >= 0) apply(pb1, 0, er1, lab1);
+    if (pb1 >= 0) {
+        const int n = pb1 >> 20, oy = (pb1 >> 10) & 1023, ox = pb1 & 1023;
+        const unsigned p = ((unsigned)n * A.H + oy) * A.W + ox;
+        A.ent[p] = er1;
+        A.target_u[p] = target_of(er1, lab1);
+        const int ly = A.nspec > 1 ? (int)S.invy[oy] : -1, lx = ly >= 0 ? (int)S.invx[ox] : -1;
+        masks(er1, lx >= 0 ? ((A.B + n) * A.hm + ly) * A.wm + lx : -1);
+    }
     rf_stamp(ws, 6);
     rf_stamp(ws, 7);
     if (t == 0) {
@@ -1129,7 +1286,7 @@ U2PL_API int u2pl_reliability_fused(const float* logits_low, long sn, long sc, l
     // dynamic LDS: phase A's corner logits | the sorted run (RF_PXMAX floats) | block offsets / prefixes + candidate keys
     // phase A tile: the contiguous low-resolution pixel span [c0, c1 + w + 1) of a block, pixel-major
     const size_t lds_a = ((size_t)(((long)B * h * w + G - 1) / G + w + 1) * C + 8) * sizeof(float);
-    const size_t lds_g = ((size_t)2 * RF_MAXSLOT * 256 + RF_CAP) * sizeof(unsigned);
+    const size_t lds_g = ((size_t)2 * RF_MAXSLOT * 256 + RF_CAP + 3 * RF_MAXSLOT * 512) * sizeof(unsigned);
     size_t lds = lds_a > lds_g ? lds_a : lds_g;
     if ((size_t)RF_PXMAX * sizeof(float) > lds) lds = (size_t)RF_PXMAX * sizeof(float);
     static bool attr = false;

@@ -530,8 +530,32 @@ def _nce_state(device, P, D):
     st = _NCE_STATE.get(key)
     if st is None:
         st = _NCE_STATE[key] = dict(grad=torch.zeros((P, D), dtype=torch.float32, device=device),
-                                    head=torch.full((P,), -1, dtype=torch.int32, device=device), dirty=None, pending=None)
+                                    head=torch.full((P,), -1, dtype=torch.int32, device=device), dirty=None, pending=None,
+                                    ws=None)
     return st
+
+
+NCE_FUSED = os.environ.get("U2PL_NCE_UNFUSED") is None     # loss reduce + stale-row clearing inside the InfoNCE launch
+
+
+def _nce_forward(st, rep_rows, jobs_dev, njobs, Q, K, temp, valid_seg, groups, loss_q, ganchor, apix, nxt, loss):
+    """the forward launches: ONE (u2pl_infonce_fused_f32: InfoNCE + loss reduction + clearing of the rows the previous
+    backward wrote) when the shape allows it, else u2pl_infonce_f32 + u2pl_infonce_reduce_f32 (rows cleared in backward)"""
+    P, D = rep_rows.shape
+    if NCE_FUSED and Q % 4 == 0 and D <= 256:
+        need = query("u2pl_infonce_fused_workspace_bytes", njobs, Q)
+        if st["ws"] is None or st["ws"].numel() < need:
+            st["ws"] = torch.zeros(max(need, query("u2pl_infonce_fused_workspace_bytes", MAXC, Q)), dtype=torch.uint8,
+                                   device=rep_rows.device)
+        dirty = st["dirty"]
+        call("u2pl_infonce_fused_f32", jobs_dev, njobs, rep_rows, D, D, Q, K, float(temp), loss_q, ganchor, apix, st["head"], nxt,
+             groups[2], st["grad"] if dirty is not None else None, D, dirty, dirty.numel() if dirty is not None else 0,
+             st["ws"], 1.0 / valid_seg, loss)
+        st["dirty"] = None
+    else:
+        call("u2pl_infonce_f32", jobs_dev, njobs, rep_rows, D, D, Q, K, float(temp), loss_q, ganchor, apix, st["head"], nxt,
+             groups[2])
+        call("u2pl_infonce_reduce_f32", loss_q, njobs, Q, 1.0 / valid_seg, loss)
 
 
 def _nce_rearm(st):
@@ -574,11 +598,9 @@ class _InfoNCE(torch.autograd.Function):
         apix = torch.empty((njobs, Q), dtype=torch.int32, device=dev)
         nxt = torch.empty((njobs, Q), dtype=torch.int32, device=dev)
         _nce_rearm(st)
-        call("u2pl_infonce_f32", jobs_dev, njobs, rep_rows, D, D, Q, K, float(temp), loss_q, ganchor, apix, st["head"], nxt,
-             groups[2])
-        st["pending"] = apix
         loss = torch.empty((), dtype=torch.float32, device=dev)
-        call("u2pl_infonce_reduce_f32", loss_q, njobs, Q, 1.0 / valid_seg, loss)
+        _nce_forward(st, rep_rows, jobs_dev, njobs, Q, K, temp, valid_seg, groups, loss_q, ganchor, apix, nxt, loss)
+        st["pending"] = apix
         ctx.save_for_backward(ganchor, apix, nxt, groups)
         ctx.meta = (P, D, njobs * Q, 1.0 / (Q * valid_seg))
         return loss
@@ -601,8 +623,8 @@ class _InfoNCE(torch.autograd.Function):
 
 
 def infonce_kernels_once(rep_rows, jobs_dev, njobs, Q, K, temp, valid_seg, groups):
-    """the exact launch sequence of _InfoNCE forward + backward (bench.py's roofline replay): InfoNCE, loss reduce,
-    lazy re-zero of the previous rows, ordered row-sparse scatter"""
+    """the exact launch sequence of _InfoNCE forward + backward (bench.py's roofline replay): InfoNCE (+ loss reduce + clearing
+    of the previous rows in the same launch), ordered row-sparse scatter"""
     P, D = rep_rows.shape
     dev = rep_rows.device
     st = _nce_state(dev, P, D)
@@ -611,9 +633,8 @@ def infonce_kernels_once(rep_rows, jobs_dev, njobs, Q, K, temp, valid_seg, group
     apix = torch.empty((njobs, Q), dtype=torch.int32, device=dev)
     nxt = torch.empty((njobs, Q), dtype=torch.int32, device=dev)
     _nce_rearm(st)
-    call("u2pl_infonce_f32", jobs_dev, njobs, rep_rows, D, D, Q, K, float(temp), loss_q, ganchor, apix, st["head"], nxt, groups[2])
     loss = torch.empty((), dtype=torch.float32, device=dev)
-    call("u2pl_infonce_reduce_f32", loss_q, njobs, Q, 1.0 / valid_seg, loss)
+    _nce_forward(st, rep_rows, jobs_dev, njobs, Q, K, temp, valid_seg, groups, loss_q, ganchor, apix, nxt, loss)
     if st["dirty"] is not None:
         call("u2pl_zero_rows_f32", st["grad"], D, D, st["dirty"], st["dirty"].numel())
     call("u2pl_scatter_rows_ordered_f32", st["grad"], D, D, apix, nxt, st["head"], groups[0], groups[1], groups[2], ganchor,

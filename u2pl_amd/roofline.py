@@ -263,9 +263,9 @@ def measure(trainer, batch, args, ms_per_step):
     h, w = (H - 1) // 4 + 1, (W - 1) // 4 + 1
     rel_names = ["u2pl_entropy_f32", "u2pl_entropy_up_f32", "u2pl_select_f32", "u2pl_apply_drop_i64",
                  "u2pl_reliability_masks", "u2pl_reliability_apply", "u2pl_reliability_fused"]
-    con_names = ["u2pl_contra_classify", "u2pl_compact_lists", "u2pl_class_prototypes", "u2pl_bank_append_f32", "u2pl_bank_append_multi_f32",
-                 "u2pl_infonce_f32", "u2pl_infonce_reduce_f32", "u2pl_scatter_rows_ordered_f32",
-                 "u2pl_zero_rows_f32"]
+    con_names = ["u2pl_contra_classify", "u2pl_compact_lists", "u2pl_class_prototypes", "u2pl_contra_phase1", "u2pl_bank_append_f32",
+                 "u2pl_bank_append_multi_f32", "u2pl_infonce_f32", "u2pl_infonce_fused_f32", "u2pl_infonce_reduce_f32",
+                 "u2pl_scatter_rows_ordered_f32", "u2pl_zero_rows_f32"]
     rel_b, con_b = hbm_algorithmic_bytes(B, C, H, W, h, w, 256, LH.LAST_STATS)
     t_rel = sum(agg[n]["ms"] for n in rel_names if n in agg)
     t_con = sum(agg[n]["ms"] for n in con_names if n in agg)
@@ -275,7 +275,7 @@ def measure(trainer, batch, args, ms_per_step):
         t_con = (replay["phase1_us"] + replay.get("bank_append_us", 0.0) + replay.get("infonce_fwd_bwd_us", 0.0)) * 1e-3
     if t_rel > 0 and t_con > 0:
         ach = (rel_b + con_b) / ((t_rel + t_con) * 1e-3) / 1e9
-        out["roofline_hbm"] = {"kernel": "k_reliability_fused (entropy + exact percentiles + target + masks, one persistent launch) + contrastive (classify/compact/proto/bank append/InfoNCE fwd + ordered row-sparse bwd)",
+        out["roofline_hbm"] = {"kernel": "k_reliability_fused (entropy + exact percentiles + target + masks: one persistent launch, one device-wide barrier) + contrastive (phase 1 in three launches: classify, prototype stream, compaction write || prototype finish; bank append; InfoNCE with the loss reduction and the stale-row clearing in the same launch; ordered row-sparse bwd)",
                                "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
                                "algorithmic_MB": round((rel_b + con_b) / 1e6, 1), "reliability_us": round(t_rel * 1e3, 1),

@@ -110,6 +110,104 @@ def test_two_rank_training_keeps_replicas_and_banks_identical():
     assert r0["rm"] == r1["rm"]                                  # SyncBN running stats identical
 
 
+def _pack_case(rank, world):
+    """model forward + backward on R50-DeepLabv3+ with the SyncBN exchanges packed (bn3 + downsample BN, the five ASPP
+    branches: one all-reduce per group and direction) and unit by unit (U2PL_NO_SYNCBN_PACK=1)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from u2pl_amd import nn as K
+    from model_utils import formula_state_dict, net_cfg
+    from u2pl_amd.models.model_helper import ModelBuilder
+    dev = torch.device("cuda", 0)
+    out = {}
+    g = torch.Generator().manual_seed(20 + rank)
+    x = torch.randn(2, 3, 65, 65, generator=g).to(dev)
+    for mode in ("packed", "unit"):
+        if mode == "unit":
+            os.environ["U2PL_NO_SYNCBN_PACK"] = "1"
+        else:
+            os.environ.pop("U2PL_NO_SYNCBN_PACK", None)
+        cfg = net_cfg("resnet50", 19, True)
+        cfg["sync_bn"] = True
+        m = ModelBuilder(cfg)
+        m.load_state_dict(formula_state_dict(m))
+        m = m.to(dev).train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout2d):
+                mod.p = 0.0
+        arena = K.ParamArena([list(m.parameters())])
+        arena.zero_grad()
+        n0 = K.COMM_STATS["syncbn_allreduce"]
+        o = m(x)
+        loss = (o["pred"] ** 2).mean() + (o["rep"] ** 2).mean() + (o["aux"] ** 2).mean()
+        loss.backward()
+        K.wgrad_stream_sync()
+        arena.finish_allreduce()
+        torch.cuda.synchronize()
+        out[mode] = dict(pred=o["pred"].detach().cpu(), grad=arena.grad.detach().cpu().clone(),
+                         rm=m.encoder.layer2[0].downsample[1].running_mean.cpu().clone(),
+                         rv=m.decoder.aspp.conv1[2].running_var.cpu().clone(),
+                         ncoll=K.COMM_STATS["syncbn_allreduce"] - n0)
+    os.environ.pop("U2PL_NO_SYNCBN_PACK", None)
+    a, b = out["packed"], out["unit"]
+    return dict(pred_eq=bool(torch.equal(a["pred"], b["pred"])), grad_eq=bool(torch.equal(a["grad"], b["grad"])),
+                rm_eq=bool(torch.equal(a["rm"], b["rm"])), rv_eq=bool(torch.equal(a["rv"], b["rv"])),
+                grad_abs=float(a["grad"].abs().sum()), n_packed=a["ncoll"], n_unit=b["ncoll"])
+
+
+def test_packed_syncbn_exchanges_equal_the_per_layer_exchanges():
+    """the packed statistics exchanges (one all-reduce for a bottleneck's bn3 + downsample BN, one for the five ASPP
+    branches, forward and backward) give bit-identical activations, gradients and running statistics, with fewer
+    collectives: R50 = 53 BNs in the encoder + 5 ASPP + 4 decoder/head + 2 aux = 2 x 64 per-layer exchanges"""
+    r0, r1 = _run(_pack_case)
+    for r in (r0, r1):
+        assert r["pred_eq"] and r["grad_eq"] and r["rm_eq"] and r["rv_eq"] and r["grad_abs"] > 0, r
+        # 4 stages x (2 -> 1) + ASPP (5 -> 1): 8 fewer forward, 8 fewer backward
+        assert r["n_unit"] - r["n_packed"] == 16, r
+
+
+def _overlap_case(rank, world):
+    """the bucketed gradient all-reduce launched from the backward hooks must wait for the weight-gradient
+    side stream even in the FIRST step (the stream is created lazily by the first conv backward): step-1 parameters with
+    the overlap on and with every bucket launched after backward (U2PL_NO_BUCKET_OVERLAP=1) must agree bit for bit."""
+    from u2pl_amd import configs
+    from u2pl_amd.models.model_helper import ModelBuilder
+    from u2pl_amd.trainer import SemiTrainer
+    from u2pl_amd.utils.loss_helper import get_criterion
+    dev = torch.device("cuda", 0)
+    os.environ["U2PL_BUCKET_MB"] = "4"
+    res = {}
+    for mode in ("overlap", "after"):
+        if mode == "after":
+            os.environ["U2PL_NO_BUCKET_OVERLAP"] = "1"
+        else:
+            os.environ.pop("U2PL_NO_BUCKET_OVERLAP", None)
+        torch.manual_seed(2)
+        np.random.seed(2)
+        cfg = configs.cityscapes_semi(arch="resnet50", crop=129, batch_size=2, sync_bn=True, epochs=10)
+        cfg["criterion"]["kwargs"]["min_kept"] = 3000
+        cfg["trainer"]["sup_only_epoch"] = 1          # supervised step: no RNG-dependent branches
+        model, teacher = ModelBuilder(cfg["net"]).to(dev), ModelBuilder(cfg["net"]).to(dev)
+        for mod in list(model.modules()) + list(teacher.modules()):
+            if isinstance(mod, torch.nn.Dropout2d):
+                mod.p = 0.0
+        tr = SemiTrainer(cfg, model, teacher, get_criterion(cfg), steps_per_epoch=4)
+        g = torch.Generator().manual_seed(30 + rank)
+        il, iu = torch.randn(2, 3, 129, 129, generator=g), torch.randn(2, 3, 129, 129, generator=g)
+        ll = torch.randint(0, 19, (2, 129, 129), generator=g)
+        tr.train_step(il.to(dev), ll.to(dev), iu.to(dev), epoch=0)       # the FIRST step of the process in "overlap" mode
+        torch.cuda.synchronize()
+        res[mode] = tr.arena.flat.detach().cpu().clone()
+    os.environ.pop("U2PL_NO_BUCKET_OVERLAP", None)
+    return dict(eq=bool(torch.equal(res["overlap"], res["after"])), w=float(res["overlap"].double().sum()))
+
+
+def test_bucket_overlap_first_step_equals_reduce_after_backward():
+    r0, r1 = _run(_overlap_case)
+    assert r0["eq"] and r1["eq"], (r0, r1)
+    assert r0["w"] == r1["w"]            # and the replicas agree
+
+
 def test_bench_two_ranks_runs_and_reports_weak_scaling_line():
     """bench.py under torch.distributed.run with 2 ranks (gloo, shared GPU): no hang in the roofline leg,
     one JSON line from rank 0 with the contract's keys."""

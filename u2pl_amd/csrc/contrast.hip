@@ -91,14 +91,10 @@ __global__ __launch_bounds__(CP_PIX) void k_contra_classify_rows(
     __syncthreads();
     const long total = (long)N2 * hw;
     const long p0 = blockIdx.x * (long)CP_PIX, p = p0 + threadIdx.x;
+    // label bits, masks and the block's probability rows are all requested at once (ONE memory round trip; the rows of a
+    // block without label bits -- half of them under quirk Q0 -- are 19 KB of coalesced loads that are then ignored)
     const unsigned lb = p < total ? lbits[p] : 0u;
-    if (__ballot(lb != 0) && (threadIdx.x & 63) == 0) any_s = 1;
-    __syncthreads();
-    if (!any_s) {        // block-uniform
-        if (p < total) { abits[p] = 0; lowbits[p] = 0; nbits[p] = 0; }
-        if (blk && threadIdx.x < 3 * MAXC) blk[(long)threadIdx.x * nblk + blockIdx.x] = 0;
-        return;
-    }
+    const float lmv = p < total ? low_mask[p] : 0.f, hmv = p < total ? high_mask[p] : 0.f;
     {
         const long npx = min((long)CP_PIX, total - p0);
         const int nfl = (int)(npx * C);
@@ -108,8 +104,14 @@ __global__ __launch_bounds__(CP_PIX) void k_contra_classify_rows(
             else for (int k = i; k < nfl; ++k) rows[k] = src[k];
         }
     }
-    const bool lo = p < total && lb != 0 && low_mask[p] != 0.f, hi = p < total && lb != 0 && high_mask[p] != 0.f;
+    if (__ballot(lb != 0) && (threadIdx.x & 63) == 0) any_s = 1;
     __syncthreads();
+    if (!any_s) {        // block-uniform
+        if (p < total) { abits[p] = 0; lowbits[p] = 0; nbits[p] = 0; }
+        if (blk && threadIdx.x < 3 * MAXC) blk[(long)threadIdx.x * nblk + blockIdx.x] = 0;
+        return;
+    }
+    const bool lo = lb != 0 && lmv != 0.f, hi = lb != 0 && hmv != 0.f;
     if (p < total) {
         const long n = p / hw;
         unsigned a = 0, l = 0, ng = 0;
@@ -386,6 +388,8 @@ __global__ __launch_bounds__(P1_T) void k_phase1_tail(const unsigned* __restrict
     const int ndc = (D + 63) / 64;
     const int c = fb / ndc, cl = lane, rg = wave;
     const int d = (fb % ndc) * 64 + cl;
+    const unsigned n = p1_row_sum(blk + ((long)1 * MAXC + c) * nblk, nblk, lane);     // members of class c (every wave sums it; its
+                                                                                     // loads travel with the flag loads below)
     int basei = 0;
     for (int bb0 = 0; bb0 < npb; bb0 += P1_T) {
         const int bb = bb0 + t;
@@ -402,17 +406,23 @@ __global__ __launch_bounds__(P1_T) void k_phase1_tail(const unsigned* __restrict
         __syncthreads();
     }
     const int n_act = basei;
-    const unsigned n = p1_row_sum(blk + ((long)1 * MAXC + c) * nblk, nblk, lane);     // members of class c (every wave sums it)
     double acc = 0.0;
     if (d < D) {
         const float* pp = partial + (long)c * D + d;
         int i = rg;
-        for (; i + 7 * 16 < n_act; i += 8 * 16) {
-            float vv[8];
+        for (; i + 15 * 16 < n_act; i += 16 * 16) {      // 16 independent loads per thread in flight (256 flagged blocks = one batch)
+            float vv[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) vv[u] = pp[(long)act[i + 16 * u] * C * D];
+            for (int u = 0; u < 16; ++u) vv[u] = pp[(long)act[i + 16 * u] * C * D];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += (double)vv[u];
+            for (int u = 0; u < 16; ++u) acc += (double)vv[u];
+        }
+        for (; i + 3 * 16 < n_act; i += 4 * 16) {
+            float vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) vv[u] = pp[(long)act[i + 16 * u] * C * D];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += (double)vv[u];
         }
         for (; i < n_act; i += 16) acc += (double)pp[(long)act[i] * C * D];
     }

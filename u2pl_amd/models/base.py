@@ -50,9 +50,9 @@ class ASPP(nn.Module):
     def forward(self, x):
         _, _, h, w = x.size()
         pooled = K.global_avg_pool(x)
-        feat1 = K.upsample_bilinear(K.run_seq(nn.Sequential(*list(self.conv1)[1:]), pooled), (h, w))
-        feat2 = K.run_seq(self.conv2, x)
-        feat3 = K.run_seq(self.conv3, x)
-        feat4 = K.run_seq(self.conv4, x)
-        feat5 = K.run_seq(self.conv5, x)
-        return K.cat_channels((feat1, feat2, feat3, feat4, feat5))
+        # five independent conv -> BN -> ReLU branches: under a process group their SyncBatchNorm statistics are exchanged
+        # in ONE packed all-reduce (forward and backward); otherwise exactly run_seq's fused conv_bn per branch
+        units = [(self.conv1[1], self.conv1[2], pooled, True, None)]
+        units += [(seq[0], seq[1], x, True, None) for seq in (self.conv2, self.conv3, self.conv4, self.conv5)]
+        f = K.conv_bn_group(units)
+        return K.cat_channels((K.upsample_bilinear(f[0], (h, w)), f[1], f[2], f[3], f[4]))

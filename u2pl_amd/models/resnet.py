@@ -69,8 +69,10 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         out = K.conv_bn(self.conv1, self.bn1, x, relu=True)
         out = K.conv_bn(self.conv2, self.bn2, out, relu=True)
-        identity = x if self.downsample is None else K.run_seq(self.downsample, x)
-        return K.conv_bn(self.conv3, self.bn3, out, res=identity, relu=True)
+        if self.downsample is None:
+            return K.conv_bn(self.conv3, self.bn3, out, res=x, relu=True)
+        # bn3 and the downsample BatchNorm are independent: under a process group their statistics share one all-reduce
+        return K.conv_bn_res_pair(self.conv3, self.bn3, out, self.downsample[0], self.downsample[1], x)
 
 
 class ResNet(nn.Module):

@@ -416,6 +416,210 @@ class _BNFn(torch.autograd.Function):
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None
 
 
+# ---- packed SyncBatchNorm exchanges ------------------------------------------------------------------------------------
+# A BatchNorm's statistics depend on the previous layer's normalised output, so consecutive layers of one network cannot
+# share a collective -- but INDEPENDENT BatchNorms can: the five ASPP branches (base.py:23-83) and, in the first
+# bottleneck of every ResNet stage, bn3 and the downsample BatchNorm (resnet.py:120-140).  Each group exchanges ONE packed
+# buffer forward and one backward instead of one all-reduce per layer.  Only used in train mode under a
+# process group with sync=True; everything else goes through _BNFn unit by unit (the single-GPU path is untouched).
+def _bn_local_sums(x, ldx, M, C, mod, pre_sums, out):
+    """pivot-shifted sums of one BatchNorm into out (double [2C+1], slot 2C = the local row count)"""
+    if pre_sums is not None:
+        out.copy_(pre_sums)
+    else:
+        wsb = _ws(query("u2pl_colreduce_workspace_bytes", M, 1, C), x.device)
+        call("u2pl_bn_stats_f32", x, ldx, M, C, mod.running_mean, wsb, out)
+    out[2 * C] = float(M)
+
+
+def _bn_finalize(sums, count, mod, C, dev):
+    mean = torch.empty(C, dtype=torch.float32, device=dev)
+    invstd = torch.empty(C, dtype=torch.float32, device=dev)
+    call("u2pl_bn_finalize_f32", sums, count, mod.running_mean, C, mod.eps, mod.momentum, mean, invstd, mod.running_mean,
+         mod.running_var)
+    mod._nbt += 1
+    return mean, invstd
+
+
+def _param_grads(sums, C, gsink, bsink, need, dev):
+    """LOCAL parameter gradients from the (un-reduced) backward sums: dbeta = sums[:C], dgamma = sums[C:]"""
+    if not need:
+        return None, None
+    if gsink is not None:
+        call("u2pl_sums_to_f32", sums[C:], C, 1.0, 1, gsink)
+        call("u2pl_sums_to_f32", sums, C, 1.0, 1, bsink)
+        _mark_ready(gsink)
+        _mark_ready(bsink)
+        return None, None
+    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+    call("u2pl_sums_to_f32", sums[C:], C, 1.0, 0, dgamma)
+    call("u2pl_sums_to_f32", sums, C, 1.0, 0, dbeta)
+    return dgamma, dbeta
+
+
+class _BNGroupFn(torch.autograd.Function):
+    """n independent train-mode SyncBatchNorms (+ReLU, Dropout2d scale) with ONE statistics all-reduce forward and ONE
+    backward.  args: n, then per unit (x, gamma, beta, drop, pre_sums), then the per-unit python metadata list."""
+
+    @staticmethod
+    def forward(ctx, n, *flat):
+        meta = flat[5 * n]                      # [(mod, relu, gsink, bsink)] * n
+        units, total = [], 0
+        for i in range(n):
+            x, gamma, beta, drop, pre = flat[5 * i:5 * i + 5]
+            x, ldx = as_rows(x)
+            N, C, H, W = x.shape
+            units.append((x, ldx, N, C, H, W, gamma, beta, drop, pre))
+            total += 2 * C + 1
+        dev = units[0][0].device
+        group = meta[0][0].group
+        packed = torch.empty(total, dtype=torch.float64, device=dev)
+        off = 0
+        for (x, ldx, N, C, H, W, gamma, beta, drop, pre), (mod, relu, gs, bs) in zip(units, meta):
+            _bn_local_sums(x, ldx, N * H * W, C, mod, pre, packed[off:off + 2 * C + 1])
+            off += 2 * C + 1
+        dist.all_reduce(packed, group=group)
+        COMM_STATS["syncbn_allreduce"] += 1
+        outs, saved, ctx.meta, off = [], [], [], 0
+        W_ = _world()
+        for (x, ldx, N, C, H, W, gamma, beta, drop, pre), (mod, relu, gs, bs) in zip(units, meta):
+            M = N * H * W
+            count = float(M * W_)
+            mean, invstd = _bn_finalize(packed[off:off + 2 * C + 1], count, mod, C, dev)
+            off += 2 * C + 1
+            y = new_act(N, C, H, W, dev)
+            call("u2pl_bn_apply_f32", x, ldx, mean, invstd, gamma, None if beta is None else beta, None, 0, int(relu), drop, H * W, y, C, M, C)
+            outs.append(y)
+            saved += [x, y if relu else None, mean, invstd, gamma, drop]
+            ctx.meta.append((N, C, H, W, ldx, count, gs, bs))
+        ctx.save_for_backward(*saved)
+        ctx.n, ctx.group = n, group
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        n, sv = ctx.n, ctx.saved_tensors
+        dev = gys[0].device
+        total = sum(2 * m[1] for m in ctx.meta)
+        packed = torch.empty(total, dtype=torch.float64, device=dev)
+        work, off = [], 0
+        for i in range(n):
+            x, y, mean, invstd, gamma, drop = sv[6 * i:6 * i + 6]
+            N, C, H, W, ldx, count, gs, bs = ctx.meta[i]
+            M = N * H * W
+            gy, ldg = as_rows(gys[i])
+            sums = packed[off:off + 2 * C]
+            off += 2 * C
+            wsb = _ws(query("u2pl_colreduce_workspace_bytes", M, 1, C), dev)
+            call("u2pl_bn_bwd_sums_f32", gy, ldg, x, ldx, y, C, mean, invstd, drop, H * W, M, C, wsb, sums)
+            dg, db = _param_grads(sums, C, gs, bs, ctx.needs_input_grad[1 + 5 * i + 1], dev)
+            work.append((gy, ldg, x, ldx, y, mean, invstd, gamma, drop, N, C, H, W, count, sums, dg, db))
+        dist.all_reduce(packed, group=ctx.group)
+        COMM_STATS["syncbn_allreduce"] += 1
+        grads = [None]
+        for i, (gy, ldg, x, ldx, y, mean, invstd, gamma, drop, N, C, H, W, count, sums, dg, db) in enumerate(work):
+            dx = None
+            if ctx.needs_input_grad[1 + 5 * i]:
+                dx = new_act(N, C, H, W, dev)
+                call("u2pl_bn_bwd_apply_f32", gy, ldg, x, ldx, y, C, mean, invstd, gamma, drop, H * W, sums, count, dx, C, None, C,
+                     N * H * W, C)
+            grads += [dx, dg, db, None, None]
+        grads.append(None)
+        return tuple(grads)
+
+
+class _BNResPairFn(torch.autograd.Function):
+    """out = relu(bn_a(xa) + bn_b(xb)) -- a bottleneck's bn3 and its downsample BatchNorm (resnet.py:120-140), train mode,
+    SyncBatchNorm: the two statistics exchanges travel in one all-reduce, forward and backward (both backward sums are taken
+    from the same masked gradient: d out / d bn_a = d out / d bn_b = relu mask)."""
+
+    @staticmethod
+    def forward(ctx, xa, ga, ba, pre_a, xb, gb, bb, pre_b, meta):
+        (mod_a, gsa, bsa), (mod_b, gsb, bsb) = meta
+        xa, lda = as_rows(xa)
+        xb, ldb = as_rows(xb)
+        N, C, H, W = xa.shape
+        M, dev = N * H * W, xa.device
+        packed = torch.empty(2 * (2 * C + 1), dtype=torch.float64, device=dev)
+        _bn_local_sums(xa, lda, M, C, mod_a, pre_a, packed[:2 * C + 1])
+        _bn_local_sums(xb, ldb, M, C, mod_b, pre_b, packed[2 * C + 1:])
+        dist.all_reduce(packed, group=mod_a.group)
+        COMM_STATS["syncbn_allreduce"] += 1
+        count = float(M * _world())
+        mean_a, inv_a = _bn_finalize(packed[:2 * C + 1], count, mod_a, C, dev)
+        mean_b, inv_b = _bn_finalize(packed[2 * C + 1:], count, mod_b, C, dev)
+        ident = new_act(N, C, H, W, dev)
+        call("u2pl_bn_apply_f32", xb, ldb, mean_b, inv_b, gb, bb, None, 0, 0, None, H * W, ident, C, M, C)
+        y = new_act(N, C, H, W, dev)
+        call("u2pl_bn_apply_f32", xa, lda, mean_a, inv_a, ga, ba, ident, C, 1, None, H * W, y, C, M, C)
+        ctx.save_for_backward(xa, xb, y, mean_a, inv_a, mean_b, inv_b, ga, gb)
+        ctx.meta = (N, C, H, W, lda, ldb, count, gsa, bsa, gsb, bsb, mod_a.group)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xa, xb, y, mean_a, inv_a, mean_b, inv_b, ga, gb = ctx.saved_tensors
+        N, C, H, W, lda, ldb, count, gsa, bsa, gsb, bsb, group = ctx.meta
+        M, dev = N * H * W, gy.device
+        gy, ldg = as_rows(gy)
+        packed = torch.empty(4 * C, dtype=torch.float64, device=dev)
+        sa, sb = packed[:2 * C], packed[2 * C:]
+        wsb = _ws(query("u2pl_colreduce_workspace_bytes", M, 1, C), dev)
+        call("u2pl_bn_bwd_sums_f32", gy, ldg, xa, lda, y, C, mean_a, inv_a, None, H * W, M, C, wsb, sa)
+        wsb2 = _ws(query("u2pl_colreduce_workspace_bytes", M, 1, C), dev)
+        call("u2pl_bn_bwd_sums_f32", gy, ldg, xb, ldb, y, C, mean_b, inv_b, None, H * W, M, C, wsb2, sb)
+        dga, dba = _param_grads(sa, C, gsa, bsa, ctx.needs_input_grad[1], dev)
+        dgb, dbb = _param_grads(sb, C, gsb, bsb, ctx.needs_input_grad[5], dev)
+        dist.all_reduce(packed, group=group)
+        COMM_STATS["syncbn_allreduce"] += 1
+        dxa = dxb = None
+        if ctx.needs_input_grad[0]:
+            dxa = new_act(N, C, H, W, dev)
+            call("u2pl_bn_bwd_apply_f32", gy, ldg, xa, lda, y, C, mean_a, inv_a, ga, None, H * W, sa, count, dxa, C, None, C, M, C)
+        if ctx.needs_input_grad[4]:
+            dxb = new_act(N, C, H, W, dev)
+            call("u2pl_bn_bwd_apply_f32", gy, ldg, xb, ldb, y, C, mean_b, inv_b, gb, None, H * W, sb, count, dxb, C, None, C, M, C)
+        return dxa, dga, dba, None, dxb, dgb, dbb, None, None
+
+
+def _packable(bns):
+    return (_world() > 1 and os.environ.get("U2PL_NO_SYNCBN_PACK") is None
+            and all(b.training and b.sync for b in bns) and len({id(b.group) for b in bns}) == 1)
+
+
+def _conv_with_stats(conv, bn, x):
+    """conv output + its fused train-mode BN sums (None where the epilogue form does not exist: stem, pooled 1x1)"""
+    if conv.in_channels % 32 == 0:
+        y, sums = conv(x, stat_pivot=bn.running_mean)
+        return y, sums
+    return conv(x), None
+
+
+def conv_bn_group(units):
+    """units: [(conv, bn, x, relu, drop)], mutually independent -> list of outputs.  Under a process group in train mode
+    the SyncBatchNorm statistics of all units are exchanged in ONE all-reduce (forward and backward)."""
+    if not _packable([u[1] for u in units]) or len(units) < 2:
+        return [conv_bn(c, b, x, relu=r, drop=d) for c, b, x, r, d in units]
+    flat, meta = [], []
+    for conv, bn, x, relu, drop in units:
+        y, sums = _conv_with_stats(conv, bn, x)
+        flat += [y, bn.weight, bn.bias, drop, sums]
+        meta.append((bn, relu, _grad_sink(bn.weight), _grad_sink(bn.bias)))
+    return list(_BNGroupFn.apply(len(units), *flat, meta))
+
+
+def conv_bn_res_pair(conv_a, bn_a, xa, conv_b, bn_b, xb):
+    """relu(bn_a(conv_a(xa)) + bn_b(conv_b(xb))): the tail of a bottleneck with a downsample branch"""
+    if not _packable([bn_a, bn_b]):
+        identity = conv_bn(conv_b, bn_b, xb)
+        return conv_bn(conv_a, bn_a, xa, res=identity, relu=True)
+    ya, sa = _conv_with_stats(conv_a, bn_a, xa)
+    yb, sb = _conv_with_stats(conv_b, bn_b, xb)
+    meta = ((bn_a, _grad_sink(bn_a.weight), _grad_sink(bn_a.bias)), (bn_b, _grad_sink(bn_b.weight), _grad_sink(bn_b.bias)))
+    return _BNResPairFn.apply(ya, bn_a.weight, bn_a.bias, sa, yb, bn_b.weight, bn_b.bias, sb, meta)
+
+
 class BatchNorm2d(nn.Module):
     """nn.BatchNorm2d / nn.SyncBatchNorm (base.py:6-8) with torch defaults (eps 1e-5,
     momentum 0.1, affine, running stats).  `sync=True` exchanges the per-channel

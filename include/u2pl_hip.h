@@ -110,6 +110,15 @@ int u2pl_contra_phase1(const float* prob, long sn, long sc, long sp, const unsig
 int u2pl_gather_rows_f32(const float* rows, long ld, int D, const int* list, long n, float* out,
                          hipStream_t stream);
 /* dequeue_and_enqueue FIFO (utils.py:27-47) on a device ring; tail=(head+len)%cap */
+/* The bank as a device-resident object: state = int64 [C][5] {ring offset in `storage` (rows), cap, head, len,
+ * ptr}; u2pl_bank_enqueue_f32 appends counts_dev[c] rows per class at the tails and advances the state with the
+ * arithmetic of dequeue_and_enqueue (utils.py:27-47) -- no host-side lengths or heads needed.  idx == NULL: class c's
+ * rows are rows[row_start_dev[c] + j]. */
+size_t u2pl_bank_state_bytes(int C);
+int u2pl_bank_init(long long* state, int C, const long long* caps_host, hipStream_t stream);
+int u2pl_bank_enqueue_f32(long long* state, float* storage, int D, const float* rows, long ld, const int* idx,
+                          long idx_stride, const long long* row_start_dev, const unsigned* counts_dev, int C,
+                          hipStream_t stream);
 int u2pl_bank_append_f32(float* bank, long cap, long tail, int D, const float* rows, long ld, const int* list,
                          long n_new, hipStream_t stream);
 /* same for every class in ONE launch; desc_dev = int64 [nclass][6] {bank, cap, tail, rows, list|0, n_new} */
@@ -293,6 +302,11 @@ int u2pl_softmax_rows_f32(const float* x, long ldx, float* y, long ldy, long M, 
 int u2pl_sgd_step_f32(float* p, const float* g, float* buf, long n, long b1, long b2, float lr0, float lr1, float lr2,
                       float momentum, float weight_decay, int first, float grad_scale, hipStream_t stream);
 int u2pl_ema_update_f32(float* t, const float* s, long n, float decay, float one_minus_decay, hipStream_t stream);
+/* torch.optim.Adam step (lr_helper.py:20-21; amsgrad off) on the same arena layout: bias_correction1 = 1 - beta1^t,
+ * bias_correction2_sqrt = sqrt(1 - beta2^t) for the step count t kept by the host */
+int u2pl_adam_step_f32(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, long b1, long b2, float lr0,
+                       float lr1, float lr2, float beta1, float beta2, float eps, float weight_decay,
+                       float bias_correction1, float bias_correction2_sqrt, float grad_scale, hipStream_t stream);
 /* The whole reliability split in ONE persistent launch (csrc/relfused.hip): bilinear up-sampling + entropy of the
  * train-mode teacher logits (train_semi.py:371-374,402), exact np.percentile thresholds (loss_helper.py:38-40,
  * train_semi.py:405-415), unsup target overwrite (loss_helper.py:41-43), low / high masks + nearest down-sampling +

@@ -493,3 +493,35 @@ def test_bf16_student_training_step_tracks_the_fp32_step():
     assert torch.equal(out[0][1], out[1][1])                     # teacher (fp32) pseudo labels identical
     for a, b in zip(out[0][0], out[1][0]):
         assert abs(a - b) <= 0.02 * max(1.0, abs(a)), (out[0][0], out[1][0])
+
+
+def test_adam_step_matches_torch_adam():
+    """u2pl_adam_step_f32 on the flat arena (three lr segments, weight decay, DDP mean folded in as grad_scale) against
+    torch.optim.Adam on CPU (lr_helper.py:20-21 `optim.Adam(parms, **kwargs)`) over five steps"""
+    from u2pl_amd.utils.lr_helper import get_optimizer
+    g = torch.Generator().manual_seed(4)
+    shapes = [(64, 32, 3, 3), (64,), (128, 64, 1, 1), (19, 128, 1, 1), (19,)]
+    ref_p = [torch.nn.Parameter(torch.randn(s_, generator=g)) for s_ in shapes]
+    our_p = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ref_p]
+    lrs = (1e-3, 1e-2, 5e-3)
+    split = [ref_p[:2], ref_p[2:3], ref_p[3:]], [our_p[:2], our_p[2:3], our_p[3:]]
+    kw = dict(lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-4)
+    ref = torch.optim.Adam([dict(params=gr, lr=lr) for gr, lr in zip(split[0], lrs)], **kw)
+    ours = get_optimizer([dict(params=gr, lr=lr) for gr, lr in zip(split[1], lrs)], dict(type="adam", kwargs=kw))
+    for step in range(5):
+        grads = [torch.randn(s_, generator=g) for s_ in shapes]
+        ours.zero_grad()
+        for p, q, gr in zip(ref_p, our_p, grads):
+            p.grad = gr.clone()
+            q._u2pl_grad.copy_(gr.to(DEV))
+        ref.step()
+        ours.step()
+        for p, q in zip(ref_p, our_p):
+            err = (q.detach().cpu() - p.detach()).abs().max().item()
+            assert err <= 2e-6 * max(1.0, p.detach().abs().max().item()), (step, err)
+    sd = ours.state_dict()
+    assert float(sd["state"][0]["step"]) == 5.0
+    rs = ref.state_dict()["state"]
+    for i in range(len(shapes)):
+        assert (sd["state"][i]["exp_avg"] - rs[i]["exp_avg"]).abs().max().item() <= 1e-6
+        assert (sd["state"][i]["exp_avg_sq"] - rs[i]["exp_avg_sq"]).abs().max().item() <= 1e-6

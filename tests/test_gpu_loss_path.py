@@ -240,6 +240,48 @@ def test_bank_sequence_golden():
         assert bank.ptr[0] == int(g[f"ptr{i}"])
 
 
+def test_bank_sequence_golden_through_the_device_resident_state():
+    """u2pl_bank_init / u2pl_bank_enqueue_f32 (ring bookkeeping ON THE DEVICE, list lengths never on the host) against the
+    reference's dequeue_and_enqueue sequence (utils.py:27-47): contents, FIFO order after wrap-around, ptr, and the host
+    mirror of the bookkeeping equals the device state after every step; a second, multi-class bank checks per-class
+    offsets, index lists and an oversized batch (only the last `cap` rows are kept, utils.py:38-41)."""
+    from u2pl_amd._lib import call
+    H = hip()
+    g = golden("bank_seq")
+    bank = H.DeviceMemoryBank(1, [int(g["queue_size"])], feat_dim=16, device=DEV)
+    for i, n in enumerate(g["sizes"]):
+        keys = T(g[f"keys{i}"]) if n else torch.zeros(1, 16, device=DEV)
+        cnt = torch.tensor([int(n)], dtype=torch.int32, device=DEV)
+        bank.enqueue_device(keys, 16, None, 0, cnt)
+        bank.mirror_counts([int(n)])
+        assert np.array_equal(bank.logical(0).cpu().numpy(), g[f"queue{i}"])
+        assert bank.ptr[0] == int(g[f"ptr{i}"])
+        st = bank.state.cpu().numpy()
+        assert [int(st[0, 2]), int(st[0, 3]), int(st[0, 4])] == [bank.head[0], bank.length[0], bank.ptr[0]]
+    # three classes, index lists, one class over capacity; state initialised by u2pl_bank_init itself
+    caps = [7, 5, 9]
+    b3 = H.DeviceMemoryBank(3, caps, feat_dim=8, device=DEV)
+    b3.state = torch.empty((3, 5), dtype=torch.int64, device=DEV)
+    call("u2pl_bank_init", b3.state, 3, np.array(caps, dtype=np.int64).ctypes.data)
+    b3._state_stale = False
+    assert b3.state.cpu().numpy().tolist() == [[0, 7, 0, 0, 0], [7, 5, 0, 0, 0], [12, 9, 0, 0, 0]]
+    gen = torch.Generator().manual_seed(1)
+    rows = torch.randn(40, 8, generator=gen).to(DEV)
+    ref = [torch.zeros(0, 8) for _ in caps]
+    for step in range(4):
+        cnts = [[3, 0, 4], [6, 12, 1], [0, 2, 9], [5, 5, 5]][step]
+        idx = torch.zeros((3, 16), dtype=torch.int32)
+        for c in range(3):
+            idx[c, : cnts[c]] = torch.randperm(40, generator=gen)[: cnts[c]].int()
+        b3.enqueue_device(rows, 8, idx.to(DEV), 16, torch.tensor(cnts, dtype=torch.int32, device=DEV))
+        b3.mirror_counts(cnts)
+        for c in range(3):
+            ref[c] = torch.cat((ref[c], rows.cpu()[idx[c, : cnts[c]].long()]))[-caps[c]:]
+            assert torch.equal(b3.logical(c).cpu(), ref[c]), (step, c)
+        st = b3.state.cpu().numpy()
+        assert st[:, 2].tolist() == b3.head and st[:, 3].tolist() == b3.length and st[:, 4].tolist() == b3.ptr
+
+
 # ------------------------------------------------------------------ contrastive loss (a14-a16)
 @pytest.mark.parametrize("tag", ["65_empty", "65_prefill", "65_t007", "65_t001", "65_wrap"])
 @pytest.mark.parametrize("api", ["device_bank", "reference_lists"])

@@ -89,8 +89,40 @@ def test_sgd_kwargs_that_change_the_update_rule_are_rejected():
         check_sgd_kwargs({"lr": 0.01, "betas": (0.9, 0.999)})
     with pytest.raises(NotImplementedError):
         check_sgd_kwargs({"lr": 0.01, "momentum": 0.9, "nesterov": True})
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError):          # the reference asserts "optimizer type is not supported" (lr_helper.py:22-25)
         get_optimizer([], {"type": "AdamW", "kwargs": {"lr": 1e-3}})
+
+
+def test_adam_state_dict_has_the_torch_layout_and_round_trips():
+    """`type: adam` (lr_helper.py:20-21): same keys / group order / numbering as torch.optim.Adam.state_dict(), and a real
+    torch.optim.Adam over the same shapes accepts it"""
+    from u2pl_amd.utils.lr_helper import adam_state_dict, check_adam_kwargs, load_adam_state_dict
+    check_adam_kwargs({"lr": 1e-3, "betas": (0.9, 0.99), "eps": 1e-8, "weight_decay": 1e-4})
+    with pytest.raises(NotImplementedError):
+        check_adam_kwargs({"lr": 1e-3, "amsgrad": True})
+    with pytest.raises(ValueError):
+        check_adam_kwargs({"lr": 1e-3, "momentum": 0.9})
+    g = torch.Generator().manual_seed(0)
+    groups = [[torch.nn.Parameter(torch.randn(4, 3, generator=g)), torch.nn.Parameter(torch.randn(5, generator=g))],
+              [torch.nn.Parameter(torch.randn(2, 2, generator=g))], [torch.nn.Parameter(torch.randn(7, generator=g))]]
+    m = {id(p): (torch.randn(p.shape, generator=g), torch.rand(p.shape, generator=g)) for gr in groups for p in gr}
+    hyper = dict(betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-4)
+    sd = adam_state_dict(groups, [0.001, 0.01, 0.01], hyper, lambda p: m[id(p)], steps=3)
+    ref = torch.optim.Adam([dict(params=gr, lr=lr) for gr, lr in zip(groups, (0.001, 0.01, 0.01))], lr=0.001, betas=(0.9, 0.99),
+                           eps=1e-8, weight_decay=1e-4)
+    for gr in groups:
+        for p in gr:
+            p.grad = torch.zeros_like(p)
+    ref.step()
+    rsd = ref.state_dict()
+    assert [gg["params"] for gg in sd["param_groups"]] == [gg["params"] for gg in rsd["param_groups"]]
+    assert set(sd["param_groups"][0]) == set(rsd["param_groups"][0])
+    assert set(sd["state"][0]) == set(rsd["state"][0]) and float(sd["state"][2]["step"]) == 3.0
+    ref.load_state_dict(sd)               # torch accepts the layout
+    m2 = {id(p): (torch.zeros(p.shape), torch.zeros(p.shape)) for gr in groups for p in gr}
+    assert load_adam_state_dict(sd, groups, lambda p: m2[id(p)]) == 3
+    for k in m:
+        assert torch.equal(m[k][0], m2[k][0]) and torch.equal(m[k][1], m2[k][1])
 
 
 def test_sgd_state_dict_has_the_torch_layout_and_round_trips():

@@ -781,6 +781,87 @@ U2PL_API int u2pl_bank_append_multi_f32(const long long* desc_dev, int nclass, i
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// The memory bank as a device-resident object driven from this header alone (SURVEY 8b `u2pl_bank_t`): the ring
+// bookkeeping of dequeue_and_enqueue (utils.py:27-47) lives in a small DEVICE state array, so an enqueue needs neither the
+// list lengths nor the ring heads on the host and can be issued before the step's host synchronisation.
+//   state: int64 [C][5] = {row offset of the class's ring inside `storage`, cap, head, len, ptr}
+//   u2pl_bank_init     caps (host) -> offsets = prefix sums, head = len = ptr = 0
+//   u2pl_bank_enqueue  class c appends counts_dev[c] rows (rows[idx[c * idx_stride + j]], j < counts_dev[c]; idx NULL:
+//                      row j of a class-major block starting at row_start_dev[c]) at its tail, only the last `cap` of
+//                      them if there are more (utils.py:38-41), then the state advances: len' = min(len + n, cap),
+//                      head' = (tail + n - len') mod cap, ptr' = cap once full, else (ptr + n) mod cap (utils.py:36-45)
+// A host that wants the lengths (the reference samples torch.randint(len) on the CPU) copies the state back, or mirrors
+// the same arithmetic from the counts it reads anyway (u2pl_amd.hipops.DeviceMemoryBank does the latter).
+// ---------------------------------------------------------------------------
+struct BankCaps { long long cap[MAXC]; };
+__global__ void k_bank_init(long long* __restrict__ state, int C, BankCaps caps) {
+    if (threadIdx.x == 0) {
+        long long off = 0;
+        for (int c = 0; c < C; ++c) {
+            state[5 * c + 0] = off; state[5 * c + 1] = caps.cap[c]; state[5 * c + 2] = 0; state[5 * c + 3] = 0; state[5 * c + 4] = 0;
+            off += caps.cap[c];
+        }
+    }
+}
+U2PL_API size_t u2pl_bank_state_bytes(int C) { return (size_t)C * 5 * sizeof(long long); }
+U2PL_API int u2pl_bank_init(long long* state, int C, const long long* caps_host, hipStream_t stream) {
+    if (C <= 0 || C > MAXC || !state || !caps_host) return U2PL_EINVAL;
+    BankCaps caps = {};
+    for (int c = 0; c < C; ++c) {
+        if (caps_host[c] <= 0) return U2PL_EINVAL;
+        caps.cap[c] = caps_host[c];
+    }
+    U2PL_LAUNCH(k_bank_init, dim3(1), dim3(64), 0, stream, state, C, caps);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void k_bank_enqueue(const long long* __restrict__ state, float* __restrict__ storage, int D,
+                               const float* __restrict__ rows, long ld, const int* __restrict__ idx, long idx_stride,
+                               const long long* __restrict__ row_start, const unsigned* __restrict__ counts) {
+    const int c = blockIdx.y;
+    const long n_new = counts[c];
+    if (n_new <= 0) return;
+    const long off = state[5 * c + 0], cap = state[5 * c + 1], head = state[5 * c + 2], len = state[5 * c + 3];
+    const long tail = (head + len) % cap;
+    const long skip = n_new > cap ? n_new - cap : 0;
+    const int D4 = D >> 2;
+    const long total = (n_new - skip) * D4;
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long j = skip + t / D4;
+        const int dd = (int)(t % D4);
+        const long src = idx ? (long)idx[(long)c * idx_stride + j] : (row_start ? row_start[c] : 0) + j;
+        long slot = tail + j;
+        slot = slot >= cap ? slot % cap : slot;
+        ((float4*)storage)[(off + slot) * D4 + dd] = *(const float4*)(rows + src * ld + 4 * dd);
+    }
+}
+__global__ void k_bank_advance(long long* __restrict__ state, const unsigned* __restrict__ counts, int C) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    const long n = counts[c];
+    const long cap = state[5 * c + 1], head = state[5 * c + 2], len = state[5 * c + 3], ptr = state[5 * c + 4];
+    const long tail = (head + len) % cap;
+    const long nl = len + n < cap ? len + n : cap;
+    const long new_tail = (tail + n) % cap;
+    state[5 * c + 3] = nl;
+    state[5 * c + 2] = ((new_tail - nl) % cap + cap) % cap;
+    state[5 * c + 4] = nl >= cap ? cap : (ptr + n) % cap;
+}
+U2PL_API int u2pl_bank_enqueue_f32(long long* state, float* storage, int D, const float* rows, long ld, const int* idx,
+                                   long idx_stride, const long long* row_start_dev, const unsigned* counts_dev, int C,
+                                   hipStream_t stream) {
+    if (D % 4 || C <= 0 || C > MAXC || !state || !storage || !rows || !counts_dev) return U2PL_EINVAL;
+    // the list lengths are on the device only: a fixed grid per class, grid-stride over the rows (a step adds ~10^3 keys of
+    // 64 float4 per class: one pass of 256 blocks; blocks of a class without new keys leave after one load)
+    U2PL_LAUNCH(k_bank_enqueue, dim3(256, C), dim3(256), 0, stream, state, storage, D, rows, ld, idx, idx_stride, row_start_dev,
+                counts_dev);
+    U2PL_LAUNCH_CHECK();
+    U2PL_LAUNCH(k_bank_advance, dim3(1), dim3(64), 0, stream, state, counts_dev, C);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
 U2PL_API int u2pl_bank_append_f32(float* bank, long cap, long tail, int D, const float* rows, long ld,
                                   const int* list, long n_new, hipStream_t stream) {
     if (D % 4 || cap <= 0) return U2PL_EINVAL;

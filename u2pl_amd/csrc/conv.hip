@@ -373,7 +373,18 @@ static IgemmPlan plan_igemm(const ConvGeom& g, int batch = 1) {
     if (c22 <= c12 && c22 <= c11) { p.tail_tm = 2; p.tail_tn = 2; }
     else if (c12 <= c11) { p.tail_tm = 1; p.tail_tn = 2; }
     else { p.tail_tm = 1; p.tail_tn = 1; }
-    p.nblk_tail = cdiv(tail, 64 * p.tail_tm);
+    {   // experiment switch (tools/bench_igemm_tail.py): U2PL_IGEMM_TAIL = 0 (one launch of body tiles) | 22 | 12 | 11 | 14 (128x64, 8 waves)
+        const char* e = getenv("U2PL_IGEMM_TAIL");
+        if (e && *e) {
+            const int v = atoi(e);
+            if (v == 0) { p.m_body = M; p.nblk_body = cdiv(M, 128); p.tail_tm = p.tail_tn = 0; p.nblk_tail = 0; return p; }
+            if (v == 22) { p.tail_tm = 2; p.tail_tn = 2; }
+            else if (v == 12) { p.tail_tm = 1; p.tail_tn = 2; }
+            else if (v == 11) { p.tail_tm = 1; p.tail_tn = 1; }
+            else if (v == 14) { p.tail_tm = 4; p.tail_tn = 1; }     // <1, 1, 4>: 128 x 64 tiles on 8 waves
+        }
+    }
+    p.nblk_tail = p.tail_tm == 4 ? cdiv(tail, 128) : cdiv(tail, 64 * p.tail_tm);
     return p;
 }
 static int run_igemm(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
@@ -402,6 +413,7 @@ static int run_igemm(const float* x, long ldx, const float* w, const float* bias
                         : launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, 0, p.m_body, stream, stats, pivot, batch, zx, zw, zy, epi);
     if (rc || p.nblk_tail == 0) return rc;
     float* st = stats ? stats + (long)p.nblk_body * 2 * g.Cout : nullptr;
+    if (p.tail_tm == 4) return launch_igemm<1, 1, 4>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy, epi);
     if (p.tail_tm == 2) return launch_igemm<2, 2>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy, epi);
     if (p.tail_tn == 2) return launch_igemm<1, 2>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy, epi);
     return launch_igemm<1, 1>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy, epi);

@@ -585,6 +585,34 @@ U2PL_API int u2pl_sgd_step_f32(float* p, const float* g, float* buf, long n, lon
     U2PL_LAUNCH_CHECK();
     return 0;
 }
+// torch.optim.Adam (lr_helper.py:20-21 `optim.Adam(parms, **kwargs)`; amsgrad = False) on the flat arena, torch's
+// single-tensor update order:  g += wd p;  m += (1 - b1)(g - m);  v = b2 v + (1 - b2) g g;
+// p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).   bc1 = 1 - b1^t and bc2s = sqrt(1 - b2^t) come from the host.
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                       long b1, long b2, float lr0, float lr1, float lr2, float beta1, float beta2, float eps, float wd,
+                       float bc1, float bc2s, float gscale) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float lr = i < b1 ? lr0 : (i < b2 ? lr1 : lr2);
+        const float pv = p[i];
+        const float gv = __fadd_rn(__fmul_rn(g[i], gscale), __fmul_rn(wd, pv));
+        const float mv = __fadd_rn(m[i], __fmul_rn(1.0f - beta1, __fsub_rn(gv, m[i])));             // lerp_(grad, 1 - beta1), weight < 0.5
+        const float vv = __fadd_rn(__fmul_rn(v[i], beta2), __fmul_rn(1.0f - beta2, __fmul_rn(gv, gv)));
+        m[i] = mv;
+        v[i] = vv;
+        const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vv), bc2s), eps);
+        p[i] = __fsub_rn(pv, __fmul_rn(__fdiv_rn(lr, bc1), __fdiv_rn(mv, denom)));
+    }
+}
+U2PL_API int u2pl_adam_step_f32(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, long b1, long b2,
+                                float lr0, float lr1, float lr2, float beta1, float beta2, float eps, float weight_decay,
+                                float bias_correction1, float bias_correction2_sqrt, float grad_scale, hipStream_t stream) {
+    if (n <= 0) return 0;
+    if (!(bias_correction1 > 0.f) || !(bias_correction2_sqrt > 0.f)) return U2PL_EINVAL;
+    U2PL_LAUNCH(k_adam, dim3(grid_for(n, 256)), dim3(256), 0, stream, p, g, exp_avg, exp_avg_sq, n, b1, b2, lr0, lr1, lr2, beta1,
+                beta2, eps, weight_decay, bias_correction1, bias_correction2_sqrt, grad_scale);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
 __global__ void k_ema(float* __restrict__ t, const float* __restrict__ s, long n, float d, float omd) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         t[i] = __fadd_rn(__fmul_rn(d, t[i]), __fmul_rn(omd, s[i]));

@@ -404,10 +404,50 @@ class DeviceMemoryBank:
     def __init__(self, num_classes, queue_size, feat_dim=256, device="cuda"):
         self.C, self.D = num_classes, feat_dim
         self.cap = [int(q) for q in queue_size]
-        self.buf = [torch.zeros((q, feat_dim), dtype=torch.float32, device=device) for q in self.cap]
+        # ONE storage buffer, the class rings are row ranges of it (u2pl_bank_* address it through the device state)
+        self.storage = torch.zeros((sum(self.cap), feat_dim), dtype=torch.float32, device=device)
+        offs = np.concatenate([[0], np.cumsum(self.cap)]).astype(np.int64)
+        self.buf = [self.storage[int(offs[c]):int(offs[c + 1])] for c in range(num_classes)]
         self.head = [0] * num_classes
         self.length = [0] * num_classes
         self.ptr = [0] * num_classes  # reference's queue_ptr bookkeeping (utils.py:36-45)
+        # device copy of the bookkeeping (int64 [C][5]: ring offset, cap, head, len, ptr) for u2pl_bank_enqueue_f32; the host
+        # lists above mirror it (the reference draws torch.randint(len) on the CPU).  Host-driven appends mark it stale.
+        self._offs = offs
+        self.state = None
+        self._state_stale = True
+
+    def _sync_state(self):
+        """upload the host bookkeeping when a host-driven append / load changed it"""
+        if self.storage.device.type != "cuda":
+            return False
+        if self.state is None:
+            self.state = torch.zeros((self.C, 5), dtype=torch.int64, device=self.storage.device)
+        if self._state_stale:
+            st = np.stack([self._offs[:-1], np.array(self.cap), np.array(self.head), np.array(self.length), np.array(self.ptr)], 1)
+            self.state.copy_(h2d(torch.from_numpy(st.astype(np.int64)), self.storage.device))
+            self._state_stale = False
+        return True
+
+    def enqueue_device(self, rows, ld, idx, idx_stride, counts_dev):
+        """dequeue_and_enqueue for every class in ONE call with the list lengths still on the DEVICE (counts_dev: uint32
+        [C]): can be issued before the step's host synchronisation.  Follow with mirror_counts() once the counts are on
+        the host."""
+        self._sync_state()
+        call("u2pl_bank_enqueue_f32", self.state, self.storage, self.D, rows, ld, idx, idx_stride, None, counts_dev, self.C)
+        if REPLAY is not None:
+            REPLAY["enqueue"] = (rows, ld, idx, idx_stride, counts_dev)
+            REPLAY["bank"] = self
+
+    def mirror_counts(self, counts):
+        """the host copy of what u2pl_bank_enqueue_f32 did to the bookkeeping (same arithmetic, utils.py:36-45)"""
+        for c in range(self.C):
+            n_new = int(counts[c])
+            cap = self.cap[c]
+            tail = (self.head[c] + self.length[c]) % cap
+            self.length[c] = min(self.length[c] + n_new, cap)
+            self.head[c] = ((tail + n_new) % cap - self.length[c]) % cap
+            self._book(c, n_new)
 
     def append_rows(self, c, rows, ld, n_new, idx_list=None):
         """append n_new rows (rows base pointer/tensor, leading dim ld, optional int32 index list)."""
@@ -417,6 +457,7 @@ class DeviceMemoryBank:
         cap = self.cap[c]
         tail = (self.head[c] + self.length[c]) % cap
         call("u2pl_bank_append_f32", self.buf[c], cap, tail, self.D, rows, ld, idx_list, n_new)
+        self._state_stale = True
         tot = self.length[c] + n_new
         new_tail = (tail + n_new) % cap
         self.length[c] = min(tot, cap)
@@ -452,6 +493,7 @@ class DeviceMemoryBank:
             if REPLAY is not None:
                 REPLAY["append"] = (dd, len(entries), self.D, ld, mx, [e[1] for e in entries], [e[3] for e in entries])
         self.head, self.length = head, length
+        self._state_stale = True
         for c, n in per_class.items():
             self._book(c, n)
 
@@ -471,6 +513,7 @@ class DeviceMemoryBank:
         n = min(rows.shape[0], self.cap[c])
         self.buf[c][:n].copy_(rows[-n:])
         self.head[c], self.length[c] = 0, n
+        self._state_stale = True
 
     def __len__(self):
         return self.C

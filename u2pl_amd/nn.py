@@ -1045,6 +1045,27 @@ class ParamArena:
              float(grad_scale))
         self.steps += 1
 
+    def adam_step(self, lrs, betas, eps, weight_decay, grad_scale=1.0):
+        """torch.optim.Adam(betas, eps, weight_decay; amsgrad off) semantics with per-group lr (lr_helper.py:20-21)."""
+        if getattr(self, "exp_avg", None) is None:
+            self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.steps += 1
+        b = self.bounds + [self.n] * 3
+        lr = list(lrs) + [lrs[-1]] * 3
+        bc1 = 1.0 - betas[0] ** self.steps
+        bc2s = math.sqrt(1.0 - betas[1] ** self.steps)
+        call("u2pl_adam_step_f32", self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.n, b[0], b[1], float(lr[0]),
+             float(lr[1]), float(lr[2]), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), float(bc1),
+             float(bc2s), float(grad_scale))
+
+    def adam_views(self, p):
+        """(exp_avg, exp_avg_sq) views shaped / strided like parameter p (allocated on first use)"""
+        if getattr(self, "exp_avg", None) is None:
+            self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        off, n = self._offs[id(p)], p.numel()
+        return (self.exp_avg[off:off + n].as_strided(p.shape, p.stride()),
+                self.exp_avg_sq[off:off + n].as_strided(p.shape, p.stride()))
+
     def ema_from(self, other, decay):
         """self = decay*self + (1-decay)*other  (train_semi.py:543-548)."""
         call("u2pl_ema_update_f32", self.flat, other.flat, self.n, float(decay), float(1 - decay))

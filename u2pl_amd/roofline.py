@@ -138,6 +138,19 @@ def replay_hbm_group(reps=10):
         if "append" in R:
             dd, n, D, ld, mx = R["append"][:5]
             out["bank_append_us"] = timed(lambda: _lib.call("u2pl_bank_append_multi_f32", dd, n, D, ld, mx))
+        if "enqueue" in R and R.get("bank") is not None:
+            # the device-resident enqueue of the last step, replayed on a scratch copy of the ring state and a scratch
+            # storage buffer (a replay on the real bank would append the step's keys ten more times)
+            bank = R["bank"]
+            rows, ld, idx, idx_stride, counts_dev = R["enqueue"]
+            st0 = bank.state.clone()
+            scratch = torch.empty_like(bank.storage)
+            st = st0.clone()
+
+            def enq():
+                _lib.call("u2pl_bank_enqueue_f32", st, scratch, bank.D, rows, ld, idx, idx_stride, None, counts_dev, bank.C)
+            out["bank_append_us"] = timed(enq)
+            del scratch
         if "infonce" in R:
             rep_rows, jobs_dev, njobs, Q, K, temp, valid_seg, groups, keep = R["infonce"]
 

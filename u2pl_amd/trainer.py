@@ -24,7 +24,8 @@ import torch.distributed as dist
 from . import hipops as H
 from . import nn as K
 from .utils import loss_helper as LH
-from .utils.lr_helper import check_sgd_kwargs, load_sgd_state_dict, poly_lr, sgd_state_dict
+from .utils.lr_helper import (adam_state_dict, check_adam_kwargs, check_sgd_kwargs, load_adam_state_dict, load_sgd_state_dict,
+                              poly_lr, sgd_state_dict)
 
 
 def _world():
@@ -135,11 +136,18 @@ class SemiTrainer:
 
     def _init_schedule(self, tr):
         ok = tr["optimizer"]
-        if ok["type"] != "SGD":
-            raise NotImplementedError("the flat-arena step implements torch.optim.SGD (what the reference configs use)")
-        check_sgd_kwargs(ok["kwargs"])
-        self.base_lr = ok["kwargs"]["lr"]
-        self.momentum = ok["kwargs"].get("momentum", 0.0)
+        self.opt_type = ok["type"]
+        if ok["type"] == "SGD":            # lr_helper.py:18-19
+            check_sgd_kwargs(ok["kwargs"])
+            self.momentum = ok["kwargs"].get("momentum", 0.0)
+        elif ok["type"] == "adam":         # lr_helper.py:20-21
+            check_adam_kwargs(ok["kwargs"])
+            self.adam = dict(betas=tuple(ok["kwargs"].get("betas", (0.9, 0.999))), eps=ok["kwargs"].get("eps", 1e-8),
+                             weight_decay=ok["kwargs"].get("weight_decay", 0.0))
+            self.momentum = 0.0
+        else:
+            raise AssertionError("optimizer type is not supported by LightSeg")      # the reference's own message (lr_helper.py:25)
+        self.base_lr = ok["kwargs"].get("lr", 1e-3)
         self.weight_decay = ok["kwargs"].get("weight_decay", 0.0)
         sch = tr["lr_scheduler"]
         self.lr_mode = sch.get("mode", "poly")
@@ -175,12 +183,22 @@ class SemiTrainer:
         m = self.lr_mult
         lrs = getattr(self, "last_lrs", None) or [self.base_lr * k for k in m]    # before the first step: the base lrs
         ref_lrs = [lrs[0]] + ([lrs[2]] if len(m) > 2 else []) + [lrs[1]]            # reference group order: encoder, aux, decoder
+        if self.opt_type == "adam":
+            return adam_state_dict(self._ref_groups(), ref_lrs, self.adam, self.arena.adam_views, self.arena.steps)
         return sgd_state_dict(self._ref_groups(), ref_lrs, self.momentum, self.weight_decay,
                               self.arena.momentum_view, self.arena.steps > 0)
 
     def load_optimizer_state_dict(self, sd):
-        if load_sgd_state_dict(sd, self._ref_groups(), self.arena.momentum_view):
+        if self.opt_type == "adam":
+            self.arena.steps = max(self.arena.steps, load_adam_state_dict(sd, self._ref_groups(), self.arena.adam_views))
+        elif load_sgd_state_dict(sd, self._ref_groups(), self.arena.momentum_view):
             self.arena.steps = max(self.arena.steps, 1)
+
+    def _optimizer_step(self, lrs, grad_scale):
+        if self.opt_type == "adam":
+            self.arena.adam_step(lrs, self.adam["betas"], self.adam["eps"], self.adam["weight_decay"], grad_scale=grad_scale)
+        else:
+            self.arena.sgd_step(lrs, self.momentum, self.weight_decay, grad_scale=grad_scale)
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
@@ -193,7 +211,7 @@ class SemiTrainer:
         # bucketed all-reduce: most buckets were launched from the backward hooks and overlapped with it; this
         # launches the rest and joins them (DDP's mean is folded into the SGD launch)
         self.arena.finish_allreduce()
-        self.arena.sgd_step(lrs, self.momentum, self.weight_decay, grad_scale=1.0 / W)
+        self._optimizer_step(lrs, 1.0 / W)
 
     def train_step(self, image_l, label_l, image_u, epoch, cutmix_boxes=None, randint=None, debug=None):
         cfg = self.cfg
@@ -368,6 +386,7 @@ class SupTrainer:
     _ref_groups = SemiTrainer._ref_groups
     optimizer_state_dict = SemiTrainer.optimizer_state_dict
     load_optimizer_state_dict = SemiTrainer.load_optimizer_state_dict
+    _optimizer_step = SemiTrainer._optimizer_step
 
     def train_step(self, image, label, epoch=0):
         lrs = self._lrs()
@@ -385,7 +404,7 @@ class SupTrainer:
         K.wgrad_stream_sync()
         W = _world()
         self.arena.finish_allreduce()
-        self.arena.sgd_step(lrs, self.momentum, self.weight_decay, grad_scale=1.0 / W)
+        self._optimizer_step(lrs, 1.0 / W)
         z = torch.zeros((), device=loss.device)
         meters = torch.stack((loss.detach(), z, z))
         if W > 1:

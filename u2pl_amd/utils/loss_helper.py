@@ -6,6 +6,8 @@ as the reference's u2pl/utils/loss_helper.py, computed by HIP kernels.
   get_criterion / Criterion / CriterionOhem / OhemCrossEntropy2dTensor
                                  loss_helper.py:238-360, 451-531
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -26,6 +28,15 @@ def compute_unsupervised_loss(predict, target, percent, pred_teacher):
 
 
 LAST_STATS = {}  # counts of the last contrastive call (bench roofline accounting)
+# single-rank key enqueue through the device-resident bank state (u2pl_bank_enqueue_f32, issued before the host sync).  OFF by
+# default: measured on MI355X it does not change the step time (191.6 vs 192.0 ms) and its fixed grid + state-advance launch
+# cost 3.7 us more GPU time than the host-sized append (9.1 vs 5.4 us); the C API is what a non-Python host would drive.
+DEVICE_ENQUEUE = os.environ.get("U2PL_DEVICE_ENQUEUE") is not None
+
+
+def _world():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 def _rows_view(t):
@@ -57,11 +68,20 @@ def contra_memobank_core(rep, lbits, num_labeled, prob_l, prob_u, low_mask, high
     with torch.no_grad():
         ph1 = H.contra_phase1(rep_t_rows, D, D, prob, pstr, lbits, low_mask.contiguous(), high_mask.contiguous(),
                               num_labeled, C, h, w, cfg)
+        device_enqueue = _world() == 1 and rep.is_cuda and isinstance(memobank, H.DeviceMemoryBank) and DEVICE_ENQUEUE
+        if device_enqueue:
+            # single rank: the keys are appended by the device-resident bank from the list lengths ON THE DEVICE, i.e.
+            # before (and under) the host synchronisation below instead of after it
+            memobank.enqueue_device(rep_t_rows, D, ph1.idx[2], ph1.cap, ph1.counts[2])
         # the ONE host sync of the step: the RNG bounds live on the host (loss_helper.py:179-196).  Under a process group
         # the ranks' key counts ride along (gathered on the device first), so the key exchange needs no second sync.
         counts, all_neg = exchange_counts(ph1.counts, C)
         ph1.counts_host = counts
-        new_keys = enqueue_all_classes(memobank, rep_t_rows, D, ph1.idx[2], counts[2], C, all_counts=all_neg)
+        if device_enqueue:
+            memobank.mirror_counts(counts[2])
+            new_keys = [int(counts[2][c]) for c in range(C)]
+        else:
+            new_keys = enqueue_all_classes(memobank, rep_t_rows, D, ph1.idx[2], counts[2], C, all_counts=all_neg)
     valid_classes = [i for i in range(C) if counts[1][i] > 0]
     LAST_STATS.update(n_keys=int(sum(new_keys)), valid_seg=len(valid_classes), njobs=0,
                       Q=int(cfg["num_queries"]), K=int(cfg["num_negatives"]))

@@ -154,8 +154,99 @@ class ArenaSGD:
             g["lr"] = src["lr"]
 
 
+_ADAM_DEFAULTS = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
+                      capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False)
+
+
+def check_adam_kwargs(kw):
+    extra = set(kw) - {"lr", "betas", "eps", "weight_decay", "amsgrad"}
+    if extra:
+        raise ValueError(f"optimizer kwargs not supported by the HIP Adam step: {sorted(extra)}")
+    if kw.get("amsgrad", False):
+        raise NotImplementedError("amsgrad is not implemented by u2pl_adam_step_f32")
+
+
+def adam_state_dict(ref_groups, lrs, hyper, views_of, steps):
+    """torch.optim.Adam.state_dict() layout: state[i] = {step, exp_avg, exp_avg_sq}; groups in the reference's order"""
+    state, groups, idx = {}, [], 0
+    for g, lr in zip(ref_groups, lrs):
+        ids = []
+        for p in g:
+            if steps > 0:
+                m, v = views_of(p)
+                state[idx] = {"step": torch.tensor(float(steps)), "exp_avg": m.detach().cpu().contiguous(),
+                              "exp_avg_sq": v.detach().cpu().contiguous()}
+            ids.append(idx)
+            idx += 1
+        groups.append(dict(_ADAM_DEFAULTS, lr=lr, betas=tuple(hyper["betas"]), eps=hyper["eps"], weight_decay=hyper["weight_decay"],
+                           params=ids))
+    return {"state": state, "param_groups": groups}
+
+
+def load_adam_state_dict(sd, ref_groups, views_of):
+    """copies exp_avg / exp_avg_sq back into the arenas; returns the step count stored in the file (0: never stepped)"""
+    params = [p for g in ref_groups for p in g]
+    if sum(len(g["params"]) for g in sd["param_groups"]) != len(params):
+        raise ValueError("optimizer_state has a different number of parameters than this model")
+    order = [i for g in sd["param_groups"] for i in g["params"]]
+    steps = 0
+    for p, i in zip(params, order):
+        st = sd["state"].get(i, sd["state"].get(str(i)))
+        if st is not None and st.get("exp_avg") is not None:
+            m, v = views_of(p)
+            m.copy_(st["exp_avg"].to(m.device))
+            v.copy_(st["exp_avg_sq"].to(v.device))
+            steps = max(steps, int(float(st["step"])))
+    return steps
+
+
+class ArenaAdam(ArenaSGD):
+    """`get_optimizer` for `type: adam` (lr_helper.py:20-21): torch.optim.Adam's surface on the flat arena"""
+
+    def __init__(self, params_list, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, **kw):
+        from .. import nn as K
+        check_adam_kwargs(dict(kw, lr=lr))
+        params_list = list(params_list)
+        if len(params_list) > 3:
+            raise ValueError("u2pl_adam_step_f32 has three learning-rate segments (encoder / aux head / decoder)")
+        self.hyper = dict(betas=tuple(betas), eps=float(eps), weight_decay=float(weight_decay))
+        for g in params_list:
+            g["params"] = list(g["params"])
+            for k, v in dict(_ADAM_DEFAULTS, lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay).items():
+                g.setdefault(k, v)
+        self.param_groups = params_list
+        self.groups = [g["params"] for g in params_list]
+        owner = getattr(self.groups[0][0], "_u2pl_owner", None)
+        if owner is not None:
+            self.arena = owner.arena
+        else:
+            self.arena = K.ParamArena(self.groups)
+            for g in self.groups:
+                for p in g:
+                    p._u2pl_owner = self
+
+    def step(self):
+        import torch.distributed as dist
+        from .. import nn as K
+        K.wgrad_stream_sync()
+        W = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.arena.finish_allreduce()
+        self.arena.adam_step([g["lr"] for g in self.param_groups], self.hyper["betas"], self.hyper["eps"],
+                             self.hyper["weight_decay"], grad_scale=1.0 / W)
+
+    def state_dict(self):
+        return adam_state_dict(self.groups, [g["lr"] for g in self.param_groups], self.hyper, self.arena.adam_views, self.arena.steps)
+
+    def load_state_dict(self, sd):
+        self.arena.steps = max(self.arena.steps, load_adam_state_dict(sd, self.groups, self.arena.adam_views))
+        for g, src in zip(self.param_groups, sd["param_groups"]):
+            g["lr"] = src["lr"]
+
+
 def get_optimizer(parms, cfg_optim):
-    """lr_helper.py:12-27"""
-    if cfg_optim["type"] != "SGD":
-        raise NotImplementedError("only `SGD` (what every reference config uses) has a HIP step; got %r" % cfg_optim["type"])
-    return ArenaSGD(parms, **cfg_optim["kwargs"])
+    """lr_helper.py:12-27: `SGD` and `adam` (anything else is the reference's "optimizer type is not supported" assert)"""
+    if cfg_optim["type"] == "SGD":
+        return ArenaSGD(parms, **cfg_optim["kwargs"])
+    if cfg_optim["type"] == "adam":
+        return ArenaAdam(parms, **cfg_optim["kwargs"])
+    raise AssertionError("optimizer type is not supported by LightSeg")

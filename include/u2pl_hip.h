@@ -322,6 +322,9 @@ int u2pl_adam_step_f32(float* p, const float* g, float* exp_avg, float* exp_avg_
  * Returns 1001 when the shape is not covered (fall back to entropy_up + select + reliability_apply). */
 /* kernel launches issued by this library so far (host counter; bench.py: kernel launches per step vs C-ABI calls) */
 size_t u2pl_kernel_launches(void);
+/* (debug) arm per-block start / end stamps of the three phase-1 kernels: buf = device uint32 [3][4096][2] in 100 MHz
+ * ticks (kernel 0 classify, 1 prototype stream, 2 tail); NULL disarms.  tools/bench_phase1_blocks.py reads it. */
+int u2pl_debug_phase1_times(unsigned* buf);
 size_t u2pl_reliability_fused_workspace_bytes(int G);
 size_t u2pl_reliability_fused_cand_floats(long n_px, int G);
 int u2pl_reliability_fused(const float* logits_low, long sn, long sc, long sh, long sw, int B, int C, int h, int w,

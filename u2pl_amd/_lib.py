@@ -8,7 +8,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libu2pl_hip.so")
+# (U2PL_LIB_PATH: an alternative build of the same library, for A/B measurements of build-time variants)
+LIB_PATH = os.environ.get("U2PL_LIB_PATH") or os.path.join(_HERE, "lib", "libu2pl_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "u2pl_hip.h")
 
 _CT = {

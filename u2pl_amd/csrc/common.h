@@ -23,6 +23,15 @@ extern unsigned long long u2pl_kernel_launch_count;
         hipLaunchKernelGGL(__VA_ARGS__);        \
     } while (0)
 
+// HBM-bound elementwise / transform kernels (BatchNorm apply + backward, column reductions, Winograd transforms) are capped
+// at U2PL_HBM_MAXW waves per SIMD when that macro is defined at build time: the cap leaves wave slots (and all of the LDS)
+// on every CU for an MFMA-bound kernel of another stream to run beside them (experiment: see DESIGN section 3).
+#ifdef U2PL_HBM_MAXW
+#define U2PL_HBM_KERNEL __attribute__((amdgpu_waves_per_eu(1, U2PL_HBM_MAXW)))
+#else
+#define U2PL_HBM_KERNEL
+#endif
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int grid_for(long n, int block, int max_blocks = 256 * 16) {
     long g = (n + block - 1) / block;

@@ -19,6 +19,15 @@
 // prob is addressed through strides so NCHW or NHWC both work.
 // ---------------------------------------------------------------------------
 #define MAXC 32
+// (debug) per-block start / end times of the phase-1 kernels: u2pl_debug_phase1_times(buf) arms it, NULL disarms.
+// buf: uint32 [3][4096][2] (kernel 0 = classify, 1 = prototype stream, 2 = tail), 100 MHz ticks.
+__device__ unsigned* g_p1_dbg = nullptr;
+U2PL_API int u2pl_debug_phase1_times(unsigned* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_p1_dbg), &buf, sizeof(buf));
+}
+#define P1_DBG_START(k) unsigned dbg_t0_ = 0; if (g_p1_dbg && threadIdx.x == 0) dbg_t0_ = (unsigned)wall_clock64();
+#define P1_DBG_MARK(k, slot, b) if (g_p1_dbg && threadIdx.x == 0) g_p1_dbg[((k) * 4096 + 1024 * (slot) + (b)) * 2] = (unsigned)wall_clock64();
+#define P1_DBG_END(k, b) if (g_p1_dbg && threadIdx.x == 0 && (b) < 4096) { g_p1_dbg[((k) * 4096 + (b)) * 2] = dbg_t0_; g_p1_dbg[((k) * 4096 + (b)) * 2 + 1] = (unsigned)wall_clock64(); }
 #define CP_PIX 256          // pixels per block of the classify / compaction kernels (one per thread)
 #define PF_MAXBLK 4096      // prototype partial blocks a finish can order
 // The classify kernel also counts, per block of CP_PIX pixels, the members of every (kind, class) list:
@@ -86,6 +95,7 @@ __global__ __launch_bounds__(CP_PIX) void k_contra_classify_rows(
     __shared__ __attribute__((aligned(16))) float rows[CP_PIX * MAXC];
     __shared__ unsigned cnt[3 * MAXC];
     __shared__ int any_s;
+    P1_DBG_START(0)
     if (threadIdx.x < 3 * MAXC) cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) any_s = 0;
     __syncthreads();
@@ -106,9 +116,11 @@ __global__ __launch_bounds__(CP_PIX) void k_contra_classify_rows(
     }
     if (__ballot(lb != 0) && (threadIdx.x & 63) == 0) any_s = 1;
     __syncthreads();
+    P1_DBG_MARK(0, 1, blockIdx.x)
     if (!any_s) {        // block-uniform
         if (p < total) { abits[p] = 0; lowbits[p] = 0; nbits[p] = 0; }
         if (blk && threadIdx.x < 3 * MAXC) blk[(long)threadIdx.x * nblk + blockIdx.x] = 0;
+        P1_DBG_END(0, blockIdx.x)
         return;
     }
     const bool lo = lb != 0 && lmv != 0.f, hi = lb != 0 && hmv != 0.f;
@@ -135,6 +147,7 @@ __global__ __launch_bounds__(CP_PIX) void k_contra_classify_rows(
                 if (hi && pi < thr_n && cmask) ng |= 1u << i;
             }
         }
+        P1_DBG_MARK(0, 2, blockIdx.x)
         abits[p] = a;
         lowbits[p] = l;
         nbits[p] = ng;
@@ -146,7 +159,9 @@ __global__ __launch_bounds__(CP_PIX) void k_contra_classify_rows(
     }
     if (!blk) return;
     __syncthreads();
+    P1_DBG_MARK(0, 3, blockIdx.x)
     if (threadIdx.x < 3 * MAXC) blk[(long)threadIdx.x * nblk + blockIdx.x] = cnt[threadIdx.x];
+    P1_DBG_END(0, blockIdx.x)
 }
 
 U2PL_API int u2pl_contra_classify(const float* prob, long sn, long sc, long sp, const unsigned* lbits,
@@ -311,54 +326,93 @@ __global__ __launch_bounds__(P1_T) void k_phase1_tail(const unsigned* __restrict
                                                       const float* __restrict__ partial, int D, int npb, int C,
                                                       const unsigned* __restrict__ flags, float* __restrict__ proto) {
     __shared__ unsigned wcnt[16][2 * MAXC];      // write role: per-wave counts -> exclusive offsets
+    __shared__ unsigned long long msk[16][2 * MAXC];   // write role: per-wave membership masks of the 2 * MAXC lists
     __shared__ unsigned base_s[2 * MAXC];        // write role: list offset in front of this block
     __shared__ unsigned pres_s[2];
     __shared__ double sh[16][64];                // finish role
     __shared__ int act[PF_MAXBLK];
     __shared__ int wtot[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    P1_DBG_START(2)
     if ((int)blockIdx.x < nwb) {
         // ------------------------------------------------------------ compaction write
         const long p = blockIdx.x * (long)P1_T + t;
         unsigned v[2];
         v[0] = p < P ? b0[p] : 0;
         v[1] = p < P ? b2[p] : 0;
-        if (t < 2 * MAXC) {
-#pragma unroll
-            for (int w2 = 0; w2 < 16; ++w2) wcnt[w2][t] = 0;
-            base_s[t] = 0;
-        }
+        // membership masks: lane l of wave w owns msk[w][l] = the 64-bit mask of the wave's pixels that are on list
+        // l = kind * MAXC + class.  They are built with one LDS atomic per SET bit of a pixel (1-2 per kind) instead of one
+        // ballot per present class: a block of the dense labeled image has all C classes in every wave, and two loops of
+        // 2 C ballot rounds (count, then write) were 5 of the block's 9 us -- the tail of the launch.
+        msk[wave][lane] = 0ull;
+        if (t < 2 * MAXC) base_s[t] = 0;
         if (t < 2) pres_s[t] = 0;
         __syncthreads();
-        unsigned pres[2];
+        P1_DBG_MARK(2, 1, blockIdx.x)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            pres[k] = wave_or_uniform(v[k]);
-            for (unsigned x = pres[k]; x; x &= x - 1) {
-                const int c = __ffs(x) - 1;
-                const unsigned long long m = __ballot((v[k] >> c) & 1u);
-                if (lane == 0) wcnt[wave][k * MAXC + c] = (unsigned)__popcll(m);
+        for (int k = 0; k < 2; ++k)
+            for (unsigned x = v[k]; x; x &= x - 1) atomicOr(&msk[wave][k * MAXC + __ffs(x) - 1], 1ull << lane);
+        __syncthreads();
+        {
+            const unsigned long long m = msk[wave][lane];
+            wcnt[wave][lane] = (unsigned)__popcll(m);
+            const unsigned long long pm = __ballot(m != 0ull);      // bit k * MAXC + c: list present in this wave
+            if (lane == 0) {
+                if ((unsigned)pm) atomicOr(&pres_s[0], (unsigned)pm);
+                if ((unsigned)(pm >> 32)) atomicOr(&pres_s[1], (unsigned)(pm >> 32));
             }
-            if (lane == 0 && pres[k]) atomicOr(&pres_s[k], pres[k]);
         }
         __syncthreads();
-        {   // offsets in front of this block: list r of the block's present lists is summed by wave (r mod 16)
+        {   // offsets in front of this block: list r of the block's present lists is summed by wave (r mod 16).  A wave's
+            // lists (<= 4 of the <= 2 * MAXC present ones) are summed TOGETHER: all their loads are in flight at once (one
+            // memory round trip; one list after the other was three for the block with the most lists -- the launch's tail)
             const int first = blockIdx.x * (P1_T / CP_PIX);          // count rows are per CP_PIX pixels
-            int r = 0;
+            int r = 0, nm = 0, sm[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int k = 0; k < 2; ++k)
                 for (unsigned x = pres_s[k]; x; x &= x - 1, ++r) {
                     if ((r & 15) != wave) continue;
-                    const int c = __ffs(x) - 1;
-                    const unsigned sum = p1_row_sum(blk + ((long)(2 * k) * MAXC + c) * nblk, first, lane);
-                    if (lane == 0) base_s[k * MAXC + c] = sum;
+                    const int sidx = k * MAXC + __ffs(x) - 1;
+                    if (nm == 0) sm[0] = sidx; else if (nm == 1) sm[1] = sidx; else if (nm == 2) sm[2] = sidx; else sm[3] = sidx;
+                    ++nm;
                 }
+            if (nm > 0) {
+                const unsigned* rw[4];
+                int nn[4];
+                unsigned a[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    rw[q] = blk + ((long)(2 * (sm[q] / MAXC)) * MAXC + sm[q] % MAXC) * nblk;
+                    nn[q] = q < nm ? first : 0;
+                }
+                for (int i0 = 0; i0 < first; i0 += 8 * 64) {
+                    unsigned v[4][8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + u * 64 + lane;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q][u] = i < nn[q] ? rw[q][i] : 0u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) a[q] += v[q][u];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned sum = wave_sum_u(a[q]);
+                    if (lane == 0 && q < nm) base_s[sm[q]] = sum;
+                }
+            }
         }
-        for (int r = blockIdx.x * 16 + wave; r < 3 * MAXC; r += nwb * 16) {   // list lengths (all three kinds) for the host / the InfoNCE jobs
+        // list lengths (all three kinds) for the host / the InfoNCE jobs: summed by the LAST write blocks (under quirk Q0 the
+        // trailing images carry no lists, so these blocks have no offsets to sum; the first blocks are the dense ones)
+        for (int r = (nwb - 1 - (int)blockIdx.x) * 16 + wave; r < 3 * MAXC; r += nwb * 16) {
             const unsigned sum = p1_row_sum(blk + (long)r * nblk, nblk, lane);
             if (lane == 0) counts[r] = sum;
         }
         __syncthreads();
+        P1_DBG_MARK(2, 2, blockIdx.x)
         if (t < 2 * MAXC) {
             unsigned run = base_s[t];
 #pragma unroll
@@ -372,15 +426,12 @@ __global__ __launch_bounds__(P1_T) void k_phase1_tail(const unsigned* __restrict
         const unsigned long long lt = lanemask_lt();
 #pragma unroll
         for (int k = 0; k < 2; ++k)
-            for (unsigned x = pres[k]; x; x &= x - 1) {
+            for (unsigned x = v[k]; x; x &= x - 1) {       // this pixel's own lists: rank within the wave from the list's mask
                 const int c = __ffs(x) - 1;
-                const bool on = (v[k] >> c) & 1u;
-                const unsigned long long m = __ballot(on);
-                if (on) {
-                    const unsigned pos = wcnt[wave][k * MAXC + c] + (unsigned)__popcll(m & lt);
-                    idx[((long)(2 * k) * MAXC + c) * cap + pos] = (int)p;
-                }
+                const unsigned pos = wcnt[wave][k * MAXC + c] + (unsigned)__popcll(msk[wave][k * MAXC + c] & lt);
+                idx[((long)(2 * k) * MAXC + c) * cap + pos] = (int)p;
             }
+        P1_DBG_END(2, blockIdx.x)
         return;
     }
     // ---------------------------------------------------------------- prototype finish (ordered, double precision)
@@ -405,6 +456,7 @@ __global__ __launch_bounds__(P1_T) void k_phase1_tail(const unsigned* __restrict
         basei += tot;
         __syncthreads();
     }
+    P1_DBG_MARK(2, 1, blockIdx.x)
     const int n_act = basei;
     double acc = 0.0;
     if (d < D) {
@@ -428,12 +480,14 @@ __global__ __launch_bounds__(P1_T) void k_phase1_tail(const unsigned* __restrict
     }
     sh[rg][cl] = acc;
     __syncthreads();
+    P1_DBG_MARK(2, 2, blockIdx.x)
     if (rg == 0 && d < D) {
         double tsum = 0.0;
 #pragma unroll
         for (int gq = 0; gq < 16; ++gq) tsum += sh[gq][cl];
         proto[(long)c * D + d] = n ? (float)(tsum / (double)n) : __uint_as_float(0x7fc00000u);
     }
+    P1_DBG_END(2, blockIdx.x)
 }
 
 U2PL_API size_t u2pl_compact_workspace_bytes(long P) {
@@ -469,87 +523,90 @@ U2PL_API int u2pl_compact_lists(const unsigned* abits, const unsigned* lowbits, 
 // round) and wave W streams pixels W, W + NW, W + 2 NW, ... -- every wave gets the same share of every image, so the
 // dense labeled image 0, the 20 %-dense unlabeled image B and the empty images in between (quirk Q0) no longer make
 // heavy and idle blocks (contiguous 128-pixel blocks: 582 busy blocks of 4 row rounds over 512 slots = two rounds
-// of blocks, 28 us; now ~22 rows = 3 row rounds per wave).  A wave fetches the bits of all its <= 128 pixels with one
-// batch of loads, keeps 8 row loads in flight while the previous 8 are accumulated, and the four waves of a block
-// are combined through LDS in a fixed order => deterministic.  Blocks without members only write flag 0.
+// of blocks, 28 us; now ~22 rows per wave).  A wave fetches the bits of all its <= 128 pixels with one batch of loads,
+// the block pools its members (see proto_stream_body), every wave requests all of its rows in one batch, and the
+// waves of a block are combined through LDS in a fixed order => deterministic.  Blocks without members only write flag 0.
 // Then an ordered double-precision finish over the flagged blocks.
 // ---------------------------------------------------------------------------
 #define PR_BLOCKS 256          // x PR_WPB waves: one 8-wave block per CU (the register file admits two waves per SIMD either way;
 #define PR_WPB 8               // eight waves per block halve the number -- and the bytes -- of the block partials the finish reads)
+// the streaming body: block `pblk` of `npblk` prototype blocks; bits0 / bits1 = class bits of this lane's two pixels
+// (pixels W + NW * lane and W + NW * (64 + lane) of wave W = pblk * PR_WPB + wave, NW = npblk * PR_WPB)
+#define PR_SLOTS 32            // member rows a wave keeps in flight (one round of loads for up to 8 * 32 members per block)
 template <int CT>
-__global__ __launch_bounds__(64 * PR_WPB, 2) void k_proto_stream(const float* __restrict__ rows, long ld, int D,
-                                                         const unsigned* __restrict__ lowbits, long P,
-                                                         float* __restrict__ partial, unsigned* __restrict__ flags,
-                                                         unsigned rows_bytes) {
-    extern __shared__ float red[];   // [4][CT][D]: waves 4..7 hand their sums to waves 0..3, whose four sums are then combined
-    __shared__ int any_s;
+__device__ __forceinline__ void proto_stream_body(const float* __restrict__ rows, long ld, int D, unsigned bits0, unsigned bits1,
+                                                  float* __restrict__ partial, unsigned* __restrict__ flags,
+                                                  unsigned rows_bytes, float* red, int pblk, int npblk) {
+    // The block POOLS its member pixels before streaming: the members of its 8 * 128 pixel slots are compacted, in slot
+    // order, into an LDS list and wave w takes entries w, w + 8, w + 16, ...  A wave's own 128 slots hold 22 +- 5 members
+    // at 769^2 (the slowest of a block's eight waves had ~30 % more rows than the mean and the block waits for it);
+    // pooled, every wave of a block streams the same number of rows (+- 1).  All of a wave's rows (<= PR_SLOTS, else
+    // further rounds) are requested in ONE batch: one memory round trip instead of three to five dependent batches of 8.
+    __shared__ int wcnt_s[2 * PR_WPB];
+    __shared__ unsigned short lst_slot[PR_WPB * 128];
+    __shared__ unsigned lst_bits[PR_WPB * 128];
     // (readfirstlane: the wave index is uniform, which keeps every row base in scalar registers -- a row load is then
-    // "scalar base + per-lane offset" and needs no address VGPRs that could alias a load still in flight)
+    // "scalar base + per-lane offset" and needs no address VGPRs)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long NW = (long)gridDim.x * PR_WPB;            // waves of the launch (host: P <= 128 * NW)
-    const long W = (long)blockIdx.x * PR_WPB + wave;     // this wave streams pixels W + NW * j, j = 0 .. 127
-    const long pa = W + NW * lane, pb = W + NW * (64 + lane);   // lane j holds the class bits of pixels j and 64 + j
-    const unsigned bits0 = pa < P ? lowbits[pa] : 0u;
-    const unsigned bits1 = pb < P ? lowbits[pb] : 0u;
-    unsigned long long todo0 = __ballot(bits0 != 0), todo1 = __ballot(bits1 != 0);
-    if (threadIdx.x == 0) any_s = 0;
+    const long NW = (long)npblk * PR_WPB;                // waves of the launch (host: P <= 128 * NW)
+    const unsigned long long m0 = __ballot(bits0 != 0), m1 = __ballot(bits1 != 0);
+    if (lane == 0) { wcnt_s[2 * wave] = __popcll(m0); wcnt_s[2 * wave + 1] = __popcll(m1); }
     __syncthreads();
-    if (lane == 0 && (todo0 | todo1)) any_s = 1;
-    __syncthreads();
-    if (!any_s) {
-        if (threadIdx.x == 0) flags[blockIdx.x] = 0;
+    int base = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 2 * PR_WPB; ++i) {
+        const int cw = wcnt_s[i];
+        if (i < 2 * wave) base += cw;
+        total += cw;
+    }
+    total = __builtin_amdgcn_readfirstlane(total);
+    if (!total) {
+        if (threadIdx.x == 0) flags[pblk] = 0;
         return;
     }
+    {
+        const unsigned long long lt = lanemask_lt();
+        if (bits0) { const int pos = base + __popcll(m0 & lt); lst_slot[pos] = (unsigned short)(wave * 128 + lane); lst_bits[pos] = bits0; }
+        if (bits1) { const int pos = base + __popcll(m0) + __popcll(m1 & lt); lst_slot[pos] = (unsigned short)(wave * 128 + 64 + lane); lst_bits[pos] = bits1; }
+    }
+    __syncthreads();
+    P1_DBG_MARK(1, 1, pblk)
     const int d = lane * 4;
     const bool act = d < D;       // D <= 256
-    const unsigned doff_b = act ? d * 4 : 0;           // byte offset of the lane's channels (exhausted queues request pixel 0's row and ignore it)
+    const unsigned doff_b = act ? d * 4 : 0;           // byte offset of the lane's channels
     const long ldb = ld * 4;
     const __amdgpu_buffer_rsrc_t rrows = make_rsrc(rows, rows_bytes);
     float4 acc[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 va[8], vb[8];
-    unsigned ba[8], bb[8];
-// every slot of a batch issues its row load UNCONDITIONALLY (an exhausted queue re-reads pixel 0's row and ignores it):
-// see k_infonce -- a load under an `if` would make the compiler wait for ALL loads (vmcnt(0)) before each accumulate
-// and the two batches would no longer overlap.  All of this is wave-uniform scalar code.
-#define PROTO_FETCH(V, B)                                                                     \
-    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                           \
-        const bool h0 = todo0 != 0, h1 = !h0 && todo1 != 0;                                   \
-        const int s0 = h0 ? __ffsll((long long)todo0) - 1 : 0;                                \
-        const int s1 = h1 ? __ffsll((long long)todo1) - 1 : 0;                                \
-        const unsigned b0_ = __builtin_amdgcn_readlane(bits0, s0);                            \
-        const unsigned b1_ = __builtin_amdgcn_readlane(bits1, s1);                            \
-        B[u] = h0 ? b0_ : (h1 ? b1_ : 0u);                                                    \
-        const long pix_ = h0 ? W + NW * s0 : (h1 ? W + NW * (64 + s1) : 0L);                  \
-        if (h0) todo0 &= todo0 - 1;                                                           \
-        if (h1) todo1 &= todo1 - 1;                                                           \
-        const int rowoff_ = __builtin_amdgcn_readfirstlane((int)(pix_ * ldb));   /* P * ld * 4 < 2^31 (host check) */ \
-        V[u] = buf_load4s(rrows, (int)doff_b, rowoff_);   /* SGPR row offset + constant per-lane offset: no address VGPRs */ \
+    for (int e0 = 0; e0 < total; e0 += PR_WPB * PR_SLOTS) {
+        // lane u < PR_SLOTS holds entry e0 + wave + 8 u of the block's list; its fields reach the scalar unit by readlane
+        const int e = e0 + wave + PR_WPB * lane;
+        const bool mine = lane < PR_SLOTS && e < total;
+        const unsigned my_slot = mine ? lst_slot[e] : 0u, my_bits = mine ? lst_bits[e] : 0u;
+        const int n_mine = __popcll(__ballot(mine));      // uniform
+        float4 V[PR_SLOTS];
+#pragma unroll
+        for (int u = 0; u < PR_SLOTS; ++u)
+            if (u < n_mine) {
+                const unsigned sl = __builtin_amdgcn_readlane(my_slot, u);
+                const long pix = (long)pblk * PR_WPB + (sl >> 7) + NW * (long)(sl & 127u);
+                const int rowoff = __builtin_amdgcn_readfirstlane((int)(pix * ldb));     // P * ld * 4 < 2^31 (host check)
+                V[u] = buf_load4s(rrows, (int)doff_b, rowoff);
+            }
+#pragma unroll
+        for (int u = 0; u < PR_SLOTS; ++u)
+            if (u < n_mine) {
+                const unsigned B = __builtin_amdgcn_readlane(my_bits, u);
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    if ((B >> c) & 1u) {   // scalar branch: the asm keeps it from being if-converted
+                        asm volatile("");
+                        acc[c].x += V[u].x; acc[c].y += V[u].y; acc[c].z += V[u].z; acc[c].w += V[u].w;
+                    }
+            }
     }
-#define PROTO_ACC(V, B)                                                                       \
-    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                           \
-        if (B[u]) {                                                                           \
-            _Pragma("unroll") for (int c = 0; c < CT; ++c)                                    \
-                if ((B[u] >> c) & 1u) {  /* scalar branch: the asm keeps it from being if-converted */ \
-                    asm volatile("");                                                         \
-                    acc[c].x += V[u].x; acc[c].y += V[u].y; acc[c].z += V[u].z; acc[c].w += V[u].w; \
-                }                                                                             \
-        }                                                                                     \
-    }
-    PROTO_FETCH(va, ba)
-    while (true) {
-        const bool more_b = (todo0 | todo1) != 0;
-        PROTO_FETCH(vb, bb)
-        PROTO_ACC(va, ba)
-        if (!more_b) break;
-        const bool more_a = (todo0 | todo1) != 0;
-        PROTO_FETCH(va, ba)
-        PROTO_ACC(vb, bb)
-        if (!more_a) break;
-    }
-#undef PROTO_FETCH
-#undef PROTO_ACC
+    P1_DBG_MARK(1, 2, pblk)
     if (act && wave >= 4) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) *(float4*)(red + ((long)(wave - 4) * CT + c) * D + d) = acc[c];
@@ -568,7 +625,8 @@ __global__ __launch_bounds__(64 * PR_WPB, 2) void k_proto_stream(const float* __
         for (int c = 0; c < CT; ++c) *(float4*)(red + ((long)wave * CT + c) * D + d) = acc[c];
     }
     __syncthreads();
-    float* out = partial + (long)blockIdx.x * CT * D;
+    P1_DBG_MARK(1, 3, pblk)
+    float* out = partial + (long)pblk * CT * D;
     for (int i = threadIdx.x; i < CT * D / 4; i += blockDim.x) {
         const float4 a = ((float4*)red)[i], b2 = ((float4*)red)[CT * D / 4 + i];
         const float4 c2 = ((float4*)red)[2 * CT * D / 4 + i], e = ((float4*)red)[3 * CT * D / 4 + i];
@@ -577,8 +635,24 @@ __global__ __launch_bounds__(64 * PR_WPB, 2) void k_proto_stream(const float* __
         r.z = (a.z + b2.z) + (c2.z + e.z); r.w = (a.w + b2.w) + (c2.w + e.w);
         ((float4*)out)[i] = r;
     }
-    if (threadIdx.x == 0) flags[blockIdx.x] = 1;
+    if (threadIdx.x == 0) flags[pblk] = 1;
 }
+template <int CT>
+__global__ __launch_bounds__(64 * PR_WPB) void k_proto_stream(const float* __restrict__ rows, long ld, int D,
+                                                         const unsigned* __restrict__ lowbits, long P,
+                                                         float* __restrict__ partial, unsigned* __restrict__ flags,
+                                                         unsigned rows_bytes) {
+    extern __shared__ float red[];   // [4][CT][D]: waves 4..7 hand their sums to waves 0..3, whose four sums are then combined
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long NW = (long)gridDim.x * PR_WPB, W = (long)blockIdx.x * PR_WPB + wave;
+    const long pa = W + NW * lane, pb = W + NW * (64 + lane);   // lane j holds the class bits of pixels j and 64 + j
+    P1_DBG_START(1)
+    const unsigned bits0 = pa < P ? lowbits[pa] : 0u;
+    const unsigned bits1 = pb < P ? lowbits[pb] : 0u;
+    proto_stream_body<CT>(rows, ld, D, bits0, bits1, partial, flags, rows_bytes, red, (int)blockIdx.x, (int)gridDim.x);
+    P1_DBG_END(1, blockIdx.x)
+}
+
 // grid (C, D/64), 1024 threads: 64 channels x 16 row groups; the flagged blocks are first compacted (in
 // ascending order) into an LDS list so that the partial loads are independent (8 in flight per thread)
 __global__ __launch_bounds__(1024) void k_proto_finish(const float* __restrict__ partial, int D,
@@ -681,13 +755,16 @@ U2PL_API int u2pl_contra_phase1(const float* prob, long sn, long sc, long sp, co
     const int npb = proto_blocks(P);
     const long rb = ((P - 1) * ld + D) * 4;
     if (D % 4 || D > 256 || npb > PF_MAXBLK || rb >= (1L << 31) || !(C == 19 || C == 21 || C == 32)) return U2PL_EINVAL;
-    int rc = u2pl_contra_classify(prob, sn, sc, sp, lbits, low_mask, high_mask, N2, num_labeled, C, h, w, thr_p, thr_n,
-                                  low_rank, high_rank, abits, lowbits, nbits, workspace, stream);
-    if (rc) return rc;
     const unsigned* blk = (const unsigned*)workspace;
     const int nblk = cdiv(P, CP_PIX);
     float* partial = (float*)((char*)workspace + ((u2pl_compact_workspace_bytes(P) + 255) & ~(size_t)255));
     unsigned* flags = (unsigned*)(partial + (size_t)npb * C * D);
+    // (classify and the prototype stream are independent -- the low-valid bits are label bits & low mask -- but running them
+    // as two roles of ONE launch was measured SLOWER: 34.1 us vs 19.2 + 10.4 us; the classify blocks inherit the prototype
+    // role's register / LDS footprint and one-block-per-CU residency)
+    int rc = u2pl_contra_classify(prob, sn, sc, sp, lbits, low_mask, high_mask, N2, num_labeled, C, h, w, thr_p, thr_n,
+                                  low_rank, high_rank, abits, lowbits, nbits, workspace, stream);
+    if (rc) return rc;
     const size_t lds = (size_t)4 * C * D * sizeof(float);
 #define P1_PROTO(CT)                                                                                             \
     case CT: {                                                                                                   \

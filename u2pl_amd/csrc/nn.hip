@@ -51,7 +51,7 @@ struct BnBwdOp {  // g = dy*[y>0]*drop ; v0 = g, v1 = g * xhat     (BN backward 
 // grid = (row blocks, segments, column slabs of 64 float4): enough blocks in flight to cover HBM latency
 // even when the tensor has few rows (layer3/4: 37636 rows x 1024-2048 channels)
 template <class Op>
-__global__ void k_colreduce_partial(Op op, long Mseg, int C, float* __restrict__ partial) {
+__global__ U2PL_HBM_KERNEL void k_colreduce_partial(Op op, long Mseg, int C, float* __restrict__ partial) {
     __shared__ float4 sh0[256], sh1[256];
     const int C4 = C >> 2;
     const int slab0 = blockIdx.z * 64;
@@ -232,7 +232,7 @@ U2PL_API int u2pl_bn_eval_invstd_f32(const float* running_var, int C, float eps,
 }
 
 // y = [relu]( (x - mean)*invstd*gamma + beta [+ res] ) [* drop[n][c]]
-__global__ void k_bn_apply(const float* __restrict__ x, long ldx, const float* __restrict__ mean,
+__global__ U2PL_HBM_KERNEL void k_bn_apply(const float* __restrict__ x, long ldx, const float* __restrict__ mean,
                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                            const float* __restrict__ beta, const float* __restrict__ res, long ldr, int relu,
                            const float* __restrict__ drop, long rows_per_image, float* __restrict__ y, long ldy,
@@ -265,7 +265,7 @@ U2PL_API int u2pl_bn_apply_f32(const float* x, long ldx, const float* mean, cons
 
 // g = dy*[y>0]*drop ; dres = g ; dx = gamma*invstd*(g - S0/cnt - xhat*S1/cnt)  (train)
 //                                dx = gamma*invstd*g                           (eval: sums == NULL)
-__global__ void k_bn_bwd_apply(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
+__global__ U2PL_HBM_KERNEL void k_bn_bwd_apply(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
                                const float* __restrict__ y, long ldy, const float* __restrict__ mean,
                                const float* __restrict__ invstd, const float* __restrict__ gamma,
                                const float* __restrict__ drop, long rows_per_image,

@@ -124,7 +124,7 @@ __device__ __forceinline__ void tile_coords(const WinoGeom& g, long t, int& n, i
 
 // ---- input transform: one thread per (tile, 4 channels) ----------------------------------------------------
 template <int MT>
-__global__ __launch_bounds__(256) void k_wino_input(const float* __restrict__ x, long ldx, unsigned xbytes, WinoGeom g,
+__global__ __launch_bounds__(256) U2PL_HBM_KERNEL void k_wino_input(const float* __restrict__ x, long ldx, unsigned xbytes, WinoGeom g,
                                                     float* __restrict__ V) {
     constexpr int A = WinoT<MT>::A;
     const int C4 = g.C >> 2;
@@ -214,7 +214,7 @@ __global__ void k_wino_weight(const float* __restrict__ w, int O, int C, int tra
 // Optionally produces the following BatchNorm's statistics (pivot-shifted column sums, the two-stage
 // column-reduce partial format [nblk][2][O]): a block covers 256 / (O/4) consecutive tiles x all channels.
 template <int MT>
-__global__ __launch_bounds__(256) void k_wino_output(const float* __restrict__ Mb, WinoGeom g, int O,
+__global__ __launch_bounds__(256) U2PL_HBM_KERNEL void k_wino_output(const float* __restrict__ Mb, WinoGeom g, int O,
                                                      const float* __restrict__ bias, float* __restrict__ y, long ldy,
                                                      float* __restrict__ stats, const float* __restrict__ pivot,
                                                      BnEpi epi) {
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void k_wino_output(const float* __restrict__ M
 // dU[comp] = sum_tiles (A dY_tile A^T)[comp] (x) V[comp]  ;  dg = G^T dU G
 // gy transform: one thread per (tile, 4 channels of dY): MT x MT output-gradient tile -> a x a components
 template <int MT>
-__global__ __launch_bounds__(256) void k_wino_gy(const float* __restrict__ gy, long ldg, unsigned gbytes, WinoGeom g,
+__global__ __launch_bounds__(256) U2PL_HBM_KERNEL void k_wino_gy(const float* __restrict__ gy, long ldg, unsigned gbytes, WinoGeom g,
                                                  float* __restrict__ Mg) {
     constexpr int A = WinoT<MT>::A;
     const int C4 = g.C >> 2;

@@ -323,7 +323,8 @@ int u2pl_adam_step_f32(float* p, const float* g, float* exp_avg, float* exp_avg_
 /* kernel launches issued by this library so far (host counter; bench.py: kernel launches per step vs C-ABI calls) */
 size_t u2pl_kernel_launches(void);
 /* (debug) arm per-block start / end stamps of the three phase-1 kernels: buf = device uint32 [3][4096][2] in 100 MHz
- * ticks (kernel 0 classify, 1 prototype stream, 2 tail); NULL disarms.  tools/bench_phase1_blocks.py reads it. */
+ * ticks (kernel 0 classify, 1 prototype stream, 2 tail); NULL disarms.  Only in a -DU2PL_P1_DBG build of the library
+ * (U2PL_EINVAL otherwise); tools/bench_phase1_blocks.py reads it. */
 int u2pl_debug_phase1_times(unsigned* buf);
 size_t u2pl_reliability_fused_workspace_bytes(int G);
 size_t u2pl_reliability_fused_cand_floats(long n_px, int G);

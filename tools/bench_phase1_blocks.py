@@ -1,5 +1,6 @@
 """Block timelines of the three phase-1 kernels of the contrastive loss at config-3 sizes (debug stamps armed through
-u2pl_debug_phase1_times).  GPU only."""
+u2pl_debug_phase1_times).  GPU only.  Needs the instrumented build of the library:
+    python -m u2pl_amd.build_ext --variant p1dbg -DU2PL_P1_DBG"""
 import json
 import os
 import sys
@@ -7,7 +8,9 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["U2PL_LIB_PATH"] = os.path.join(ROOT, "u2pl_amd", "lib", "variants", "libu2pl_hip_p1dbg.so")
 from u2pl_amd import hipops as H, _lib  # noqa: E402
 from u2pl_amd.utils import loss_helper as LH  # noqa: E402
 from tools.bench_loss_path import CFG  # noqa: E402

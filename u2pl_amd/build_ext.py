@@ -25,10 +25,16 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, variant=None, defs=()):
+    """variant / defs: a second build of the same sources with extra -D switches (debug instrumentation), written to
+    lib/variants/libu2pl_hip_<variant>.so and loaded through U2PL_LIB_PATH; the product library has neither."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
-    objdir = os.path.join(HERE, "lib", "obj")
+    objdir = os.path.join(HERE, "lib", "obj" + ("_" + variant if variant else ""))
+    LIB = globals()["LIB"]
+    if variant:
+        os.makedirs(os.path.join(HERE, "lib", "variants"), exist_ok=True)
+        LIB = os.path.join(HERE, "lib", "variants", "libu2pl_hip_%s.so" % variant)
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(ROOT, "include", "u2pl_hip.h"))
@@ -37,7 +43,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + ["-D" + d for d in defs] + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))
@@ -53,5 +59,6 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    # python -m u2pl_amd.build_ext [--force] [--variant NAME -DX -DY ...]
+    var = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
+    print(build(force="--force" in sys.argv, variant=var, defs=[a[2:] for a in sys.argv if a.startswith("-D")]))

@@ -19,8 +19,10 @@
 // prob is addressed through strides so NCHW or NHWC both work.
 // ---------------------------------------------------------------------------
 #define MAXC 32
-// (debug) per-block start / end times of the phase-1 kernels: u2pl_debug_phase1_times(buf) arms it, NULL disarms.
+// (debug, -DU2PL_P1_DBG builds only: `python -m u2pl_amd.build_ext --variant p1dbg -DU2PL_P1_DBG`) per-block start / end
+// times and three marks of the phase-1 kernels: u2pl_debug_phase1_times(buf) arms them, NULL disarms.
 // buf: uint32 [3][4096][2] (kernel 0 = classify, 1 = prototype stream, 2 = tail), 100 MHz ticks.
+#ifdef U2PL_P1_DBG
 __device__ unsigned* g_p1_dbg = nullptr;
 U2PL_API int u2pl_debug_phase1_times(unsigned* buf) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_p1_dbg), &buf, sizeof(buf));
@@ -28,6 +30,12 @@ U2PL_API int u2pl_debug_phase1_times(unsigned* buf) {
 #define P1_DBG_START(k) unsigned dbg_t0_ = 0; if (g_p1_dbg && threadIdx.x == 0) dbg_t0_ = (unsigned)wall_clock64();
 #define P1_DBG_MARK(k, slot, b) if (g_p1_dbg && threadIdx.x == 0) g_p1_dbg[((k) * 4096 + 1024 * (slot) + (b)) * 2] = (unsigned)wall_clock64();
 #define P1_DBG_END(k, b) if (g_p1_dbg && threadIdx.x == 0 && (b) < 4096) { g_p1_dbg[((k) * 4096 + (b)) * 2] = dbg_t0_; g_p1_dbg[((k) * 4096 + (b)) * 2 + 1] = (unsigned)wall_clock64(); }
+#else
+U2PL_API int u2pl_debug_phase1_times(unsigned*) { return U2PL_EINVAL; }     // not an instrumented build
+#define P1_DBG_START(k)
+#define P1_DBG_MARK(k, slot, b)
+#define P1_DBG_END(k, b)
+#endif
 #define CP_PIX 256          // pixels per block of the classify / compaction kernels (one per thread)
 #define PF_MAXBLK 4096      // prototype partial blocks a finish can order
 // The classify kernel also counts, per block of CP_PIX pixels, the members of every (kind, class) list:
@@ -1062,13 +1070,34 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
 #pragma unroll
             for (int i = 0; i < VPL; ++i) { nf[u] = fmaf(f[u][i], f[u][i], nf[u]); dot[u] = fmaf(ah[i], f[u][i], dot[u]); }   // (the library is built with -ffp-contract=off: fused multiply-adds are spelled out where they are wanted)
         }
-        // eight wave totals (DPP only, no LDS-crossbar shuffles), parked in lanes 0..3 of two registers so that the
-        // per-row scalar chain (sqrt, reciprocal, exp) runs ONCE for the four rows instead of four times on all lanes
-        float vn = 1.f, vd = 0.f;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            vn = lane_put(vn, wave_sum_sgpr(nf[u]), u);
-            vd = lane_put(vd, wave_sum_sgpr(dot[u]), u);
+        // eight wave totals in ONE transposed reduction (19 instructions; eight separate 6-step DPP reductions + readlanes
+        // were 64): each step halves the number of live values instead of the number of live lanes.  gfx950's
+        // v_permlane32_swap / v_permlane16_swap exchange half-waves / odd-even rows between two registers, so "add the two
+        // halves of X and of Y" is one swap + one add and leaves X's sums in one half, Y's in the other.  After the
+        // two swap levels row u (lanes 16u .. 16u+15) holds the partial sums of row u's |f|^2 in one register and of its
+        // dot product in another; a select + row_ror:8 puts |f|^2 into the row's lanes 0..7 and the dot product into 8..15
+        // of ONE register, three more DPP adds (half-mirror, quad xor 1, quad xor 2) finish both.  The per-row scalar
+        // chain (rsqrt, exp) then runs once for the four rows: row u's values are read from lane 16 u.
+        float vn, vd;
+        {
+            auto sw32 = [](float x, float y) {
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+                return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            };
+            auto sw16 = [](float x, float y) {
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+                return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            };
+            const float a0 = sw32(nf[0], nf[2]), a1 = sw32(nf[1], nf[3]), a2 = sw32(dot[0], dot[2]), a3 = sw32(dot[1], dot[3]);
+            const float b0 = sw16(a0, a1), b1 = sw16(a2, a3);           // row u: partial |f_u|^2 / partial a.f_u
+            const bool hi8 = (lane & 8) != 0;
+            const float keep = hi8 ? b1 : b0, send = hi8 ? b0 : b1;
+            float c = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x128, 0xf, 0xf, false));
+            c = dpp_add<0x141>(c);     // row_half_mirror: i <-> 7 - i inside each group of eight
+            c = dpp_add<0xB1>(c);      // quad_perm [1,0,3,2]
+            c = dpp_add<0x4E>(c);      // quad_perm [2,3,0,1]
+            vn = c;                    // (valid in lanes 16u .. 16u+7; the other lanes compute along and are never read)
+            vd = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c), 0x128, 0xf, 0xf, false));
         }
         // cos = (ahat . f) / |f|, fhat = f / |f|; softmax weight w = exp(l - shift)
         // 1 / max(|f|, 1e-8) as ONE v_rsq_f32 (1 ulp) instead of an IEEE sqrt + IEEE division (~25 instructions): the
@@ -1079,7 +1108,7 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
         const float vl = vcos * inv_temp;
         if constexpr (ONLINE) {
             // rows past the end are clamped duplicates of row K (a real logit): including them in the maximum is harmless
-            const float m4 = fmaxf(fmaxf(lane_get(vl, 0), lane_get(vl, 1)), fmaxf(lane_get(vl, 2), lane_get(vl, 3)));
+            const float m4 = fmaxf(fmaxf(lane_get(vl, 0), lane_get(vl, 16)), fmaxf(lane_get(vl, 32), lane_get(vl, 48)));
             const float mnew = fmaxf(shift, m4);
             const float resc = __expf(shift - mnew);      // first batch: exp(-inf) = 0 on all-zero accumulators
             shift = mnew;
@@ -1093,10 +1122,10 @@ __global__ void k_infonce(const NceJob* __restrict__ jobs, const float* __restri
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (j0 + u > K) continue;
-            const float w = lane_get(vw, u), cosv = lane_get(vcos, u), wn = lane_get(vwn, u);
+            const float w = lane_get(vw, 16 * u), cosv = lane_get(vcos, 16 * u), wn = lane_get(vwn, 16 * u);
             if (j0 + u == 0) {
-                l0 = lane_get(vl, u);
-                const float inv = lane_get(vinv, u);
+                l0 = lane_get(vl, 16 * u);
+                const float inv = lane_get(vinv, 16 * u);
 #pragma unroll
                 for (int i = 0; i < VPL; ++i) f0h[i] = f[u][i] * inv;
             }
@@ -1293,10 +1322,31 @@ __global__ __launch_bounds__(256) void k_scatter_rows_ordered(float* __restrict_
                                                               const float* __restrict__ gout, float scale) {
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (e >= n) return;
-    if (seg_len[e] <= 0) return;                   // not a group leader
-    const int p = pix[e];
-    if (head[p] != e) return;                      // not the chain head: the head's wave does the work
+    // Everything that is indexed by the entry itself is requested at once, then everything that hangs off those values:
+    // three dependent round trips on the common path (a leader that is alone in its chain) instead of seven
+    // (seg_len -> pix -> head -> next -> seg_pos -> order -> row).
+    const int len_e = seg_len[e], p = pix[e], nxt = next[e], pos_e = seg_pos[e];
+    if (len_e <= 0) return;                        // not a group leader (its next[] / seg_pos[] are not meaningful: nothing below uses them)
+    const int hd = head[p], id0 = order[pos_e];
+    const bool act = lane * 4 < D;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) v0 = *(const float4*)(src + (long)id0 * D + lane * 4);     // first member of this leader's own group (used on the common path)
+    if (hd != e) return;                           // not the chain head: the head's wave does the work
     const float sc = scale * (gout ? *gout : 1.0f);
+    if (nxt < 0) {                                 // the only leader on this pixel: its group in entry order
+        float4 acc = v0;
+        for (int k = 1; k < len_e; ++k) {
+            const int id = order[pos_e + k];
+            if (act) {
+                const float4 v = *(const float4*)(src + (long)id * D + lane * 4);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        // (0 + v0 == v0 bit for bit unless v0 is -0: the general path below starts from +0, so add it explicitly)
+        if (act) *(float4*)(dst + (long)p * ld + lane * 4) = make_float4(sc * (0.f + acc.x), sc * (0.f + acc.y), sc * (0.f + acc.z), sc * (0.f + acc.w));
+        if (lane == 0) head[p] = -1;
+        return;
+    }
     int myid = 0x7fffffff, cnt = 0;
     for (int cur = e; cur >= 0 && cnt < 64; cur = next[cur]) {   // <= one leader per job (MAXC = 32 jobs)
         if (lane == cnt) myid = cur;
@@ -1305,7 +1355,6 @@ __global__ __launch_bounds__(256) void k_scatter_rows_ordered(float* __restrict_
     int rank = 0;
     for (int j = 0; j < cnt; ++j) rank += __shfl(myid, j, 64) < myid;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool act = lane * 4 < D;
     for (int r = 0; r < cnt; ++r) {
         const unsigned long long m = __ballot(lane < cnt && rank == r);
         const int L = __shfl(myid, __ffsll((long long)m) - 1, 64);

@@ -1,6 +1,7 @@
 """Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md
 prescribes) of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline` into profiles/rNN_traffic.json
-(usage: parse_pmc_traffic.py <fetch_dir> <write_dir> <out.json> 5 10  -- 5 full steps, 10 replay repetitions).
+(usage: parse_pmc_traffic.py <fetch_dir> <write_dir> <out.json> 6 10  -- 6 full steps (1 warm-up + 3 timed + the recorded
+roofline step + the lr-0.01 sanity step), 10 replay repetitions of the HBM-bound group).
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of a wide coalesced stream -> x2."""
 import collections
 import csv
@@ -32,7 +33,7 @@ def main(fetch_dir, write_dir, out, steps_profiled, hbm_reps=0):
     ig = [v for k, v in rows.items() if k.startswith("k_conv_igemm")]
     ig_l = sum(v["launches"] for v in ig)
     ig_b = sum(v["bytes_per_launch"] * v["launches"] for v in ig) / max(ig_l, 1)
-    hbm_names = ("k_entropy", "k_sel_", "k_reliability", "k_apply_drop", "k_contra", "k_compact", "k_proto", "k_bank",
+    hbm_names = ("k_entropy", "k_sel_", "k_reliability", "k_apply_drop", "k_contra", "k_compact", "k_proto", "k_phase1", "k_bank",
                  "k_infonce", "k_scatter_add", "k_scatter_rows", "k_zero_rows")
     # bench.py's roofline leg re-issues every stage of the HBM-bound group hbm_reps more times (replay_hbm_group)
     hb = sum(v["bytes_per_launch"] * v["launches"] for k, v in rows.items() if k.startswith(hbm_names)) / (steps_profiled + hbm_reps)

@@ -842,25 +842,55 @@ __global__ void k_bank_append_multi(const long long* __restrict__ desc, int D, l
     const float* rows = (const float*)d[3];
     const int* list = (const int*)d[4];
     const long n_new = d[5];
-    const long skip = n_new > cap ? n_new - cap : 0;
-    const int D4 = D >> 2;
-    const long total = (n_new - skip) * D4;
-    // (the grid covers every float4 of the largest class in ONE pass: index load -> row load -> store is two dependent
-    // round trips per element, a grid-stride loop of 3-4 elements per thread made it seven)
-    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const long j = skip + t / D4;
-        const int dd = (int)(t % D4);
-        const long src = list ? (long)list[j] : j;
-        long slot = tail + j;                 // tail < cap, j < n_new: at most a few wraps (one unless n_new > cap)
-        slot = slot >= cap ? slot % cap : slot;
-        ((float4*)bank)[slot * D4 + dd] = *(const float4*)(rows + src * ld + 4 * dd);
+    const long skip = n_new > cap ? n_new - cap : 0;       // more new rows than slots: only the last `cap` are kept
+    const unsigned D4 = (unsigned)D >> 2;
+    const unsigned total = (unsigned)((n_new - skip) * D4);   // < 2^31 (host check)
+    const unsigned base = (unsigned)((tail + skip) % cap);  // slot of the first kept row; block-uniform (one scalar division)
+    // index load -> row load -> store is a chain of dependent round trips: every thread runs the chain for FOUR float4 at
+    // once (all index loads, then all row loads, then the stores), in 32-bit arithmetic without branches between the
+    // loads, and the grid covers the largest class in one pass of at most one resident round of blocks (3100 blocks of
+    // one float4 per thread were 1.5 rounds at 769^2: two chains)
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned t0 = blockIdx.x * blockDim.x + threadIdx.x; t0 < total; t0 += 4 * stride) {
+        unsigned jj[4], slot[4], dd[4];
+        bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned t = t0 + u * stride;
+            on[u] = t < total;
+            const unsigned tt = on[u] ? t : 0u;
+            jj[u] = tt / D4;                           // kept row index, < cap
+            dd[u] = tt - jj[u] * D4;
+            const unsigned sl = base + jj[u];          // < 2 cap
+            slot[u] = sl >= (unsigned)cap ? sl - (unsigned)cap : sl;
+        }
+        // (descriptor pointers: explicit global-memory loads / stores -- see common.h ldg; flat accesses are each waited for
+        // with vmcnt(0) lgkmcnt(0) and the four chains would run one after the other)
+        long srcr[4];
+        if (list) {
+            int li[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) li[u] = ldg(list + skip + jj[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) srcr[u] = li[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) srcr[u] = skip + (long)jj[u];
+        }
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ldg((const u32x4*)(rows + srcr[u] * ld + 4 * dd[u]));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (on[u]) *(U2PL_GLOBAL u32x4*)((u32x4*)bank + (long)slot[u] * D4 + dd[u]) = v[u];
     }
 }
 U2PL_API int u2pl_bank_append_multi_f32(const long long* desc_dev, int nclass, int D, long ld, long max_new,
                                         hipStream_t stream) {
     if (D % 4) return U2PL_EINVAL;
     if (nclass <= 0 || max_new <= 0) return 0;
-    dim3 grid(grid_for(max_new * (D / 4), 256, 2048), nclass);
+    if (max_new * (D / 4) >= (1L << 31)) return U2PL_EINVAL;      // the kernel indexes a class's float4s with 32 bits
+    dim3 grid(grid_for((max_new * (D / 4) + 3) / 4, 256, 2048), nclass);
     U2PL_LAUNCH(k_bank_append_multi, grid, dim3(256), 0, stream, desc_dev, D, ld);
     U2PL_LAUNCH_CHECK();
     return 0;

@@ -613,6 +613,7 @@ __global__ __launch_bounds__(RF_T, 1) void k_reliability_fused(RfArgs A) {
         }
     }
     __syncthreads();
+    rf_stamp(ws, 18);
     unsigned vmask[RF_NIT];
 #pragma unroll
     for (int it = 0; it < RF_NIT; ++it) {
@@ -631,53 +632,88 @@ __global__ __launch_bounds__(RF_T, 1) void k_reliability_fused(RfArgs A) {
         o00 = tshift + (int)(q - pix_lo) * CT;
         o01 = o00 + dx; o10 = o00 + dy; o11 = o10 + dx;
     };
+    // CT <= 19: the entropies are COMPUTED column-wise and OWNED row-wise.  Thread (cell, part) owns the four pixels of
+    // output row `part` of its cell (labels, sort keys, 16-byte stores along x), but evaluating the bilinear form for a
+    // row costs 4 horizontal + 2 vertical operations per pixel and class, while a COLUMN shares its horizontal
+    // interpolation between the four rows: 1 + 2.  So thread (cell, col) evaluates column `col` of its cell (two rows at a
+    // time, the up-sampled logits of the pair kept in registers between the max pass and the exp pass) and hands the four
+    // entropies to the row owners through a 17-word-per-cell LDS exchange (odd stride: conflict-free both ways).  Same
+    // operations on the same operands as the row form -- bit-identical entropies -- at 5 instead of 7 VALU operations per
+    // pixel and class in the first pass.
+    constexpr bool XPOSE = CT <= 19;
+    float* X = dyn + (((size_t)(per + A.w + 1) * CT + 8 + 3) & ~(size_t)3);     // [RF_NIT][RF_CELLS * 17] behind the tile
+    if constexpr (XPOSE) {
+#pragma unroll
+        for (int it = 0; it < RF_NIT; ++it) {
+            if (it >= nit4) continue;                                 // block-uniform
+            const int cl = t & (RF_CELLS - 1), col = t >> 8;
+            const long q = c0 + (long)it * RF_CELLS + cl;
+            if (q < c1) {
+                int n, ci, cj;
+                cell_geom(q, n, ci, cj);
+                int o00, o01, o10, o11;
+                corners(q, ci, cj, o00, o01, o10, o11);
+                const AcCoord cx = ac_coord(min(cj * 4 + col, A.W - 1), A.sx, A.w);    // (columns / rows past the edge: clamped,
+                float ly0[4], ly1[4];                                                  //  computed along, never read)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const AcCoord cy = ac_coord(min(ci * 4 + r, A.H - 1), A.sy, A.h);
+                    ly0[r] = cy.l0; ly1[r] = cy.l1;
+                }
+                float* xo = X + (size_t)it * (RF_CELLS * 17) + cl * 17 + col;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    float z0[CT], z1[CT], m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        const float v00 = T[o00 + c], v01 = T[o01 + c], v10 = T[o10 + c], v11 = T[o11 + c];
+                        const float tp = __fmaf_rn(cx.l0, v00, __fmul_rn(cx.l1, v01));
+                        const float bt = __fmaf_rn(cx.l0, v10, __fmul_rn(cx.l1, v11));
+                        z0[c] = __fmaf_rn(ly0[2 * hf], tp, __fmul_rn(ly1[2 * hf], bt));
+                        z1[c] = __fmaf_rn(ly0[2 * hf + 1], tp, __fmul_rn(ly1[2 * hf + 1], bt));
+                        m0 = fmaxf(m0, z0[c]);
+                        m1 = fmaxf(m1, z1[c]);
+                    }
+                    float s0 = 0.f, s1 = 0.f, u0 = 0.f, u1 = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        const float d0 = z0[c] - m0, d1 = z1[c] - m1;
+                        const float e0 = rf_exp_neg(d0), e1 = rf_exp_neg(d1);
+                        s0 += e0; u0 += e0 * d0;
+                        s1 += e1; u1 += e1 * d1;
+                    }
+                    xo[(2 * hf) * 4] = logf(s0) - u0 / s0;
+                    xo[(2 * hf + 1) * 4] = logf(s1) - u1 / s1;
+                }
+            }
+        }
+        __syncthreads();
+        rf_stamp(ws, 19);
+    }
 #pragma unroll
     for (int it = 0; it < RF_NIT; ++it) {
         if (it >= nit4) continue;                                     // block-uniform
         if (pbase[it] >= 0) {
             const int cl = t & (RF_CELLS - 1);
-            const long q = c0 + (long)it * RF_CELLS + cl;
-            const int oy = (pbase[it] >> 10) & 1023, ox0 = pbase[it] & 1023;
-            int o00, o01, o10, o11;
-            corners(q, oy >> 2, ox0 >> 2, o00, o01, o10, o11);
-            const AcCoord cy = ac_coord(oy, A.sy, A.h);
-            float lx0[4], lx1[4];
+            const int ox0 = pbase[it] & 1023;
+            float eraw[4];
+            if constexpr (XPOSE) {
+                const float* xi = X + (size_t)it * (RF_CELLS * 17) + cl * 17 + (t >> 8) * 4;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const AcCoord cx = ac_coord(min(ox0 + a, A.W - 1), A.sx, A.w);
-                lx0[a] = cx.l0; lx1[a] = cx.l1;
-            }
-            // two pixels at a time: their CT up-sampled logits stay in registers between the max pass and the exp pass
-            // (the bilinear form is evaluated once per value instead of twice)
-            float s[4], tt[4];
-            if constexpr (CT <= 19) {
+                for (int a = 0; a < 4; ++a) eraw[a] = xi[a];
+            } else {      // more classes: the 2 x CT register copy would spill -> row form, the bilinear form evaluated in both passes
+                const long q = c0 + (long)it * RF_CELLS + cl;
+                const int oy = (pbase[it] >> 10) & 1023;
+                int o00, o01, o10, o11;
+                corners(q, oy >> 2, ox0 >> 2, o00, o01, o10, o11);
+                const AcCoord cy = ac_coord(oy, A.sy, A.h);
+                float lx0[4], lx1[4];
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                float z0[CT], z1[CT], m0 = -INFINITY, m1 = -INFINITY;
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    const float v00 = T[o00 + c], v01 = T[o01 + c], v10 = T[o10 + c], v11 = T[o11 + c];
-                    const float t0 = __fmaf_rn(lx0[2 * hf], v00, __fmul_rn(lx1[2 * hf], v01));
-                    const float b0 = __fmaf_rn(lx0[2 * hf], v10, __fmul_rn(lx1[2 * hf], v11));
-                    const float t1 = __fmaf_rn(lx0[2 * hf + 1], v00, __fmul_rn(lx1[2 * hf + 1], v01));
-                    const float b1 = __fmaf_rn(lx0[2 * hf + 1], v10, __fmul_rn(lx1[2 * hf + 1], v11));
-                    z0[c] = __fmaf_rn(cy.l0, t0, __fmul_rn(cy.l1, b0));
-                    z1[c] = __fmaf_rn(cy.l0, t1, __fmul_rn(cy.l1, b1));
-                    m0 = fmaxf(m0, z0[c]);
-                    m1 = fmaxf(m1, z1[c]);
+                for (int a = 0; a < 4; ++a) {
+                    const AcCoord cx = ac_coord(min(ox0 + a, A.W - 1), A.sx, A.w);
+                    lx0[a] = cx.l0; lx1[a] = cx.l1;
                 }
-                float s0 = 0.f, s1 = 0.f, u0 = 0.f, u1 = 0.f;
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    const float d0 = z0[c] - m0, d1 = z1[c] - m1;
-                    const float e0 = rf_exp_neg(d0), e1 = rf_exp_neg(d1);
-                    s0 += e0; u0 += e0 * d0;
-                    s1 += e1; u1 += e1 * d1;
-                }
-                s[2 * hf] = s0; s[2 * hf + 1] = s1; tt[2 * hf] = u0; tt[2 * hf + 1] = u1;
-            }
-            } else {      // more classes: the 2 x CT register copy would spill -> evaluate the bilinear form in both passes
-                float m[4];
+                float s[4], tt[4], m[4];
 #pragma unroll
                 for (int a = 0; a < 4; ++a) { m[a] = -INFINITY; s[a] = 0.f; tt[a] = 0.f; }
 #pragma unroll 4
@@ -703,14 +739,15 @@ __global__ __launch_bounds__(RF_T, 1) void k_reliability_fused(RfArgs A) {
                         tt[a] += e * z;
                     }
                 }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) eraw[a] = logf(s[a]) - tt[a] / s[a];
             }
             const int nx = min(4, A.W - ox0);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
                 if (a < nx) {
                     const bool valid = (vmask[it] >> a) & 1u;
-                    float e = logf(s[a]) - tt[a] / s[a];
-                    e = valid ? e : __uint_as_float(0x7fc00000u);
+                    const float e = valid ? eraw[a] : __uint_as_float(0x7fc00000u);
                     er[it][a] = e;
                     if (valid) atomicAdd(&S.hist[rf_bin(e, A.bin_scale)], 1u);
                 }
@@ -1285,15 +1322,16 @@ U2PL_API int u2pl_reliability_fused(const float* logits_low, long sn, long sc, l
     A.fences = flags & 1;
     // dynamic LDS: phase A's corner logits | the sorted run (RF_PXMAX floats) | block offsets / prefixes + candidate keys
     // phase A tile: the contiguous low-resolution pixel span [c0, c1 + w + 1) of a block, pixel-major
-    const size_t lds_a = ((size_t)(((long)B * h * w + G - 1) / G + w + 1) * C + 8) * sizeof(float);
+    // (+ the column -> row exchange of the entropies behind it: RF_NIT x 256 cells x 17 words)
+    const size_t lds_a = ((((size_t)(((long)B * h * w + G - 1) / G + w + 1) * C + 8 + 3) & ~(size_t)3) + (size_t)RF_NIT * RF_CELLS * 17) * sizeof(float);
     const size_t lds_g = ((size_t)2 * RF_MAXSLOT * 256 + RF_CAP + 3 * RF_MAXSLOT * 512) * sizeof(unsigned);
     size_t lds = lds_a > lds_g ? lds_a : lds_g;
     if ((size_t)RF_PXMAX * sizeof(float) > lds) lds = (size_t)RF_PXMAX * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static size_t attr = 0;
+    if (lds > attr) {
         (void)hipFuncSetAttribute((const void*)k_reliability_fused<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)k_reliability_fused<21>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
+        attr = lds;
     }
     if (C == 19) U2PL_LAUNCH(k_reliability_fused<19>, dim3(G), dim3(RF_T), lds, stream, A);
     else U2PL_LAUNCH(k_reliability_fused<21>, dim3(G), dim3(RF_T), lds, stream, A);

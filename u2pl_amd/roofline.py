@@ -166,7 +166,7 @@ def split_phase_table():
     """mean time of block 0 in every phase of the persistent reliability split over all launches of this process (stamps
     the kernel keeps in its workspace: csrc/relfused.hip), microseconds"""
     from . import hipops as H
-    names = [(10, "A_entropy_hist"), (11, "P_scan_prefix_totals"), (12, "P_counting_sort"), (13, "P_run_stores"), (1, "P_drain"),
+    names = [(18, "A_tile_and_labels"), (19, "A_entropies"), (10, "A_owner_hist"), (11, "P_scan_prefix_totals"), (12, "P_counting_sort"), (13, "P_run_stores"), (1, "P_drain"),
              (2, "barrier"), (14, "C_totals_scan"), (15, "C_ranks_bins_lists"), (16, "G_prefix_pairs"), (17, "G_block_prefix"),
              (3, "G_members"), (8, "D_sync"), (9, "D_select"), (5, "D_thresholds"), (6, "apply"), (7, "end")]
     out = {}

@@ -60,7 +60,7 @@ def main():
 
     res["reliability_fused_total_us"] = timeit(rel_fused)
     res["reliability_persistent_us"] = timeit(
-        lambda: H.reliability_split(low[B:], (S, S), label_l, label_u, (s, s), [80.0, 20.0, 80.0], fused=True), n=20)
+        lambda: H.reliability_split(low[B:], (S, S), label_l, label_u, (s, s), [80.0, 20.0, 80.0], fused=True), n=40)
     wsf = H.new_select_ws(DEV, B * S * S)
     res["entropy_up_us"] = timeit(lambda: H.entropy_map_up(low[B:], (S, S), label_u, wsf))
     ws = H.new_select_ws(DEV, B * S * S)
@@ -91,7 +91,7 @@ def main():
 
     keys = contra()
     res["contra_new_keys"] = [int(k) for k in keys]
-    res["contra_fwd_bwd_us"] = timeit(contra, n=5)
+    res["contra_fwd_bwd_us"] = timeit(contra, n=40, warm=3)     # (40 repetitions: the first, cold call -- ~1.5x -- would be 1/9 of a 9-call average)
     t0 = time.time()
     contra()
     torch.cuda.synchronize()

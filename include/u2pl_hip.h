@@ -322,6 +322,11 @@ int u2pl_adam_step_f32(float* p, const float* g, float* exp_avg, float* exp_avg_
  * Returns 1001 when the shape is not covered (fall back to entropy_up + select + reliability_apply). */
 /* kernel launches issued by this library so far (host counter; bench.py: kernel launches per step vs C-ABI calls) */
 size_t u2pl_kernel_launches(void);
+/* Arithmetic of the fp32 convolution / GEMM entry points: 1 (default; env U2PL_CONV_SPLIT) = every fp32 operand split
+ * exactly into three bf16 pieces and the six significant piece products accumulated in fp32 on the bf16 matrix cores
+ * (fp32-class accuracy, csrc/conv.hip BF == 3); 0 = v_mfma_f32_32x32x2_f32.  set returns the previous value. */
+int u2pl_conv_set_split(int on);
+int u2pl_conv_get_split(void);
 /* (debug) arm per-block start / end stamps of the three phase-1 kernels: buf = device uint32 [3][4096][2] in 100 MHz
  * ticks (kernel 0 classify, 1 prototype stream, 2 tail); NULL disarms.  Only in a -DU2PL_P1_DBG build of the library
  * (U2PL_EINVAL otherwise); tools/bench_phase1_blocks.py reads it. */

@@ -45,6 +45,14 @@ __device__ __forceinline__ bool gather_coord(int base, int tap, int step, int lo
 // BF: the A / B tiles are rounded to bf16 (round-to-nearest-even) on their way into LDS and multiplied on the bf16
 // matrix cores (v_mfma_f32_32x32x16_bf16, 16x the f32-input rate) with fp32 accumulation -- BASELINE configs[4]
 // ("config 5": reduced-precision student, fp32 master weights / EMA teacher).  Tensors in HBM stay fp32.
+// BF == 3 ("split fp32"): fp32 products ON THE bf16 MATRIX CORES without giving up fp32 accuracy.  Every operand is split
+// exactly into three bf16 pieces x = x0 + x1 + x2 (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1): 3 x 8 = 24
+// significand bits, both subtractions are exact in fp32) while it is staged into LDS, and a product a.b is accumulated
+// in fp32 from the six piece products whose weight is >= 2^-16: a0b0 + a0b1 + a1b0 + a0b2 + a1b1 + a2b0.  The dropped
+// terms (a1b2, a2b1, a2b2) are <= 2^-23 |ab| -- the size of ONE fp32 rounding, i.e. of what the fp32 MFMA's own
+// accumulation commits K times per output.  Six v_mfma_f32_32x32x16_bf16 (6 x 32 cycles for a 32x32x16 block) replace
+// eight v_mfma_f32_32x32x2_f32 (8 x 64 cycles): 2.7x fewer matrix-pipe cycles for the same fp32-class result
+// (measured against float64 in tests/test_gpu_conv_stack.py).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define LDPH (BK + 8)   // LDS row pitch of the bf16 tiles (elements): 80 B, 16 B aligned
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -58,8 +66,18 @@ __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
     return *(unsigned*)&v;
 }
 __device__ __forceinline__ uint2 pack4_bf16(float4 v) { return make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w)); }
+// exact three-way split of four fp32 values into bf16 pieces (see BF == 3 below): v = p0 + p1 + p2 up to 2^-24 |v|
+__device__ __forceinline__ float bf16_lo_f(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf16_hi_f(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+__device__ __forceinline__ void split3_bf16(float4 v, uint2& p0, uint2& p1, uint2& p2) {
+    p0 = pack4_bf16(v);
+    const float4 r1 = make_float4(v.x - bf16_lo_f(p0.x), v.y - bf16_hi_f(p0.x), v.z - bf16_lo_f(p0.y), v.w - bf16_hi_f(p0.y));
+    p1 = pack4_bf16(r1);
+    const float4 r2 = make_float4(r1.x - bf16_lo_f(p1.x), r1.y - bf16_hi_f(p1.x), r1.z - bf16_lo_f(p1.y), r1.w - bf16_hi_f(p1.y));
+    p2 = pack4_bf16(r2);
+}
 
-template <int TM, int TN, int WM = 2, bool BF = false>
+template <int TM, int TN, int WM = 2, int BF = 0>
 __global__ __launch_bounds__(128 * WM, WM) void k_conv_igemm(const float* __restrict__ x, long ldx,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
@@ -78,8 +96,12 @@ __global__ __launch_bounds__(128 * WM, WM) void k_conv_igemm(const float* __rest
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                  // [2][BM][LDP]
     float* Bs = smem + 2 * BM * LDP;   // [2][BN][LDP]
-    unsigned short* Ah = (unsigned short*)smem;          // BF: [2][BM][LDPH] bf16
-    unsigned short* Bh = Ah + 2 * BM * LDPH;             //     [2][BN][LDPH]
+    unsigned short* Ah = (unsigned short*)smem;          // BF: [2][BM][LDPH] bf16 (BF == 3: three such planes, piece-major)
+    // BF == 3: ONE LDS buffer (three piece planes of A, three of B: 61 KB for 128 x 128 x 32 -- two buffers would be 120 KB
+    // and leave a single 8-wave block per CU; with one buffer two blocks are resident and fill each other's barriers)
+    constexpr int NBUF = BF == 3 ? 1 : 2;
+    unsigned short* Bh = Ah + (BF == 3 ? 3 : 2) * BM * LDPH;         //     [2][BN][LDPH]
+    constexpr long APL = (long)NBUF * BM * LDPH, BPL = (long)NBUF * BN * LDPH;       // plane strides of the split form
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -132,6 +154,23 @@ __global__ __launch_bounds__(128 * WM, WM) void k_conv_igemm(const float* __rest
         }
     };
     auto store_chunk = [&](int buf, const float4 (&ra)[RA], const float4 (&rb)[RB]) {
+        if (BF == 3) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                uint2 p0, p1, p2;
+                split3_bf16(ra[i], p0, p1, p2);
+                unsigned short* d = Ah + ((long)buf * BM + r0 + RPP * i) * LDPH + kq * 4;
+                *(uint2*)d = p0; *(uint2*)(d + APL) = p1; *(uint2*)(d + 2 * APL) = p2;
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                uint2 p0, p1, p2;
+                split3_bf16(rb[i], p0, p1, p2);
+                unsigned short* d = Bh + ((long)buf * BN + r0 + RPP * i) * LDPH + kq * 4;
+                *(uint2*)d = p0; *(uint2*)(d + BPL) = p1; *(uint2*)(d + 2 * BPL) = p2;
+            }
+            return;
+        }
         if (BF) {
 #pragma unroll
             for (int i = 0; i < RA; ++i) *(uint2*)(Ah + ((long)buf * BM + r0 + RPP * i) * LDPH + kq * 4) = pack4_bf16(ra[i]);
@@ -155,6 +194,34 @@ __global__ __launch_bounds__(128 * WM, WM) void k_conv_igemm(const float* __rest
 
     const int li = lane & 31, lh = lane >> 5;
     auto mma = [&](int buf) {
+        if (BF == 3) {   // six piece products per 32x32x16 block, smallest weights first
+            const unsigned short* Ab = Ah + ((long)buf * BM + wm * 32 * TM + li) * LDPH + 8 * lh;
+            const unsigned short* Bb = Bh + ((long)buf * BN + wn * 32 * TN + li) * LDPH + 8 * lh;
+#pragma unroll
+            for (int gk = 0; gk < BK / 16; ++gk) {
+                bf16x8 a8[3][TM], b8[3][TN];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) a8[p][a] = __builtin_bit_cast(bf16x8, *(const uint4*)(Ab + p * APL + a * 32 * LDPH + gk * 16));
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) b8[p][b] = __builtin_bit_cast(bf16x8, *(const uint4*)(Bb + p * BPL + b * 32 * LDPH + gk * 16));
+                }
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        f32x16 c = acc[a][b];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[2][a], b8[0][b], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[1][a], b8[1][b], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][a], b8[2][b], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[1][a], b8[0][b], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][a], b8[1][b], c, 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][a], b8[0][b], c, 0, 0, 0);
+                    }
+            }
+            return;
+        }
         if (BF) {   // lane (li, lh) supplies row li, k = 16*gk + 8*lh + (0..7) of A and of B: one ds_read_b128 each
             const unsigned short* Ab = Ah + ((long)buf * BM + wm * 32 * TM + li) * LDPH + 8 * lh;
             const unsigned short* Bb = Bh + ((long)buf * BN + wn * 32 * TN + li) * LDPH + 8 * lh;
@@ -201,11 +268,13 @@ __global__ __launch_bounds__(128 * WM, WM) void k_conv_igemm(const float* __rest
     __syncthreads();
     for (int kc = 0; kc < nk; kc += 2) {
         mma(0);
-        if (kc + 1 < nk) store_chunk(1, ra0, rb0);
+        if (NBUF == 1) __syncthreads();          // (single buffer: everybody has read chunk kc before it is overwritten)
+        if (kc + 1 < nk) store_chunk(NBUF - 1, ra0, rb0);
         __syncthreads();
         if (kc + 3 < nk) load_chunk(kc + 3, ra0, rb0);
         if (kc + 1 < nk) {
-            mma(1);
+            mma(NBUF - 1);
+            if (NBUF == 1) __syncthreads();
             if (kc + 2 < nk) store_chunk(0, ra1, rb1);
             __syncthreads();
             if (kc + 4 < nk) load_chunk(kc + 4, ra1, rb1);
@@ -314,7 +383,7 @@ __global__ __launch_bounds__(128 * WM, WM) void k_conv_igemm(const float* __rest
     }
 }
 
-template <int TM, int TN, int WM = 2, bool BF = false>
+template <int TM, int TN, int WM = 2, int BF = 0>
 static int launch_igemm(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
                         const ConvGeom& g, long m_begin, long m_end, hipStream_t stream, float* stats = nullptr,
                         const float* pivot = nullptr, int batch = 1, long zx = 0, long zw = 0, long zy = 0,
@@ -322,7 +391,9 @@ static int launch_igemm(const float* x, long ldx, const float* w, const float* b
     constexpr int BM = 32 * TM * WM, BN = 64 * TN;
     if (m_end <= m_begin) return 0;
     const BnEpi ep = epi ? *epi : BnEpi{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
-    const size_t lds = (size_t)2 * (BM + BN) * LDP * sizeof(float);
+    const size_t lds_op = BF == 3 ? (size_t)3 * (BM + BN) * LDPH * sizeof(unsigned short) : (size_t)2 * (BM + BN) * LDP * sizeof(float);
+    const size_t lds_epi = (size_t)(4 * WM / 2) * (32 * TM) * (32 * TN + 4) * sizeof(float);     // the epilogue's per-wave transpose regions
+    const size_t lds = lds_op > lds_epi ? lds_op : lds_epi;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_conv_igemm<TM, TN, WM, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -387,21 +458,45 @@ static IgemmPlan plan_igemm(const ConvGeom& g, int batch = 1) {
     p.nblk_tail = p.tail_tm == 4 ? cdiv(tail, 128) : cdiv(tail, 64 * p.tail_tm);
     return p;
 }
+// the fp32 products' arithmetic: 1 (default) = split fp32 on the bf16 matrix cores (k_conv_igemm BF == 3), 0 = the fp32
+// matrix-core instruction v_mfma_f32_32x32x2_f32.  U2PL_CONV_SPLIT=0|1; u2pl_conv_set_split() for tests / A-B runs.
+static int g_conv_split = -1;
+static int conv_split() {
+    if (g_conv_split < 0) { const char* e = getenv("U2PL_CONV_SPLIT"); g_conv_split = (e && *e) ? (atoi(e) != 0) : 1; }
+    return g_conv_split;
+}
+U2PL_API int u2pl_conv_set_split(int on) { const int old = conv_split(); g_conv_split = on != 0; return old; }
+U2PL_API int u2pl_conv_get_split(void) { return conv_split(); }
+
 static int run_igemm(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
                      const ConvGeom& g, hipStream_t stream, float* stats = nullptr, const float* pivot = nullptr,
-                     int batch = 1, long zx = 0, long zw = 0, long zy = 0, bool bf = false, const BnEpi* epi = nullptr) {
+                     int batch = 1, long zx = 0, long zw = 0, long zy = 0, int bf = 0, const BnEpi* epi = nullptr) {
     if (g.Cin % BK) return U2PL_EINVAL;
-    if (epi && (bf || stats || batch != 1 || (g.Cout & 3))) return U2PL_EINVAL;
+    if (epi && (bf == 1 || stats || batch != 1 || (g.Cout & 3))) return U2PL_EINVAL;
     const long M = (long)g.N * g.Hout * g.Wout;
     const IgemmPlan p = plan_igemm(g, batch);
-    if (bf) {   // bf16-operand variants of the same tile shapes
-        if (g.Cout <= 64) return launch_igemm<2, 1, 2, true>(x, ldx, w, bias, y, ldy, g, 0, M, stream, stats, pivot, batch, zx, zw, zy);
-        int rc = launch_igemm<1, 2, 4, true>(x, ldx, w, bias, y, ldy, g, 0, p.m_body, stream, stats, pivot, batch, zx, zw, zy);
+    if (bf == 0 && conv_split()) bf = 3;
+    if (bf == 3) {   // split-fp32 variants of the same tile shapes (all epilogues)
+        if (g.Cout <= 64) return launch_igemm<2, 1, 2, 3>(x, ldx, w, bias, y, ldy, g, 0, M, stream, stats, pivot, batch, zx, zw, zy, epi);
+        static int waves3 = 0;
+        if (!waves3) { const char* e = getenv("U2PL_IGEMM_WAVES"); waves3 = (e && atoi(e) == 4) ? 4 : 8; }
+        int rc = waves3 == 8 ? launch_igemm<1, 2, 4, 3>(x, ldx, w, bias, y, ldy, g, 0, p.m_body, stream, stats, pivot, batch, zx, zw, zy, epi)
+                             : launch_igemm<2, 2, 2, 3>(x, ldx, w, bias, y, ldy, g, 0, p.m_body, stream, stats, pivot, batch, zx, zw, zy, epi);
         if (rc || p.nblk_tail == 0) return rc;
         float* st = stats ? stats + (long)p.nblk_body * 2 * g.Cout : nullptr;
-        if (p.tail_tm == 2) return launch_igemm<2, 2, 2, true>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy);
-        if (p.tail_tn == 2) return launch_igemm<1, 2, 2, true>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy);
-        return launch_igemm<1, 1, 2, true>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy);
+        if (p.tail_tm == 4) return launch_igemm<1, 1, 4, 3>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy, epi);
+        if (p.tail_tm == 2) return launch_igemm<2, 2, 2, 3>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy, epi);
+        if (p.tail_tn == 2) return launch_igemm<1, 2, 2, 3>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy, epi);
+        return launch_igemm<1, 1, 2, 3>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy, epi);
+    }
+    if (bf) {   // bf16-operand variants of the same tile shapes
+        if (g.Cout <= 64) return launch_igemm<2, 1, 2, 1>(x, ldx, w, bias, y, ldy, g, 0, M, stream, stats, pivot, batch, zx, zw, zy);
+        int rc = launch_igemm<1, 2, 4, 1>(x, ldx, w, bias, y, ldy, g, 0, p.m_body, stream, stats, pivot, batch, zx, zw, zy);
+        if (rc || p.nblk_tail == 0) return rc;
+        float* st = stats ? stats + (long)p.nblk_body * 2 * g.Cout : nullptr;
+        if (p.tail_tm == 2) return launch_igemm<2, 2, 2, 1>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy);
+        if (p.tail_tn == 2) return launch_igemm<1, 2, 2, 1>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy);
+        return launch_igemm<1, 1, 2, 1>(x, ldx, w, bias, y, ldy, g, p.m_body, M, stream, st, pivot, batch, zx, zw, zy);
     }
     if (g.Cout <= 64) return launch_igemm<2, 1>(x, ldx, w, bias, y, ldy, g, 0, M, stream, stats, pivot, batch, zx, zw, zy, epi);
     // 128x128 body tiles are computed by 8 waves (4x2, 32x64 outputs each; 4 waves per SIMD with two resident
@@ -446,7 +541,7 @@ U2PL_API int u2pl_conv2d_fwd_bnact_f32(const float* x, long ldx, const float* w,
     if (!mean || !invstd || !gamma || !beta || (Cout & 3) || (res && (ldr & 3))) return U2PL_EINVAL;
     ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
     const BnEpi epi = {mean, invstd, gamma, beta, res, ldr, relu};
-    return run_igemm(x, ldx, w, bias, y, ldy, g, stream, nullptr, nullptr, 1, 0, 0, 0, false, &epi);
+    return run_igemm(x, ldx, w, bias, y, ldy, g, stream, nullptr, nullptr, 1, 0, 0, 0, 0, &epi);
 }
 
 // forward fused with the BatchNorm statistics of its output (train-mode conv -> BN pairs): also writes the
@@ -469,14 +564,14 @@ U2PL_API int u2pl_conv2d_fwd_bf16op_f32(const float* x, long ldx, const float* w
                                         long ldy, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
                                         int R, int S, int stride, int pad, int dil, hipStream_t stream) {
     ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
-    return run_igemm(x, ldx, w, bias, y, ldy, g, stream, nullptr, nullptr, 1, 0, 0, 0, true);
+    return run_igemm(x, ldx, w, bias, y, ldy, g, stream, nullptr, nullptr, 1, 0, 0, 0, 1);
 }
 U2PL_API int u2pl_conv2d_fwd_bnstats_bf16op_f32(const float* x, long ldx, const float* w, const float* bias, float* y,
                                                 long ldy, int N, int Hin, int Win, int Cin, int Hout, int Wout,
                                                 int Cout, int R, int S, int stride, int pad, int dil,
                                                 const float* pivot, float* stats_partial, hipStream_t stream) {
     ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
-    return run_igemm(x, ldx, w, bias, y, ldy, g, stream, stats_partial, pivot, 1, 0, 0, 0, true);
+    return run_igemm(x, ldx, w, bias, y, ldy, g, stream, stats_partial, pivot, 1, 0, 0, 0, 1);
 }
 U2PL_API int u2pl_conv2d_dgrad_bf16op_f32(const float* dy, long lddy, const float* wT, float* dx, long lddx, int N,
                                           int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S,
@@ -484,7 +579,7 @@ U2PL_API int u2pl_conv2d_dgrad_bf16op_f32(const float* dy, long lddy, const floa
     int l2 = log2_exact(stride);
     if (l2 < 0) return U2PL_EINVAL;
     ConvGeom g = {N, Hout, Wout, Cout, Hin, Win, Cin, R, S, 1, pad, pad, -dil, l2};
-    return run_igemm(dy, lddy, wT, nullptr, dx, lddx, g, stream, nullptr, nullptr, 1, 0, 0, 0, true);
+    return run_igemm(dy, lddy, wT, nullptr, dx, lddx, g, stream, nullptr, nullptr, 1, 0, 0, 0, 1);
 }
 
 // data gradient: dX[n,hi,wi,ci] = sum_{r,s,co} dY[n,(hi+pad-r*dil)/st,(wi+pad-s*dil)/st,co] * W[co][r][s][ci]
@@ -654,17 +749,27 @@ __global__ __launch_bounds__(128 * WM, 2) void k_conv_wgrad(const float* __restr
 // two consecutive pixels and writes four 32-bit words {bf16(pixel 2pp), bf16(pixel 2pp+1)} into [channel][pixel]
 // rows (pitch 36 bf16 = 72 B), from which lane (li, lh) fetches its 8 consecutive pixels of channel li with two
 // ds_read_b64.  Same split-K slabs / ordered reduce as the fp32 kernel.
+// SP == 3: split fp32 (see k_conv_igemm BF == 3): three piece planes per operand, six piece products, ONE LDS buffer
+// (55 KB for 128 x 128: two blocks per CU); zdy / zx: batched use (Winograd components as taps, like k_conv_wgrad).
 #define LDPW 36
-template <int TM, int TN>
+template <int TM, int TN, int SP = 1>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad_bf16(const float* __restrict__ dy, long lddy,
                                                             const float* __restrict__ x, long ldx,
                                                             float* __restrict__ part, ConvGeom g, int ctiles,
-                                                            int chunks_per_split, unsigned dybytes, unsigned xbytes) {
+                                                            int chunks_per_split, unsigned dybytes, unsigned xbytes,
+                                                            long zdy, long zx) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int NBUF = SP == 3 ? 1 : 2;
+    {
+        const int tap_b = blockIdx.x / ctiles;
+        dy += (long)tap_b * zdy;
+        x += (long)tap_b * zx;
+    }
     const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, dybytes), rx = make_rsrc(x, xbytes);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned short* Ah = (unsigned short*)smem;      // [2][BM][LDPW]
-    unsigned short* Bh = Ah + 2 * BM * LDPW;          // [2][BN][LDPW]
+    unsigned short* Ah = (unsigned short*)smem;      // [SP][NBUF][BM][LDPW]
+    unsigned short* Bh = Ah + SP * NBUF * BM * LDPW;  // [SP][NBUF][BN][LDPW]
+    constexpr long APL = (long)NBUF * BM * LDPW, BPL = (long)NBUF * BN * LDPW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const long M = (long)g.N * g.Hout * g.Wout;
@@ -706,17 +811,27 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_bf16(const float* __restr
             }
         }
     };
-    auto put4 = [&](unsigned short* base, const float4& p0, const float4& p1) {   // rows c..c+3, pixels 2pp, 2pp+1
-        *(unsigned*)(base + 0 * LDPW) = pack2_bf16(p0.x, p1.x);
-        *(unsigned*)(base + 1 * LDPW) = pack2_bf16(p0.y, p1.y);
-        *(unsigned*)(base + 2 * LDPW) = pack2_bf16(p0.z, p1.z);
-        *(unsigned*)(base + 3 * LDPW) = pack2_bf16(p0.w, p1.w);
+    auto put1 = [&](unsigned short* d, long pl, float a, float b) {     // one channel row, pixels 2pp and 2pp+1
+        const unsigned w0 = pack2_bf16(a, b);
+        *(unsigned*)d = w0;
+        if (SP == 3) {
+            const float a1 = a - bf16_lo_f(w0), b1 = b - bf16_hi_f(w0);
+            const unsigned w1 = pack2_bf16(a1, b1);
+            *(unsigned*)(d + pl) = w1;
+            *(unsigned*)(d + 2 * pl) = pack2_bf16(a1 - bf16_lo_f(w1), b1 - bf16_hi_f(w1));
+        }
+    };
+    auto put4 = [&](unsigned short* base, long pl, const float4& p0, const float4& p1) {   // rows c..c+3, pixels 2pp, 2pp+1
+        put1(base + 0 * LDPW, pl, p0.x, p1.x);
+        put1(base + 1 * LDPW, pl, p0.y, p1.y);
+        put1(base + 2 * LDPW, pl, p0.z, p1.z);
+        put1(base + 3 * LDPW, pl, p0.w, p1.w);
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < JA; ++j) put4(Ah + ((long)buf * BM + j * 64 + cq * 4) * LDPW + 2 * pp, ra[j][0], ra[j][1]);
+        for (int j = 0; j < JA; ++j) put4(Ah + ((long)buf * BM + j * 64 + cq * 4) * LDPW + 2 * pp, APL, ra[j][0], ra[j][1]);
 #pragma unroll
-        for (int j = 0; j < JB; ++j) put4(Bh + ((long)buf * BN + j * 64 + cq * 4) * LDPW + 2 * pp, rb[j][0], rb[j][1]);
+        for (int j = 0; j < JB; ++j) put4(Bh + ((long)buf * BN + j * 64 + cq * 4) * LDPW + 2 * pp, BPL, rb[j][0], rb[j][1]);
     };
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -730,31 +845,42 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_bf16(const float* __restr
         load_chunk(c_begin);
         store_chunk(0);
         __syncthreads();
+        auto ld8 = [&](const unsigned short* p) {
+            const uint2 lo = *(const uint2*)p, hi = *(const uint2*)(p + 4);
+            return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        };
         for (long ch = c_begin; ch < c_end; ++ch) {
-            const int buf = (int)((ch - c_begin) & 1);
+            const int buf = NBUF == 1 ? 0 : (int)((ch - c_begin) & 1);
             if (ch + 1 < c_end) load_chunk(ch + 1);
             const unsigned short* Ab = Ah + ((long)buf * BM + wm * 32 * TM + li) * LDPW + 8 * lh;
             const unsigned short* Bb = Bh + ((long)buf * BN + wn * 32 * TN + li) * LDPW + 8 * lh;
 #pragma unroll
             for (int gk = 0; gk < BK / 16; ++gk) {
-                bf16x8 a8[TM], b8[TN];
+                bf16x8 a8[SP][TM], b8[SP][TN];
 #pragma unroll
-                for (int a = 0; a < TM; ++a) {
-                    const uint2 lo = *(const uint2*)(Ab + a * 32 * LDPW + gk * 16), hi = *(const uint2*)(Ab + a * 32 * LDPW + gk * 16 + 4);
-                    a8[a] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-                }
+                for (int p = 0; p < SP; ++p) {
 #pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    const uint2 lo = *(const uint2*)(Bb + b * 32 * LDPW + gk * 16), hi = *(const uint2*)(Bb + b * 32 * LDPW + gk * 16 + 4);
-                    b8[b] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                    for (int a = 0; a < TM; ++a) a8[p][a] = ld8(Ab + p * APL + a * 32 * LDPW + gk * 16);
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) b8[p][b] = ld8(Bb + p * BPL + b * 32 * LDPW + gk * 16);
                 }
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
-                    for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[a], b8[b], acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < TN; ++b) {
+                        f32x16 c = acc[a][b];
+                        if (SP == 3) {      // six piece products, smallest weights first
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[SP - 1][a], b8[0][b], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[SP / 2][a], b8[SP / 2][b], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][a], b8[SP - 1][b], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[SP / 2][a], b8[0][b], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][a], b8[SP / 2][b], c, 0, 0, 0);
+                        }
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][a], b8[0][b], c, 0, 0, 0);
+                    }
             }
-            if (ch + 1 < c_end) store_chunk(buf ^ 1);
+            if (NBUF == 1) __syncthreads();            // (single buffer: everybody has read this chunk)
+            if (ch + 1 < c_end) store_chunk(NBUF == 1 ? 0 : buf ^ 1);
             __syncthreads();
         }
     }
@@ -848,6 +974,20 @@ static int launch_wgrad(const float* dy, long lddy, const float* x, long ldx, fl
     return 0;
 }
 
+template <int TM, int TN, int SP = 1>
+static int launch_wgrad_bf16(const float* dy, long lddy, const float* x, long ldx, float* part, const ConvGeom& g,
+                             int ctiles, int nsplit, int cps, hipStream_t stream, long zdy = 0, long zx = 0) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    const size_t lds = (size_t)(SP == 3 ? 3 : 2) * (BM + BN) * LDPW * sizeof(unsigned short);
+    const long dyb = (((long)g.N * g.Hout * g.Wout - 1) * lddy + g.Cout) * 4;
+    const long xb = (((long)g.N * g.Hin * g.Win - 1) * ldx + g.Cin) * 4;
+    if (dyb >= (1L << 31) || xb >= (1L << 31)) return U2PL_EINVAL;
+    dim3 grid((unsigned)(ctiles * g.R * g.S), (unsigned)cdiv(g.Cout, BM), (unsigned)nsplit);
+    U2PL_LAUNCH((k_conv_wgrad_bf16<TM, TN, SP>), grid, dim3(256), lds, stream, dy, lddy, x, ldx, part, g, ctiles, cps,
+                       (unsigned)dyb, (unsigned)xb, zdy, zx);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
 // weight gradient of nn.Conv2d (autograd of the reference's loss.backward(), train_semi.py:527)
 U2PL_API int u2pl_conv2d_wgrad_f32(const float* dy, long lddy, const float* x, long ldx, float* dw,
                                    void* workspace, int accumulate, int N, int Hin, int Win, int Cin, int Hout,
@@ -860,7 +1000,13 @@ U2PL_API int u2pl_conv2d_wgrad_f32(const float* dy, long lddy, const float* x, l
     wgrad_plan(g, BM, BN, ct, ns, cps);
     float* part = (float*)workspace;
     int rc;
-    if (BM == 128 && BN == 128)
+    if (conv_split()) {
+        if (BM == 128 && BN == 128) rc = launch_wgrad_bf16<2, 2, 3>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
+        else if (BM == 128) rc = launch_wgrad_bf16<2, 1, 3>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
+        else if (BN == 128) rc = launch_wgrad_bf16<1, 2, 3>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
+        else rc = launch_wgrad_bf16<1, 1, 3>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
+    }
+    else if (BM == 128 && BN == 128)
         rc = wgrad_waves() == 8 ? launch_wgrad<1, 2, 4>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream)
                                 : launch_wgrad<2, 2>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
     else if (BM == 128) rc = launch_wgrad<2, 1>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
@@ -873,20 +1019,6 @@ U2PL_API int u2pl_conv2d_wgrad_f32(const float* dy, long lddy, const float* x, l
     return 0;
 }
 
-template <int TM, int TN>
-static int launch_wgrad_bf16(const float* dy, long lddy, const float* x, long ldx, float* part, const ConvGeom& g,
-                             int ctiles, int nsplit, int cps, hipStream_t stream) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    const size_t lds = (size_t)2 * (BM + BN) * LDPW * sizeof(unsigned short);
-    const long dyb = (((long)g.N * g.Hout * g.Wout - 1) * lddy + g.Cout) * 4;
-    const long xb = (((long)g.N * g.Hin * g.Win - 1) * ldx + g.Cin) * 4;
-    if (dyb >= (1L << 31) || xb >= (1L << 31)) return U2PL_EINVAL;
-    dim3 grid((unsigned)(ctiles * g.R * g.S), (unsigned)cdiv(g.Cout, BM), (unsigned)nsplit);
-    U2PL_LAUNCH((k_conv_wgrad_bf16<TM, TN>), grid, dim3(256), lds, stream, dy, lddy, x, ldx, part, g, ctiles, cps,
-                       (unsigned)dyb, (unsigned)xb);
-    U2PL_LAUNCH_CHECK();
-    return 0;
-}
 // weight gradient with bf16-rounded dY / X operands (fp32 accumulate); workspace as u2pl_conv2d_wgrad_workspace_bytes
 U2PL_API int u2pl_conv2d_wgrad_bf16op_f32(const float* dy, long lddy, const float* x, long ldx, float* dw,
                                           void* workspace, int accumulate, int N, int Hin, int Win, int Cin, int Hout,
@@ -933,6 +1065,12 @@ U2PL_API int u2pl_wgrad_batched_f32(const float* dy, long lddy, long zdy, const 
     const int BM = Cout > 64 ? 128 : 64, BN = Cin > 64 ? 128 : 64;
     int ct, ns, cps;
     wgrad_plan(g, BM, BN, ct, ns, cps);
+    if (conv_split()) {
+        if (BM == 128 && BN == 128) return launch_wgrad_bf16<2, 2, 3>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx);
+        if (BM == 128) return launch_wgrad_bf16<2, 1, 3>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx);
+        if (BN == 128) return launch_wgrad_bf16<1, 2, 3>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx);
+        return launch_wgrad_bf16<1, 1, 3>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx);
+    }
     if (BM == 128 && BN == 128)
         return wgrad_waves() == 8 ? launch_wgrad<1, 2, 4>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx)
                                   : launch_wgrad<2, 2>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx);

@@ -238,6 +238,11 @@ def main():
                  f"fp32 Winograd F({wt}x{wt},3x3) for the stride-1 3x3 layers whose tile padding leaves >= "
                  f"{KN.CONV_ALGO['min_gain']}x fewer multiplies (forward, data and weight gradients; component products on "
                  "the same fp32 MFMA kernel), direct fp32 implicit GEMM elsewhere; U2PL_CONV_WINO=0|2|4 selects")
+    from u2pl_amd import roofline as _RLq
+    if not args.bf16:
+        conv_algo += ("; fp32 products: " + ("exact three-way bf16 split of both operands, six piece products accumulated in fp32 on the bf16 "
+                      "matrix cores (error vs float64 <= the fp32 MFMA path's, tools/bench_conv_split.py; U2PL_CONV_SPLIT=0 selects "
+                      "v_mfma_f32_32x32x2_f32)" if _RLq.conv_split_on() else "v_mfma_f32_32x32x2_f32 (U2PL_CONV_SPLIT=0)"))
     if rank == 0:
         out = {
             "metric": "train images/sec at %dx%d (R101-DeepLabv3+)" % (args.crop, args.crop), "value": round(value, 4), "unit": "images/s",

@@ -266,15 +266,32 @@ __global__ __launch_bounds__(128 * WM, WM) void k_conv_igemm(const float* __rest
     if (nk > 1) load_chunk(1, ra0, rb0);
     if (nk > 2) load_chunk(2, ra1, rb1);
     __syncthreads();
+    if constexpr (BF == 3) {
+        // split form: a chunk lasts ~1 us here (a third of the fp32-MFMA kernel's), so the two-chunk prefetch distance has
+        // to be real: the loads are issued UNCONDITIONALLY (chunk index clamped: past the end the last chunk is re-read and
+        // never used) -- a load under `if` makes the compiler wait with vmcnt(0), i.e. also for the loads issued one chunk
+        // ago (compiler behaviour (2))
+        for (int kc = 0; kc < nk; kc += 2) {
+            mma(0);
+            __syncthreads();                      // (single buffer: everybody has read chunk kc before it is overwritten)
+            store_chunk(0, ra0, rb0);             // (past the last chunk: stale pieces, never read)
+            __syncthreads();
+            load_chunk(min(kc + 3, nk - 1), ra0, rb0);
+            if (kc + 1 >= nk) break;
+            mma(0);
+            __syncthreads();
+            store_chunk(0, ra1, rb1);
+            __syncthreads();
+            load_chunk(min(kc + 4, nk - 1), ra1, rb1);
+        }
+    } else
     for (int kc = 0; kc < nk; kc += 2) {
         mma(0);
-        if (NBUF == 1) __syncthreads();          // (single buffer: everybody has read chunk kc before it is overwritten)
-        if (kc + 1 < nk) store_chunk(NBUF - 1, ra0, rb0);
+        if (kc + 1 < nk) store_chunk(1, ra0, rb0);
         __syncthreads();
         if (kc + 3 < nk) load_chunk(kc + 3, ra0, rb0);
         if (kc + 1 < nk) {
-            mma(NBUF - 1);
-            if (NBUF == 1) __syncthreads();
+            mma(1);
             if (kc + 2 < nk) store_chunk(0, ra1, rb1);
             __syncthreads();
             if (kc + 4 < nk) load_chunk(kc + 4, ra1, rb1);

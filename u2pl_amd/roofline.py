@@ -19,6 +19,25 @@ _CONV_GEOM = {
     "u2pl_conv2d_wgrad_bf16op_f32": 7,
 }
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense
+# split fp32 (csrc/conv.hip BF == 3): one fp32 product = six bf16 piece products -> the matrix-pipe bound of the algorithm in
+# fp32-equivalent FLOP/s
+PEAK_SPLIT_F32_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+
+
+def conv_split_on():
+    return bool(_lib.lib().cdll.u2pl_conv_get_split())
+
+
+def _mfma_fields(ach):
+    """roofline fields of an fp32 GEMM-like group: against the pipe its instructions actually run on"""
+    if conv_split_on():
+        return {"peak": round(PEAK_SPLIT_F32_TFLOPS, 1), "frac": round(ach / PEAK_SPLIT_F32_TFLOPS, 4),
+                "frac_vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                "arithmetic": "fp32 products as six bf16 piece products of an exact three-way operand split, fp32 accumulate "
+                              "(v_mfma_f32_32x32x16_bf16; U2PL_CONV_SPLIT=0: v_mfma_f32_32x32x2_f32).  achieved = fp32-equivalent "
+                              "FLOP/s; peak = 2500 TF bf16 dense / 6 piece products; frac_vs_fp32_mfma_peak = achieved / 157.3"}
+    return {"peak": PEAK_F32_MFMA_TFLOPS, "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            "arithmetic": "v_mfma_f32_32x32x2_f32 (U2PL_CONV_SPLIT=0)"}
 
 
 def _conv_flops(name, args):
@@ -226,9 +245,8 @@ def measure(trainer, batch, args, ms_per_step):
         nker = sum(x["kernels"] for x in ig)
         t = dense.get("igemm", t_ev)      # sustained-load time (dense replay); the gapped per-call events read shorter
         ach = fl / (t * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "k_conv_igemm (direct conv fwd [+BN-stat / eval-BN epilogue] + dgrad, and the batched Winograd component GEMMs; fp32 MFMA, executed FLOPs)", "bound": "mfma",
-                           "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        out["roofline"] = {"kernel": "k_conv_igemm (direct conv fwd [+BN-stat / eval-BN epilogue] + dgrad, and the batched Winograd component GEMMs; executed fp32 FLOPs)", "bound": "mfma",
+                           "achieved": round(ach, 2), **_mfma_fields(ach), "unit": "TFLOP/s", "traffic": None,
                            "abi_calls_per_step": n, "kernel_launches_per_step": nker, "avg_launch_ms": round(t / max(nker, 1), 4),
                            "avg_abi_call_ms": round(t / n, 4),
                            "executed_tflop_per_step": round(fl / 1e12, 3), "ms_per_step": round(t, 2),
@@ -245,7 +263,8 @@ def measure(trainer, batch, args, ms_per_step):
                                    algorithmic_frac=round(algo / (ms_per_step * 1e-3) / PEAK_F32_MFMA_TFLOPS, 4),
                                    note="frac/achieved: executed FLOPs of this kernel's launches over their own HIP-event "
                                         "time (serialised extra step); algorithmic_*: 26.4 TFLOP (SURVEY 8d, every layer "
-                                        "counted as a direct convolution) over the WHOLE timed step")
+                                        "counted as a direct convolution) over the WHOLE timed step, against the 157.3 TF of the fp32 MFMA "
+                                        "instruction (can exceed 1: Winograd multiplies less, the split form runs on the bf16 pipe)")
     bfs = [agg.get(n) for n in ("u2pl_conv2d_fwd_bf16op_f32", "u2pl_conv2d_fwd_bnstats_bf16op_f32", "u2pl_conv2d_dgrad_bf16op_f32",
                                 "u2pl_conv2d_wgrad_bf16op_f32")]
     bfs = [x for x in bfs if x]
@@ -267,8 +286,7 @@ def measure(trainer, batch, args, ms_per_step):
         wg["ms"] = dense.get("wgrad", wg["ms"])
         ach = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
         out["roofline_wgrad"] = {"kernel": "k_conv_wgrad (direct, + ordered slab reduce; and the batched Winograd component products; executed FLOPs)", "bound": "mfma",
-                                 "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                                 "achieved": round(ach, 2), **_mfma_fields(ach), "unit": "TFLOP/s", "traffic": None,
                                  "abi_calls_per_step": wg["calls"], "kernel_launches_per_step": wg["kernels"],
                                  "ms_per_step": round(wg["ms"], 2)}
     B, H, W = ll.shape

@@ -433,6 +433,16 @@ static int log2_exact(int v) {
     return (1 << l) == v ? l : -1;
 }
 
+// the fp32 products' arithmetic: 1 (default) = split fp32 on the bf16 matrix cores (k_conv_igemm BF == 3), 0 = the fp32
+// matrix-core instruction v_mfma_f32_32x32x2_f32.  U2PL_CONV_SPLIT=0|1; u2pl_conv_set_split() for tests / A-B runs.
+static int g_conv_split = -1;
+static int conv_split() {
+    if (g_conv_split < 0) { const char* e = getenv("U2PL_CONV_SPLIT"); g_conv_split = (e && *e) ? (atoi(e) != 0) : 1; }
+    return g_conv_split;
+}
+U2PL_API int u2pl_conv_set_split(int on) { const int old = conv_split(); g_conv_split = on != 0; return old; }
+U2PL_API int u2pl_conv_get_split(void) { return conv_split(); }
+
 // Tile-quantisation planner.  All 256 CUs finish a "round" of equal blocks together, so a launch of
 // nblk blocks costs ceil(nblk/256) rounds of one block's area.  The body is covered with 128x128
 // tiles in whole rounds; the remaining rows (the partial last round that would leave most CUs idle)
@@ -461,9 +471,13 @@ static IgemmPlan plan_igemm(const ConvGeom& g, int batch = 1) {
     if (c22 <= c12 && c22 <= c11) { p.tail_tm = 2; p.tail_tn = 2; }
     else if (c12 <= c11) { p.tail_tm = 1; p.tail_tn = 2; }
     else { p.tail_tm = 1; p.tail_tn = 1; }
-    {   // experiment switch (tools/bench_igemm_tail.py): U2PL_IGEMM_TAIL = 0 (one launch of body tiles) | 22 | 12 | 11 | 14 (128x64, 8 waves)
+    {   // U2PL_IGEMM_TAIL = 0 (one launch of body tiles) | 22 | 12 | 11 | 14 (128x64, 8 waves) | -1 (the planner's choice).
+        // Split form: no tail launch by default -- two body blocks are resident per CU there, a partial last round costs
+        // less than a second launch of small tiles whose matrix pipe sits at 9-18 % (measured: 86.6 vs 88.6 ms per step for
+        // the group); fp32 instruction: the planner's tail (tools/bench_igemm_tail.py: every forced choice within +-2 %).
         const char* e = getenv("U2PL_IGEMM_TAIL");
-        if (e && *e) {
+        if (!(e && *e) && conv_split()) e = "0";
+        if (e && *e && atoi(e) >= 0) {
             const int v = atoi(e);
             if (v == 0) { p.m_body = M; p.nblk_body = cdiv(M, 128); p.tail_tm = p.tail_tn = 0; p.nblk_tail = 0; return p; }
             if (v == 22) { p.tail_tm = 2; p.tail_tn = 2; }
@@ -475,16 +489,6 @@ static IgemmPlan plan_igemm(const ConvGeom& g, int batch = 1) {
     p.nblk_tail = p.tail_tm == 4 ? cdiv(tail, 128) : cdiv(tail, 64 * p.tail_tm);
     return p;
 }
-// the fp32 products' arithmetic: 1 (default) = split fp32 on the bf16 matrix cores (k_conv_igemm BF == 3), 0 = the fp32
-// matrix-core instruction v_mfma_f32_32x32x2_f32.  U2PL_CONV_SPLIT=0|1; u2pl_conv_set_split() for tests / A-B runs.
-static int g_conv_split = -1;
-static int conv_split() {
-    if (g_conv_split < 0) { const char* e = getenv("U2PL_CONV_SPLIT"); g_conv_split = (e && *e) ? (atoi(e) != 0) : 1; }
-    return g_conv_split;
-}
-U2PL_API int u2pl_conv_set_split(int on) { const int old = conv_split(); g_conv_split = on != 0; return old; }
-U2PL_API int u2pl_conv_get_split(void) { return conv_split(); }
-
 static int run_igemm(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
                      const ConvGeom& g, hipStream_t stream, float* stats = nullptr, const float* pivot = nullptr,
                      int batch = 1, long zx = 0, long zw = 0, long zy = 0, int bf = 0, const BnEpi* epi = nullptr) {

@@ -1,0 +1,68 @@
+"""The arithmetic of the split-fp32 convolution products (u2pl_amd/csrc/conv.hip, BF == 3 / SP == 3), restated in numpy:
+the three-piece bf16 split is EXACT, and the six retained piece products reproduce an fp32 dot product to fp32 accuracy.
+(The GPU kernels are held to the same statement against float64 convolutions in tests/test_gpu_conv_stack.py.)"""
+import numpy as np
+
+
+def bf16_rne(x):
+    """float32 -> nearest bfloat16 (ties to even), returned as float32 -- what v_cvt_pk_bf16_f32 does for finite values"""
+    u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return (r & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+
+
+def split3(x):
+    x = np.asarray(x, dtype=np.float32)
+    x0 = bf16_rne(x)
+    r1 = (x - x0).astype(np.float32)          # exact in fp32
+    x1 = bf16_rne(r1)
+    r2 = (r1 - x1).astype(np.float32)         # exact in fp32
+    x2 = bf16_rne(r2)
+    return x0, x1, x2, r1, r2
+
+
+def test_three_piece_split_is_exact_and_each_piece_is_a_bfloat16():
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(200000).astype(np.float32) * s for s in (1e-6, 1e-3, 1.0, 37.0, 1e5)]
+                       + [np.float32([0.0, -0.0, 1.0, -1.0, 3.0000002, 1e-30, 6.5e4, 2.0 ** -100])])
+    x0, x1, x2, r1, r2 = split3(x)
+    for p in (x0, x1, x2):
+        assert not (p.view(np.uint32) & 0xFFFF).any()                        # 8 significand bits each
+    # the two residuals are exactly representable (computed here in float64 for the check)
+    assert np.array_equal(r1.astype(np.float64), x.astype(np.float64) - x0.astype(np.float64))
+    assert np.array_equal(r2.astype(np.float64), r1.astype(np.float64) - x1.astype(np.float64))
+    total = x0.astype(np.float64) + x1.astype(np.float64) + x2.astype(np.float64)
+    err = np.abs(total - x.astype(np.float64))
+    assert np.all(err <= np.abs(x.astype(np.float64)) * 2.0 ** -24)           # 3 x 8 bits cover the 24-bit significand
+    assert np.mean(err == 0) > 0.99                                           # ... and almost always exactly
+
+
+def test_six_piece_products_give_an_fp32_class_dot_product():
+    """sum_k a_k b_k over K = 2304 (a 3x3 conv over 256 channels) per output: the six piece products of weight >= 2^-16,
+    accumulated like the matrix core does (fp32 accumulator over k-blocks of 16), against float64 -- next to a plain fp32
+    FMA chain over the same data.  The split form must not be less accurate than the fp32 chain."""
+    rng = np.random.default_rng(1)
+    M, K = 512, 2304
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    b = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
+    ref = np.einsum("mk,mk->m", a.astype(np.float64), b.astype(np.float64))
+    a0, a1, a2, _, _ = split3(a)
+    b0, b1, b2, _, _ = split3(b)
+    acc = np.zeros(M, dtype=np.float32)
+    for k0 in range(0, K, 16):
+        s = slice(k0, k0 + 16)
+        for pa, pb in ((a2, b0), (a1, b1), (a0, b2), (a1, b0), (a0, b1), (a0, b0)):       # smallest weights first
+            # (a block of 16 exact bf16 x bf16 products summed at >= fp32 precision, then one fp32 accumulate)
+            acc = (acc.astype(np.float64) + np.einsum("mk,mk->m", pa[:, s].astype(np.float64), pb[:, s].astype(np.float64))).astype(np.float32)
+    chain = np.zeros(M, dtype=np.float32)
+    for k in range(K):
+        chain = (chain.astype(np.float64) + a[:, k].astype(np.float64) * b[:, k].astype(np.float64)).astype(np.float32)   # fmaf chain
+    scale = np.abs(ref).max()
+    e_split, e_chain = np.abs(acc - ref).max() / scale, np.abs(chain - ref).max() / scale
+    assert e_split <= 1.25 * e_chain + 1e-8, (e_split, e_chain)
+    assert e_split < 2e-6
+    # dropping one of the 2^-16 terms is visible: the six-term choice is the minimal one
+    acc5 = np.zeros(M, dtype=np.float64)
+    for pa, pb in ((a2, b0), (a0, b2), (a1, b0), (a0, b1), (a0, b0)):
+        acc5 += np.einsum("mk,mk->m", pa.astype(np.float64), pb.astype(np.float64))
+    assert np.abs(acc5 - ref).max() / scale > 4 * e_split

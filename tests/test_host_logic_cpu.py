@@ -234,3 +234,45 @@ def test_window_grid_covers_the_image_in_the_reference_visiting_order(H, W, crop
     assert cover.min() >= 1                                                # every pixel is seen by at least one window
     if (H, W, crop) == (1024, 2048, 769):
         assert len(wins) == 2 * 4                                          # Cityscapes full frame: 8 forward passes
+
+
+def test_bank_ring_bookkeeping_follows_dequeue_and_enqueue():
+    """The host mirror of the memory bank's ring bookkeeping (hipops.DeviceMemoryBank.mirror_counts, the same arithmetic
+    u2pl_bank_enqueue_f32 applies to its device state) against the reference's dequeue_and_enqueue (utils.py:27-47:
+    queue = cat(queue, keys); keep the last `queue_size`; ptr = queue_size once full, else (ptr + batch) % queue_size),
+    over a sequence that fills, wraps several times and once delivers more keys than the ring holds.  The kernel's slot
+    arithmetic (slot of new key j = (tail + j) % cap, only the last `cap` keys of an over-long batch written) is replayed
+    on a CPU array so that the logical window [head, head + len) can be compared ELEMENT by element with the FIFO."""
+    from u2pl_amd import hipops as H
+    caps = [7, 5, 11]
+    bank = H.DeviceMemoryBank(3, caps, feat_dim=1, device="cpu")
+    rng = np.random.RandomState(3)
+    fifo = [[] for _ in caps]                      # the reference: python lists of key ids
+    ptr_ref = [0] * len(caps)
+    ring = [np.full(c, -1, dtype=np.int64) for c in caps]
+    next_id = 0
+    for it in range(60):
+        counts = [int(rng.randint(0, 5)) for _ in caps]
+        if it == 17:
+            counts[1] = 13                         # more new keys than the class-1 ring holds
+        if it == 33:
+            counts = [0, 0, 0]                     # a step without keys
+        for c, n in enumerate(counts):
+            keys = list(range(next_id, next_id + n))
+            next_id += n
+            # the kernel: tail = (head + len) % cap, the last min(n, cap) keys land at (tail + j) % cap
+            tail = (bank.head[c] + bank.length[c]) % caps[c]
+            skip = max(0, n - caps[c])
+            for j in range(skip, n):
+                ring[c][(tail + j) % caps[c]] = keys[j]
+            # the reference
+            fifo[c] = (fifo[c] + keys)[-caps[c]:]
+            if len(fifo[c]) >= caps[c]:
+                ptr_ref[c] = caps[c]
+            else:
+                ptr_ref[c] = (ptr_ref[c] + n) % caps[c]
+        bank.mirror_counts(counts)
+        for c in range(len(caps)):
+            assert bank.length[c] == len(fifo[c]) and bank.ptr[c] == ptr_ref[c], (it, c)
+            window = [int(ring[c][(bank.head[c] + j) % caps[c]]) for j in range(bank.length[c])]
+            assert window == fifo[c], (it, c, window, fifo[c])

@@ -234,10 +234,10 @@ def main():
     wt = KN.CONV_ALGO["wino"]
     conv_algo = ("student: bf16-operand implicit GEMM on v_mfma_f32_32x32x16_bf16 (fwd, dgrad, wgrad; direct, no Winograd); "
                  "teacher: fp32 as in the headline" if args.bf16 else
-                 "fp32 implicit GEMM on v_mfma_f32_32x32x2_f32 for every layer (U2PL_CONV_WINO=0)" if wt not in (2, 4) else
+                 "fp32 implicit GEMM for every layer (U2PL_CONV_WINO=0)" if wt not in (2, 4) else
                  f"fp32 Winograd F({wt}x{wt},3x3) for the stride-1 3x3 layers whose tile padding leaves >= "
                  f"{KN.CONV_ALGO['min_gain']}x fewer multiplies (forward, data and weight gradients; component products on "
-                 "the same fp32 MFMA kernel), direct fp32 implicit GEMM elsewhere; U2PL_CONV_WINO=0|2|4 selects")
+                 "the same implicit-GEMM kernel), direct fp32 implicit GEMM elsewhere; U2PL_CONV_WINO=0|2|4 selects")
     from u2pl_amd import roofline as _RLq
     if not args.bf16:
         conv_algo += ("; fp32 products: " + ("exact three-way bf16 split of both operands, six piece products accumulated in fp32 on the bf16 "

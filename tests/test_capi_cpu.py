@@ -67,3 +67,23 @@ def test_winograd_layer_policy():
         assert K.wino_tile(256, 256, 3, 3, 1, 1, 1, 193, 193) == 2
     finally:
         K.CONV_ALGO.update(saved)
+
+
+def test_conv_arithmetic_switch_and_statistics_block_count():
+    """u2pl_conv_set_split / u2pl_conv_get_split (host state, no GPU needed) and the planner query that sizes the fused
+    BatchNorm-statistics partials: in the split form every launch is ONE grid of 128-row body tiles (no tail launch), with
+    the fp32 instruction the planner adds a tail of smaller tiles for the partial last round -- the Python layer sizes its
+    partial buffer with this query right before the launch, so the two must always agree with the launcher."""
+    L = _lib.lib().cdll
+    old = L.u2pl_conv_get_split()
+    try:
+        assert L.u2pl_conv_set_split(1) == old and L.u2pl_conv_get_split() == 1
+        M = 4 * 97 * 97                                     # 37636 pixels: 295 body tiles of 128 rows
+        assert L.u2pl_conv2d_fwd_stat_blocks(4, 97, 97, 256) == -(-M // 128)
+        assert L.u2pl_conv2d_fwd_stat_blocks(4, 97, 97, 64) == -(-M // 128)      # Cout <= 64: the single-launch shape
+        assert L.u2pl_conv_set_split(0) == 1 and L.u2pl_conv_get_split() == 0
+        if not os.environ.get("U2PL_IGEMM_TAIL"):
+            n = L.u2pl_conv2d_fwd_stat_blocks(4, 97, 97, 256)
+            assert n >= -(-M // 128)                         # body tiles in whole rounds + smaller tail tiles
+    finally:
+        L.u2pl_conv_set_split(old)

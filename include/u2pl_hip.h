@@ -256,6 +256,40 @@ int u2pl_conv2d_wgrad_f32(const float* dy, long lddy, const float* x, long ldx, 
 int u2pl_im2col_f32(const float* x, long ldx, float* col, int Kp, int N, int Hin, int Win, int Cin, int Hout,
                     int Wout, int R, int S, int stride, int pad, int dil, hipStream_t stream);
 
+/* ---- igemm_ws.hip (split-fp32 implicit GEMM with pre-split weights; round 4) -------------------------------------
+ * The weights of the network change once per optimizer step (train_semi.py:526-528 optimizer.step(), :531-548 the EMA
+ * teacher), the convolutions read them ~14 times per step (resnet.py:120-140 through the two student and two teacher
+ * passes and the backward).  u2pl_weight_split3_f32 splits a row-major fp32 matrix [rows][K] (K % 32 == 0) ONCE into the
+ * three bf16 piece planes of the split-fp32 arithmetic, stored chunk-major in the image the GEMM's LDS tile has; the
+ * *_ws entry points are the conv.hip calls of the same name with that buffer in place of the fp32 weight pointer:
+ *   forward:        the [Cout][R*S*Cin] matrix (the weight itself, channels_last)
+ *   data gradient:  the transposed [Cin][R*S*Cout] matrix (u2pl_weight_transpose_f32)
+ *   Winograd:       the batch of a*a component matrices U[a*a][O][C] of u2pl_wino_weight_f32 (batch = a*a)
+ * Same arithmetic, same summation order as conv.hip's split kernels: results are bit-identical to u2pl_conv2d_fwd_f32 /
+ * _bnstats / _bnact / u2pl_conv2d_dgrad_f32 / u2pl_gemm_batched_f32 under U2PL_CONV_SPLIT=1 (statistics partial sums
+ * included; stats_partial has u2pl_igemm_ws_stat_blocks rows).  Cout > 64 only (narrower layers stay on conv.hip). */
+size_t u2pl_weight_split3_bytes(int rows, int K, int batch);
+int u2pl_weight_split3_f32(const float* w, long zw, int rows, int K, int batch, void* out, hipStream_t stream);
+int u2pl_igemm_ws_stat_blocks(int N, int Hout, int Wout);
+/* main-loop variant of the ws kernel (A/B switch, same results): 1 = pinned issue order (default), 0 = compiler-scheduled */
+int u2pl_igemm_ws_set_sched(int v);
+int u2pl_conv2d_fwd_ws_f32(const float* x, long ldx, const void* wsplit, const float* bias, float* y, long ldy, int N,
+                           int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S, int stride, int pad,
+                           int dil, hipStream_t stream);
+int u2pl_conv2d_fwd_bnstats_ws_f32(const float* x, long ldx, const void* wsplit, const float* bias, float* y, long ldy,
+                                   int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S,
+                                   int stride, int pad, int dil, const float* pivot, float* stats_partial,
+                                   hipStream_t stream);
+int u2pl_conv2d_fwd_bnact_ws_f32(const float* x, long ldx, const void* wsplit, const float* bias, float* y, long ldy, int N,
+                                 int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S, int stride,
+                                 int pad, int dil, const float* mean, const float* invstd, const float* gamma,
+                                 const float* beta, const float* res, long ldr, int relu, hipStream_t stream);
+int u2pl_conv2d_dgrad_ws_f32(const float* dy, long lddy, const void* wTsplit, float* dx, long lddx, int N, int Hin,
+                             int Win, int Cin, int Hout, int Wout, int Cout, int R, int S, int stride, int pad, int dil,
+                             hipStream_t stream);
+int u2pl_gemm_batched_ws_f32(const float* x, long ldx, long zx, const void* wsplit, float* y, long ldy, long zy, long M,
+                             int K, int Nn, int batch, hipStream_t stream);
+
 /* ---- nn.hip ----------------------------------------------------------------- */
 /* nn.SyncBatchNorm / BatchNorm2d (base.py:6-8 get_syncbn): statistics, apply (+residual, ReLU,
  * Dropout2d scale: resnet.py:120-140, decoder.py:79-104), backward; sums are double [2][C] so the

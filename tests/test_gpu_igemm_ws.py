@@ -1,0 +1,191 @@
+"""-m gpu: the pre-split-weight GEMM (csrc/igemm_ws.hip) against conv.hip's in-loop split kernels.
+
+Both compute the split-fp32 product with the same six piece products in the same order, so every output -- forward,
+fused BatchNorm statistics, fused eval-mode BatchNorm, data gradient, Winograd component batches -- must be the SAME
+BITS (the conv.hip kernels themselves are checked against torch fp32 / float64 in test_gpu_conv_stack.py).  Plus the
+once-per-step operand cache: a cached split must be rebuilt when the arena optimizer or a torch in-place op changes the
+weight, and only then."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+CL = torch.channels_last
+
+
+def K():
+    from u2pl_amd import nn as Kn
+    return Kn
+
+
+@pytest.fixture
+def ws_switch():
+    Kn = K()
+    saved = (dict(Kn.CONV_ALGO), dict(Kn.CONV_WS))
+    yield Kn
+    Kn.CONV_ALGO.update(saved[0])
+    Kn.CONV_WS.update(saved[1])
+
+
+# Cin, Cout, k, stride, dil, H, W, N, bias        (Cout > 64: the layers the ws kernel serves)
+CASES = [
+    (1024, 256, 1, 1, 1, 33, 29, 2, False),     # layer3 conv1: pointwise, one 256-wide column tile
+    (256, 1024, 1, 1, 1, 33, 29, 2, False),     # layer3 conv3: four column tiles
+    (512, 128, 1, 1, 1, 25, 25, 2, False),      # layer2 conv1: the 128-wide tile
+    (256, 512, 1, 2, 1, 33, 33, 2, False),      # layer2 downsample: strided gather (not pointwise)
+    (128, 128, 3, 2, 1, 33, 33, 1, False),      # stride-2 3x3
+    (512, 256, 3, 1, 12, 25, 21, 1, True),      # ASPP-like dilated 3x3 with bias, halo > map on one side
+    (2048, 256, 3, 1, 36, 13, 13, 1, False),    # ASPP d36
+    (320, 320, 1, 1, 1, 19, 17, 1, True),       # Cout not a multiple of the tile, rows padded in the split planes
+    (64, 256, 1, 1, 1, 40, 40, 1, False),       # K = 64: two chunks (prologue / clamped prefetch only)
+    (32, 96, 1, 1, 1, 21, 21, 1, False),        # K = 32: a single chunk
+]
+
+
+def _run(Kn, ws_on, conv, x, gy, pivot=None):
+    Kn.CONV_WS["on"] = ws_on
+    x = x.detach().clone().requires_grad_(True)
+    conv.weight.grad = None
+    if pivot is None:
+        y = conv(x)
+        sums = None
+    else:
+        y, sums = conv(x, stat_pivot=pivot)
+    y.backward(gy)
+    torch.cuda.synchronize()
+    return y.detach(), x.grad.detach(), sums
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,dil,H,W,N,bias", CASES)
+@pytest.mark.parametrize("sched", [1, 0])
+def test_ws_forward_dgrad_stats_bit_identical(Cin, Cout, k, stride, dil, H, W, N, bias, sched, ws_switch):
+    Kn = ws_switch
+    Kn.CONV_ALGO.update(wino=0)
+    torch.manual_seed(Cin * 7 + Cout + k + dil)
+    conv = Kn.Conv2d(Cin, Cout, k, stride=stride, padding=dil * (k // 2), dilation=dil, bias=bias).to(DEV)
+    x = torch.randn(N, Cin, H, W, device=DEV).contiguous(memory_format=CL)
+    Ho = (H + 2 * dil * (k // 2) - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * dil * (k // 2) - dil * (k - 1) - 1) // stride + 1
+    gy = torch.randn(N, Cout, Ho, Wo, device=DEV).contiguous(memory_format=CL)
+    pivot = torch.randn(Cout, device=DEV) * 0.1
+    from u2pl_amd._lib import query
+    old = query("u2pl_igemm_ws_set_sched", sched)
+    try:
+        _check_case(Kn, conv, x, gy, pivot, Cout)
+    finally:
+        query("u2pl_igemm_ws_set_sched", old)
+
+
+def _check_case(Kn, conv, x, gy, pivot, Cout):
+    y0, dx0, _ = _run(Kn, False, conv, x, gy)
+    y1, dx1, _ = _run(Kn, True, conv, x, gy)
+    assert torch.equal(y0, y1), f"forward differs: {(y0 - y1).abs().max().item():.3e}"
+    assert torch.equal(dx0, dx1), f"data gradient differs: {(dx0 - dx1).abs().max().item():.3e}"
+    ys0, _, s0 = _run(Kn, False, conv, x, gy, pivot)
+    ys1, _, s1 = _run(Kn, True, conv, x, gy, pivot)
+    assert torch.equal(ys0, ys1) and torch.equal(ys0, y0)
+    assert torch.equal(s0[: 2 * Cout], s1[: 2 * Cout]), "fused BatchNorm statistics differ"
+
+
+@pytest.mark.parametrize("Cin,Cout,dil,H,W,N", [(256, 256, 2, 33, 29, 2), (512, 512, 4, 21, 21, 1), (128, 128, 1, 37, 37, 1)])
+@pytest.mark.parametrize("mt", [4, 2])
+def test_ws_winograd_component_batches_bit_identical(Cin, Cout, dil, H, W, N, mt, ws_switch):
+    Kn = ws_switch
+    Kn.CONV_ALGO.update(wino=mt, min_gain=0.0)
+    torch.manual_seed(Cin + Cout + dil + mt)
+    conv = Kn.Conv2d(Cin, Cout, 3, padding=dil, dilation=dil, bias=False).to(DEV)
+    x = torch.randn(N, Cin, H, W, device=DEV).contiguous(memory_format=CL)
+    gy = torch.randn(N, Cout, H, W, device=DEV).contiguous(memory_format=CL)
+    y0, dx0, _ = _run(Kn, False, conv, x, gy)
+    y1, dx1, _ = _run(Kn, True, conv, x, gy)
+    assert torch.equal(y0, y1), f"Winograd forward differs: {(y0 - y1).abs().max().item():.3e}"
+    assert torch.equal(dx0, dx1), f"Winograd data gradient differs: {(dx0 - dx1).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("res,relu", [(False, True), (True, True), (False, False)])
+def test_ws_eval_batchnorm_epilogue_bit_identical(res, relu, ws_switch):
+    Kn = ws_switch
+    Kn.CONV_ALGO.update(wino=0)
+    torch.manual_seed(5)
+    conv = Kn.Conv2d(256, 384, 1, bias=False).to(DEV)
+    bn = Kn.BatchNorm2d(384).to(DEV).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.2)
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.weight.normal_(1.0, 0.2)
+        bn.bias.normal_(0, 0.2)
+    x = torch.randn(2, 256, 27, 23, device=DEV).contiguous(memory_format=CL)
+    r = torch.randn(2, 384, 27, 23, device=DEV).contiguous(memory_format=CL) if res else None
+    outs = []
+    with torch.no_grad():
+        for on in (False, True):
+            Kn.CONV_WS["on"] = on
+            outs.append(Kn.conv_bn_eval(conv, bn, x, res=r, relu=relu))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_ws_operand_cache_follows_the_weights(ws_switch):
+    """the split planes are rebuilt when the weights change through the arena kernels (epoch) or through torch in-place
+    ops (version) -- and reused otherwise"""
+    Kn = ws_switch
+    Kn.CONV_ALGO.update(wino=0)
+    Kn.CONV_WS["on"] = True
+    torch.manual_seed(11)
+    conv = Kn.Conv2d(128, 256, 1, bias=False).to(DEV)
+    arena = Kn.ParamArena([[conv.weight]])
+    x = torch.randn(1, 128, 19, 19, device=DEV).contiguous(memory_format=CL)
+
+    def fwd(on):
+        Kn.CONV_WS["on"] = on
+        with torch.no_grad():
+            y = conv(x)
+        torch.cuda.synchronize()
+        return y
+
+    y_a = fwd(True)
+    key = (conv.weight.data_ptr(), "f")
+    stamp = Kn._WCACHE[key]["stamp"]
+    assert torch.equal(fwd(True), y_a) and Kn._WCACHE[key]["stamp"] == stamp      # reused
+    # arena SGD step (raw-pointer write: the epoch marks it)
+    arena.grad.normal_(0, 1.0)
+    arena.sgd_step([0.1], 0.9, 1e-4)
+    y_b = fwd(True)
+    assert Kn._WCACHE[key]["stamp"] != stamp
+    assert not torch.equal(y_a, y_b)
+    assert torch.equal(y_b, fwd(False)), "stale split planes after an arena optimizer step"
+    # torch in-place write (load_state_dict / init paths: the version marks it)
+    with torch.no_grad():
+        conv.weight.mul_(0.5)
+    y_c = fwd(True)
+    assert torch.equal(y_c, fwd(False)), "stale split planes after a torch in-place update"
+    assert not torch.equal(y_c, y_b)
+
+
+def test_ws_nonfinite_operands_give_nonfinite_outputs(ws_switch):
+    """documented semantics of the split arithmetic: an Inf or NaN operand makes every output
+    it contributes to NaN (the fp32 matrix instruction would keep +-Inf for Inf * finite) -- never a finite value"""
+    Kn = ws_switch
+    Kn.CONV_ALGO.update(wino=0)
+    torch.manual_seed(3)
+    conv = Kn.Conv2d(64, 128, 1, bias=False).to(DEV)
+    x = torch.randn(1, 64, 9, 9, device=DEV).contiguous(memory_format=CL)
+    for on in (True, False):
+        Kn.CONV_WS["on"] = on
+        for bad in (float("inf"), float("-inf"), float("nan")):
+            xx = x.clone()
+            xx[0, 5, 3, 4] = bad
+            with torch.no_grad():
+                y = conv(xx)
+            torch.cuda.synchronize()
+            assert not torch.isfinite(y[0, :, 3, 4]).any(), "a non-finite input produced finite outputs"
+            mask = torch.ones(9, 9, dtype=torch.bool, device=DEV)
+            mask[3, 4] = False
+            assert torch.isfinite(y[0][:, mask]).all(), "a non-finite input leaked into other pixels"
+        with torch.no_grad():
+            w0 = conv.weight[7, 9, 0, 0].item()
+            conv.weight[7, 9, 0, 0] = float("inf")
+            y = conv(x)
+            conv.weight[7, 9, 0, 0] = w0
+        torch.cuda.synchronize()
+        assert not torch.isfinite(y[0, 7]).any() and torch.isfinite(y[0, :7]).all() and torch.isfinite(y[0, 8:]).all()

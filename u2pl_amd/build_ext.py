@@ -14,6 +14,11 @@ FLAGS = [
 ]
 
 
+# per-file switches.  igemm_ws.hip: no SLP vectorisation -- it fuses the split's subtractions into v_pk_add_f32 (+ a
+# hazard nop each), which costs more beside matrix instructions than the two plain adds it replaces
+EXTRA = {"igemm_ws.hip": ["-fno-slp-vectorize"]}
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -43,7 +48,7 @@ def build(force=False, verbose=True, variant=None, defs=()):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-D" + d for d in defs] + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + EXTRA.get(os.path.basename(src), []) + ["-D" + d for d in defs] + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))

@@ -22,60 +22,7 @@
 #include "common.h"
 #include "u2pl_hip.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define BK 32
-#define LDP (BK + 4)  // LDS row pitch (floats): 16 B aligned, breaks the 128 B stride
-
-struct ConvGeom {
-    int N, Hin, Win, Cin, Hout, Wout, Cout, R, S;
-    int mul, off_h, off_w, step, log2div;  // gather: (o*mul + off + r*step) >> log2div
-};
-
-// branch-free: returns validity, writes a coordinate that is ALWAYS in [0, lim).
-__device__ __forceinline__ bool gather_coord(int base, int tap, int step, int log2div, int lim, int& out) {
-    const int v = base + tap * step;
-    const int q = v >> log2div;
-    const bool ok = (v >= 0) & ((v & ((1 << log2div) - 1)) == 0) & (q < lim);
-    out = ok ? q : 0;
-    return ok;
-}
-
-// WM = wave rows of the block (2: 4 waves / 256 threads; 4: 8 waves / 512 threads with half the rows per wave)
-// BF: the A / B tiles are rounded to bf16 (round-to-nearest-even) on their way into LDS and multiplied on the bf16
-// matrix cores (v_mfma_f32_32x32x16_bf16, 16x the f32-input rate) with fp32 accumulation -- BASELINE configs[4]
-// ("config 5": reduced-precision student, fp32 master weights / EMA teacher).  Tensors in HBM stay fp32.
-// BF == 3 ("split fp32"): fp32 products ON THE bf16 MATRIX CORES without giving up fp32 accuracy.  Every operand is split
-// exactly into three bf16 pieces x = x0 + x1 + x2 (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1): 3 x 8 = 24
-// significand bits, both subtractions are exact in fp32) while it is staged into LDS, and a product a.b is accumulated
-// in fp32 from the six piece products whose weight is >= 2^-16: a0b0 + a0b1 + a1b0 + a0b2 + a1b1 + a2b0.  The dropped
-// terms (a1b2, a2b1, a2b2) are <= 2^-23 |ab| -- the size of ONE fp32 rounding, i.e. of what the fp32 MFMA's own
-// accumulation commits K times per output.  Six v_mfma_f32_32x32x16_bf16 (6 x 32 cycles for a 32x32x16 block) replace
-// eight v_mfma_f32_32x32x2_f32 (8 x 64 cycles): 2.7x fewer matrix-pipe cycles for the same fp32-class result
-// (measured against float64 in tests/test_gpu_conv_stack.py).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#define LDPH (BK + 8)   // LDS row pitch of the bf16 tiles (elements): 80 B, 16 B aligned
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-// two fp32 -> packed bf16 pair (lo in bits 0..15): ONE v_cvt_pk_bf16_f32 on gfx950 (round to nearest even, NaN stays a
-// quiet NaN, Inf stays Inf) instead of the 4-5 integer VALU operations per element of an add-and-shift rounding (which
-// also turned small-payload NaNs into Inf)
-__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
-    bf16x2_t v;
-    v[0] = (__bf16)lo;
-    v[1] = (__bf16)hi;
-    return *(unsigned*)&v;
-}
-__device__ __forceinline__ uint2 pack4_bf16(float4 v) { return make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w)); }
-// exact three-way split of four fp32 values into bf16 pieces (see BF == 3 below): v = p0 + p1 + p2 up to 2^-24 |v|
-__device__ __forceinline__ float bf16_lo_f(unsigned p) { return __uint_as_float(p << 16); }
-__device__ __forceinline__ float bf16_hi_f(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
-__device__ __forceinline__ void split3_bf16(float4 v, uint2& p0, uint2& p1, uint2& p2) {
-    p0 = pack4_bf16(v);
-    const float4 r1 = make_float4(v.x - bf16_lo_f(p0.x), v.y - bf16_hi_f(p0.x), v.z - bf16_lo_f(p0.y), v.w - bf16_hi_f(p0.y));
-    p1 = pack4_bf16(r1);
-    const float4 r2 = make_float4(r1.x - bf16_lo_f(p1.x), r1.y - bf16_hi_f(p1.x), r1.z - bf16_lo_f(p1.y), r1.w - bf16_hi_f(p1.y));
-    p2 = pack4_bf16(r2);
-}
+#include "conv_geom.h"
 
 template <int TM, int TN, int WM = 2, int BF = 0>
 __global__ __launch_bounds__(128 * WM, WM) void k_conv_igemm(const float* __restrict__ x, long ldx,

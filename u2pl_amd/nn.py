@@ -112,6 +112,92 @@ CONV_ALGO = {"wino": int(os.environ.get("U2PL_CONV_WINO", "4")), "min_gain": flo
              "wgrad": int(os.environ.get("U2PL_WINO_WGRAD", "1")), "bf16": int(os.environ.get("U2PL_CONV_BF16", "0"))}
 
 
+# ---- weight operands derived once per step ------------------------------------------------------------------
+# The convolutions read each weight ~14 times per step (two student + two teacher passes, the backward) but the weights
+# change ONCE per step (optimizer / EMA update on the flat arenas): the operands the kernels want -- the three bf16 piece
+# planes of the split-fp32 arithmetic (u2pl_weight_split3_f32, consumed by the *_ws entry points of csrc/igemm_ws.hip), of
+# the weight itself (forward), of its transpose (data gradient) and of its Winograd transforms -- are built on first use
+# and kept until the weights change.  A cached operand is valid for (WEIGHT_EPOCH, tensor._version): the arena updates
+# (ParamArena.sgd_step / adam_step / ema_from / copy_from write through raw pointers) bump the epoch, every torch in-place
+# op (load_state_dict, init) bumps the version.  U2PL_CONV_WS=0 keeps every layer on conv.hip's in-loop split.
+WEIGHT_EPOCH = [0]
+CONV_WS = {"on": os.environ.get("U2PL_CONV_WS", "1") != "0"}
+_WCACHE = {}
+
+
+def bump_weight_epoch():
+    WEIGHT_EPOCH[0] += 1
+
+
+def _derived(weight, kind, nbytes, build):
+    """-> device buffer (uint8) of `nbytes`, filled by build(buf) when the weight changed since it was last built.  The
+    buffer is allocated once per (weight, kind) and rebuilt in place; readers on other streams wait for the build event,
+    a rebuild waits for the streams that read the previous contents."""
+    key = (weight.data_ptr(), kind)
+    stamp = (WEIGHT_EPOCH[0], weight._version)
+    ent = _WCACHE.get(key)
+    cur = torch.cuda.current_stream()
+    if ent is None or ent["buf"].numel() != nbytes or ent["buf"].device != weight.device:
+        ent = _WCACHE[key] = {"buf": torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=weight.device), "stamp": None,
+                              "event": torch.cuda.Event(), "stream": cur, "readers": set()}
+    if ent["stamp"] != stamp:
+        for st in ent["readers"]:
+            cur.wait_stream(st)
+        if ent["stream"] != cur and ent["stamp"] is not None:
+            cur.wait_stream(ent["stream"])
+        ent["readers"] = set()
+        build(ent["buf"])
+        ent["event"].record(cur)
+        ent["stream"], ent["stamp"] = cur, stamp
+    elif ent["stream"] != cur and cur not in ent["readers"]:
+        cur.wait_event(ent["event"])
+        ent["readers"].add(cur)
+    return ent["buf"]
+
+
+def _ws_ok(n_cols, k_depth):
+    """can this GEMM (n_cols output channels, reduction depth k_depth) take the pre-split-weight kernel?"""
+    return (CONV_WS["on"] and not CONV_ALGO.get("bf16", 0) and n_cols > 64 and k_depth % 32 == 0
+            and query("u2pl_conv_get_split") == 1)
+
+
+def _split_of(weight, kind, rows, K, batch, src):
+    """split planes of `batch` matrices [rows][K]; src() -> the fp32 source tensor (a temporary is fine)"""
+    nbytes = query("u2pl_weight_split3_bytes", rows, K, batch)
+
+    def build(buf):
+        w = src()
+        call("u2pl_weight_split3_f32", w, rows * K, rows, K, batch, buf)
+    return _derived(weight, kind, nbytes, build)
+
+
+def ws_forward(weight):
+    Cout, Cin, R, S = weight.shape
+    return _split_of(weight, "f", Cout, R * S * Cin, 1, lambda: weight)
+
+
+def ws_dgrad(weight):
+    Cout, Cin, R, S = weight.shape
+
+    def src():
+        wT = torch.empty(Cin * R * S * Cout, dtype=torch.float32, device=weight.device)
+        call("u2pl_weight_transpose_f32", weight, wT, Cout, R * S, Cin)
+        return wT
+    return _split_of(weight, "d", Cin, R * S * Cout, 1, src)
+
+
+def ws_wino(weight, transposed, mt):
+    Cout, Cin = weight.shape[:2]
+    a2 = (mt + 2) ** 2
+    rows, K = (Cin, Cout) if transposed else (Cout, Cin)
+
+    def src():
+        U = torch.empty(a2 * Cout * Cin, dtype=torch.float32, device=weight.device)
+        call("u2pl_wino_weight_f32", weight, Cout, Cin, int(transposed), mt, U)
+        return U
+    return _split_of(weight, ("wd" if transposed else "wf") + str(mt), rows, K, a2, src)
+
+
 def wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W):
     """-> Winograd output-tile size (2 / 4) for this layer, or 0 for the direct kernel."""
     mt = CONV_ALGO["wino"]
@@ -131,12 +217,16 @@ def _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, mt, transposed,
     a2 = (mt + 2) ** 2
     Ci, Co = (Cout, Cin) if transposed else (Cin, Cout)
     tiles = query("u2pl_wino_tiles", N, H, W, dil, mt)
-    U = torch.empty(a2 * Cout * Cin, dtype=torch.float32, device=dev)
-    call("u2pl_wino_weight_f32", weight, Cout, Cin, int(transposed), mt, U)
     V = torch.empty(a2 * tiles * Ci, dtype=torch.float32, device=dev)
     call("u2pl_wino_input_f32", x, ldx, N, H, W, Ci, dil, mt, V)
     Mb = torch.empty(a2 * tiles * Co, dtype=torch.float32, device=dev)
-    call("u2pl_gemm_batched_f32", V, Ci, tiles * Ci, U, Co * Ci, Mb, Co, tiles * Co, tiles, Ci, Co, a2)
+    if _ws_ok(Co, Ci) and weight.is_leaf:
+        call("u2pl_gemm_batched_ws_f32", V, Ci, tiles * Ci, ws_wino(weight, transposed, mt), Mb, Co, tiles * Co, tiles, Ci,
+             Co, a2)
+    else:
+        U = torch.empty(a2 * Cout * Cin, dtype=torch.float32, device=dev)
+        call("u2pl_wino_weight_f32", weight, Cout, Cin, int(transposed), mt, U)
+        call("u2pl_gemm_batched_f32", V, Ci, tiles * Ci, U, Co * Ci, Mb, Co, tiles * Co, tiles, Ci, Co, a2)
     part = None
     if pivot is not None:
         nblk = query("u2pl_wino_stat_blocks", tiles, Co)
@@ -187,12 +277,20 @@ class _ConvFn(torch.autograd.Function):
                 sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=x.device)
                 call("u2pl_colreduce_finish_f32", part, part.shape[0], Cout, sums)
         elif pivot is not None and pivot is not False:
-            nblk = query("u2pl_conv2d_fwd_stat_blocks", N, Ho, Wo, Cout)
+            ws = not use_bf and _ws_ok(Cout, R * S * Cin)
+            nblk = query("u2pl_igemm_ws_stat_blocks", N, Ho, Wo) if ws else query("u2pl_conv2d_fwd_stat_blocks", N, Ho, Wo, Cout)
             part = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=x.device)
-            call("u2pl_conv2d_fwd_bnstats" + sfx, x, ldx, weight, bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S, stride,
-                 pad, dil, pivot, part)
+            if ws:
+                call("u2pl_conv2d_fwd_bnstats_ws_f32", x, ldx, ws_forward(weight), bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout,
+                     R, S, stride, pad, dil, pivot, part)
+            else:
+                call("u2pl_conv2d_fwd_bnstats" + sfx, x, ldx, weight, bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S, stride,
+                     pad, dil, pivot, part)
             sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=x.device)
             call("u2pl_colreduce_finish_f32", part, nblk, Cout, sums)
+        elif not use_bf and _ws_ok(Cout, R * S * Cin):
+            call("u2pl_conv2d_fwd_ws_f32", x, ldx, ws_forward(weight), bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S,
+                 stride, pad, dil)
         else:
             call("u2pl_conv2d_fwd" + sfx, x, ldx, weight, bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil)
         ctx.save_for_backward(x, weight, col)
@@ -230,6 +328,9 @@ class _ConvFn(torch.autograd.Function):
             mt = wino_tile(Cp, Cin, R, S, stride, pad, dil, H, W) if (Cp == Cout and not ctx.bf) else 0
             if mt:   # data gradient = the same convolution with rotated taps and swapped channel roles
                 _wino_conv(gy, ldg, weight_k, None, dx, N, H, W, Cin, Cout, dil, mt, True)[0]
+            elif Cp == Cout and not ctx.bf and _ws_ok(Cin, R * S * Cout):
+                call("u2pl_conv2d_dgrad_ws_f32", gy, ldg, ws_dgrad(weight), dx, Cin, N, H, W, Cin, Ho, Wo, Cout, R, S, stride,
+                     pad, dil)
             else:
                 wT = torch.empty(Cin * R * S * Cp, dtype=torch.float32, device=dev)
                 call("u2pl_weight_transpose_f32", weight_k, wT, Cp, R * S, Cin)
@@ -679,6 +780,9 @@ def conv_bn_eval(conv, bn, x, res=None, relu=False):
     elif wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W):
         _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W),
                    False, None, epi)
+    elif _ws_ok(Cout, R * S * Cin):
+        call("u2pl_conv2d_fwd_bnact_ws_f32", x, ldx, ws_forward(weight), bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S,
+             stride, pad, dil, *epi)
     else:
         call("u2pl_conv2d_fwd_bnact_f32", x, ldx, weight, bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil,
              *epi)
@@ -1040,6 +1144,7 @@ class ParamArena:
             self.momentum_buf = torch.zeros_like(self.flat)
         b = self.bounds + [self.n] * 3
         lr = list(lrs) + [lrs[-1]] * 3
+        bump_weight_epoch()
         call("u2pl_sgd_step_f32", self.flat, self.grad, self.momentum_buf, self.n, b[0], b[1], float(lr[0]),
              float(lr[1]), float(lr[2]), float(momentum), float(weight_decay), int(self.steps == 0),
              float(grad_scale))
@@ -1054,6 +1159,7 @@ class ParamArena:
         lr = list(lrs) + [lrs[-1]] * 3
         bc1 = 1.0 - betas[0] ** self.steps
         bc2s = math.sqrt(1.0 - betas[1] ** self.steps)
+        bump_weight_epoch()
         call("u2pl_adam_step_f32", self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.n, b[0], b[1], float(lr[0]),
              float(lr[1]), float(lr[2]), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), float(bc1),
              float(bc2s), float(grad_scale))
@@ -1068,7 +1174,9 @@ class ParamArena:
 
     def ema_from(self, other, decay):
         """self = decay*self + (1-decay)*other  (train_semi.py:543-548)."""
+        bump_weight_epoch()
         call("u2pl_ema_update_f32", self.flat, other.flat, self.n, float(decay), float(1 - decay))
 
     def copy_from(self, other):
+        bump_weight_epoch()
         self.flat.copy_(other.flat)

@@ -17,6 +17,7 @@ _CONV_GEOM = {
     "u2pl_conv2d_fwd_f32": 6, "u2pl_conv2d_fwd_bnstats_f32": 6, "u2pl_conv2d_fwd_bnact_f32": 6, "u2pl_conv2d_dgrad_f32": 5, "u2pl_conv2d_wgrad_f32": 7,
     "u2pl_conv2d_fwd_bf16op_f32": 6, "u2pl_conv2d_fwd_bnstats_bf16op_f32": 6, "u2pl_conv2d_dgrad_bf16op_f32": 5,
     "u2pl_conv2d_wgrad_bf16op_f32": 7,
+    "u2pl_conv2d_fwd_ws_f32": 6, "u2pl_conv2d_fwd_bnstats_ws_f32": 6, "u2pl_conv2d_fwd_bnact_ws_f32": 6, "u2pl_conv2d_dgrad_ws_f32": 5,
 }
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense
 # split fp32 (csrc/conv.hip BF == 3): one fp32 product = six bf16 piece products -> the matrix-pipe bound of the algorithm in
@@ -44,12 +45,30 @@ def _conv_flops(name, args):
     if name == "u2pl_gemm_batched_f32":      # (x, ldx, zx, w, zw, y, ldy, zy, M, K, Nn, batch)
         M, K, Nn, batch = args[8:12]
         return 2.0 * M * K * Nn * batch
+    if name == "u2pl_gemm_batched_ws_f32":   # (x, ldx, zx, wsplit, y, ldy, zy, M, K, Nn, batch)
+        M, K, Nn, batch = args[7:11]
+        return 2.0 * M * K * Nn * batch
     if name == "u2pl_wgrad_batched_f32":     # (dy, lddy, zdy, x, ldx, zx, part, M, Cin, Cout, batch)
         M, Cin, Cout, batch = args[7:11]
         return 2.0 * M * Cin * Cout * batch
     i = _CONV_GEOM[name]
     N, Hin, Win, Cin, Hout, Wout, Cout, R, S = args[i:i + 9]
     return 2.0 * N * Hout * Wout * Cout * R * S * Cin
+
+
+def _conv_bytes(name, args):
+    """ALGORITHMIC HBM bytes of one igemm-group launch: the A operand read once (an R x S gather re-reads overlapping
+    pixels from cache, not from memory), the B operand once (fp32 weights: 4 B/element; pre-split planes: 6 B), the
+    output written once.  What the kernel moves above this figure is re-reads of A across column tiles / of B across
+    row tiles that L2 / MALL did not absorb."""
+    if name in ("u2pl_gemm_batched_f32", "u2pl_gemm_batched_ws_f32"):
+        M, K, Nn, batch = args[8:12] if name == "u2pl_gemm_batched_f32" else args[7:11]
+        wb = 6 if name.endswith("_ws_f32") else 4
+        return batch * (4.0 * M * K + wb * Nn * K + 4.0 * M * Nn)
+    i = _CONV_GEOM[name]
+    N, Hin, Win, Cin, Hout, Wout, Cout, R, S = args[i:i + 9]
+    wb = 6 if "_ws_" in name else 4
+    return 4.0 * N * Hin * Win * Cin + wb * Cout * R * S * Cin + 4.0 * N * Hout * Wout * Cout
 
 
 def profile_step(step_fn):
@@ -63,17 +82,20 @@ def profile_step(step_fn):
     agg, shapes = {}, {}
     agg["_dense"] = replay_dense(rec)
     for name, args, e0, e1, nk in [r[:4] + (r[7],) for r in rec]:
-        d = agg.setdefault(name, dict(ms=0.0, calls=0, flops=0.0, kernels=0))
+        d = agg.setdefault(name, dict(ms=0.0, calls=0, flops=0.0, kernels=0, bytes=0.0))
+        if name in MFMA_GROUPS["igemm"]:
+            d["bytes"] += _conv_bytes(name, args)
         ms = e0.elapsed_time(e1)
         d["ms"] += ms
         d["calls"] += 1
         d["kernels"] += nk
         if name == "u2pl_wgrad_batched_f32":
             d["flops"] += _conv_flops(name, args)
-        elif name == "u2pl_gemm_batched_f32":
+        elif name in ("u2pl_gemm_batched_f32", "u2pl_gemm_batched_ws_f32"):
             fl = _conv_flops(name, args)
             d["flops"] += fl
-            key = ("wino_gemm", args[11], args[8], 1, args[9], args[8], 1, args[10], 1, 1, 1, 0, 1)
+            o = 8 if name == "u2pl_gemm_batched_f32" else 7
+            key = ("wino_gemm", args[o + 3], args[o], 1, args[o + 1], args[o], 1, args[o + 2], 1, 1, 1, 0, 1)
             sd = shapes.setdefault(key, dict(ms=0.0, calls=0, flops=0.0))
             sd["ms"] += ms
             sd["calls"] += 1
@@ -82,7 +104,7 @@ def profile_step(step_fn):
             fl = _conv_flops(name, args)
             d["flops"] += fl
             i = _CONV_GEOM[name]
-            key = (name[12:-4].replace("fwd_bnstats", "fwd").replace("fwd_bnact", "fwd").replace("_bf16op", "@bf16"),) + tuple(args[i:i + 9]) + tuple(args[i + 9:i + 12])
+            key = (name[12:-4].replace("fwd_bnstats", "fwd").replace("fwd_bnact", "fwd").replace("_bf16op", "@bf16").replace("_ws", "@ws"),) + tuple(args[i:i + 9]) + tuple(args[i + 9:i + 12])
             sd = shapes.setdefault(key, dict(ms=0.0, calls=0, flops=0.0))
             sd["ms"] += ms
             sd["calls"] += 1
@@ -93,7 +115,8 @@ def profile_step(step_fn):
 
 MFMA_GROUPS = {
     "igemm": ("u2pl_conv2d_fwd_f32", "u2pl_conv2d_fwd_bnstats_f32", "u2pl_conv2d_fwd_bnact_f32", "u2pl_conv2d_dgrad_f32",
-              "u2pl_gemm_batched_f32"),
+              "u2pl_gemm_batched_f32", "u2pl_conv2d_fwd_ws_f32", "u2pl_conv2d_fwd_bnstats_ws_f32", "u2pl_conv2d_fwd_bnact_ws_f32",
+              "u2pl_conv2d_dgrad_ws_f32", "u2pl_gemm_batched_ws_f32"),
     "wgrad": ("u2pl_conv2d_wgrad_f32", "u2pl_wgrad_batched_f32"),
     "bf16": ("u2pl_conv2d_fwd_bf16op_f32", "u2pl_conv2d_fwd_bnstats_bf16op_f32", "u2pl_conv2d_dgrad_bf16op_f32",
              "u2pl_conv2d_wgrad_bf16op_f32"),
@@ -245,12 +268,15 @@ def measure(trainer, batch, args, ms_per_step):
         nker = sum(x["kernels"] for x in ig)
         t = dense.get("igemm", t_ev)      # sustained-load time (dense replay); the gapped per-call events read shorter
         ach = fl / (t * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "k_conv_igemm (direct conv fwd [+BN-stat / eval-BN epilogue] + dgrad, and the batched Winograd component GEMMs; executed fp32 FLOPs)", "bound": "mfma",
+        out["roofline"] = {"kernel": "k_igemm_ws / k_conv_igemm (direct conv fwd [+BN-stat / eval-BN epilogue] + dgrad, and the batched Winograd component GEMMs; executed fp32 FLOPs)", "bound": "mfma",
                            "achieved": round(ach, 2), **_mfma_fields(ach), "unit": "TFLOP/s", "traffic": None,
                            "abi_calls_per_step": n, "kernel_launches_per_step": nker, "avg_launch_ms": round(t / max(nker, 1), 4),
                            "avg_abi_call_ms": round(t / n, 4),
                            "executed_tflop_per_step": round(fl / 1e12, 3), "ms_per_step": round(t, 2),
                            "ms_per_step_gapped_events": round(t_ev, 2),
+                           "algorithmic_bytes_per_step": round(sum(x.get("bytes", 0.0) for x in ig)),
+                           "algorithmic_bytes_note": "sum over the group's launches of A read once + B read once + output written "
+                                                     "once; compare with traffic (PMC) x launches",
                            "method": "all launches of the group re-issued back to back behind a spinning kernel, one HIP-event "
                                      "pair (sustained clocks, like a rocprofv3 run); ms_per_step_gapped_events = sum of "
                                      "per-call event pairs with idle gaps (boost clocks)"}

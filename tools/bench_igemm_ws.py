@@ -1,5 +1,5 @@
 """A/B of the split-fp32 GEMM kernels at the C ABI, GPU only: conv.hip's in-loop split (k_conv_igemm<..,3>) against
-igemm_ws.hip (pre-split weights, pipelined main loop; both main-loop variants) on the R101-DeepLabv3+ heavy-hitter shapes
+igemm_ws.hip (pre-split weights, pipelined main loop) on the R101-DeepLabv3+ heavy-hitter shapes
 (reference u2pl/models/resnet.py:120-140, base.py:54-83).  Variants are interleaved round-robin in ONE process, one
 HIP-event pair per launch train of REPS launches; reports the median over ROUNDS, fp32-equivalent TFLOP/s and the
 fraction of the split form's bound (2500 / 6 TF).  Every shape is also checked bit for bit between the variants."""
@@ -54,7 +54,7 @@ def main():
             M, K, Nn, batch = tiles, Cin, Cout, 36
             x = torch.randn(batch * M * K, device=DEV)
             w = torch.randn(batch * Nn * K, device=DEV) * (K ** -0.5)
-            ys = [torch.empty(batch * M * Nn, device=DEV) for _ in range(3)]
+            ys = [torch.empty(batch * M * Nn, device=DEV) for _ in range(2)]
             wsb = torch.empty(query("u2pl_weight_split3_bytes", Nn, K, batch), dtype=torch.uint8, device=DEV)
             call("u2pl_weight_split3_f32", w, Nn * K, Nn, K, batch, wsb)
             flops = 2.0 * M * K * Nn * batch
@@ -65,7 +65,7 @@ def main():
                 continue
             x = torch.randn(N * H * H * Cin, device=DEV)
             w = torch.randn(Cout * k * k * Cin, device=DEV) * ((k * k * Cin) ** -0.5)
-            ys = [torch.empty(N * Ho * Ho * Cout, device=DEV) for _ in range(3)]
+            ys = [torch.empty(N * Ho * Ho * Cout, device=DEV) for _ in range(2)]
             wsb = torch.empty(query("u2pl_weight_split3_bytes", Cout, k * k * Cin, 1), dtype=torch.uint8, device=DEV)
             call("u2pl_weight_split3_f32", w, 0, Cout, k * k * Cin, 1, wsb)
             flops = 2.0 * N * Ho * Ho * Cout * k * k * Cin
@@ -75,37 +75,32 @@ def main():
         else:   # dgrad of a Cin -> Cout conv: dy [M][Cout] . wT [Cin][k*k*Cout]
             dy = torch.randn(N * Ho * Ho * Cout, device=DEV)
             wT = torch.randn(Cin * k * k * Cout, device=DEV) * ((k * k * Cout) ** -0.5)
-            ys = [torch.empty(N * H * H * Cin, device=DEV) for _ in range(3)]
+            ys = [torch.empty(N * H * H * Cin, device=DEV) for _ in range(2)]
             wsb = torch.empty(query("u2pl_weight_split3_bytes", Cin, k * k * Cout, 1), dtype=torch.uint8, device=DEV)
             call("u2pl_weight_split3_f32", wT, 0, Cin, k * k * Cout, 1, wsb)
             flops = 2.0 * N * H * H * Cin * k * k * Cout
             g = (N, H, H, Cin, Ho, Ho, Cout, k, k, stride, pad, dil)
             old = lambda y: call("u2pl_conv2d_dgrad_f32", dy, Cout, wT, y, Cin, *g)         # noqa: E731
             new = lambda y: call("u2pl_conv2d_dgrad_ws_f32", dy, Cout, wsb, y, Cin, *g)     # noqa: E731
-        variants = [("inloop", old, None), ("ws_pinned", new, 1), ("ws_sgb", new, 0)]
-        for (nm, fn, sch), y in zip(variants, ys):      # results + warm-up
-            if sch is not None:
-                query("u2pl_igemm_ws_set_sched", sch)
+        variants = [("inloop", old), ("ws", new)]
+        for (nm, fn), y in zip(variants, ys):      # results + warm-up
             fn(y)
         torch.cuda.synchronize()
-        same = [bool(torch.equal(ys[0], ys[1])), bool(torch.equal(ys[0], ys[2]))]
-        t = {nm: [] for nm, _, _ in variants}
+        same = bool(torch.equal(ys[0], ys[1]))
+        t = {nm: [] for nm, _ in variants}
         for _ in range(ROUNDS):
-            for (nm, fn, sch), y in zip(variants, ys):
-                if sch is not None:
-                    query("u2pl_igemm_ws_set_sched", sch)
+            for (nm, fn), y in zip(variants, ys):
                 t[nm].append(timed(lambda: fn(y)))
-        query("u2pl_igemm_ws_set_sched", 1)
         row = dict(kind=kind, N=N, H=H, Cin=Cin, Cout=Cout, k=k, d=dil, s=stride, gflop=round(flops / 1e9, 1), bit_identical=same)
         for nm in t:
             ms = statistics.median(t[nm])
             row[nm] = dict(us=round(ms * 1e3, 1), tf=round(flops / ms / 1e9, 1), frac=round(flops / ms / 1e9 / PEAK, 3))
         rows.append(row)
         print(json.dumps(row), flush=True)
-    tot = {nm: sum(r[nm]["us"] for r in rows) for nm in ("inloop", "ws_pinned", "ws_sgb")}
+    tot = {nm: sum(r[nm]["us"] for r in rows) for nm in ("inloop", "ws")}
     fl = sum(r["gflop"] for r in rows)
-    print(json.dumps(dict(total_us=tot, tf={k: round(fl / v * 1e-3, 1) for k, v in tot.items()},
-                          frac={k: round(fl / v * 1e-3 / PEAK, 3) for k, v in tot.items()})))
+    print(json.dumps(dict(total_us=tot, tf={k: round(fl / v * 1e3, 1) for k, v in tot.items()},
+                          frac={k: round(fl / v * 1e3 / PEAK, 3) for k, v in tot.items()})))
 
 
 if __name__ == "__main__":

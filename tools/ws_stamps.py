@@ -1,0 +1,39 @@
+"""time line of one wave's chunk in k_igemm_ws (a -DU2PL_WS_STAMPS build): cycles between every 4th slot."""
+import ctypes, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from u2pl_amd import _lib
+from u2pl_amd._lib import call, query
+L = _lib.lib().cdll
+DEV = "cuda"
+buf = torch.zeros(2 * 2 * 4 * 14 + 1024 * 4, dtype=torch.int64, device=DEV)
+L.u2pl_igemm_ws_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+for (M, K, Nn, batch) in [(32768, 1024, 256, 1)]:
+    x = torch.randn(batch * M * K, device=DEV)
+    w = torch.randn(batch * Nn * K, device=DEV) * (K ** -0.5)
+    y = torch.empty(batch * M * Nn, device=DEV)
+    wsb = torch.empty(query("u2pl_weight_split3_bytes", Nn, K, batch), dtype=torch.uint8, device=DEV)
+    call("u2pl_weight_split3_f32", w, Nn * K, Nn, K, batch, wsb)
+    for sch in (2,):
+        for _ in range(3):
+            call("u2pl_gemm_batched_ws_f32", x, K, M * K, wsb, y, Nn, M * Nn, M, K, Nn, batch)
+        torch.cuda.synchronize()
+        full = buf.cpu()
+        t = full[:224].reshape(2, 2, 4, 14)
+        print(f"shape M{M} K{K} N{Nn} sched={sch}")
+        for b in range(2):
+            for p in range(2):
+                for c in range(4):
+                    r = t[b, p, c]
+                    if r[0] == 0:
+                        continue
+                    d = [int(r[i] - t[b, 0, 0, 0]) for i in range(14)]
+                    print(f"  blk{b} wave{4*p} chunk{8+c}: abs stamps (slot 0,4,..,44, pre-barrier, post-barrier): {d}")
+        ph = full[224:].reshape(1024, 4)
+        ph = ph[ph[:, 0] != 0]
+        t0 = int(ph[:, 0].min())
+        import statistics as st
+        d = lambda a: (int(a.min()), int(st.median(a.tolist())), int(a.max()))
+        print("  blocks", len(ph), "start-t0", d(ph[:, 0] - t0), "prologue", d(ph[:, 1] - ph[:, 0]), "mainloop", d(ph[:, 2] - ph[:, 1]),
+              "epilogue", d(ph[:, 3] - ph[:, 2]), "end-t0", d(ph[:, 3] - t0))
+        buf.zero_()

@@ -17,9 +17,20 @@
 // One block per CU (144 KB of LDS).  Tiles are mapped to blocks XCD-aware: consecutive tiles of one XCD share the A rows
 // (N tiles fastest), every XCD works on a contiguous range of tiles.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "conv_geom.h"
 #include "u2pl_hip.h"
+
+// compile-time loop: f(integral_constant<int, B>) ... f(integral_constant<int, E - 1>) as straight-line code (the pinned main
+// loop must not depend on the loop unroller's size budget: a rolled slot loop sends the register arrays to scratch)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 
 #define WS_ROW_B 64                      // bytes of one piece row of a 32-deep chunk (32 bf16)
 // rows of a split matrix are padded (zero rows) to the widest tile that reads them: no read ever leaves the allocation
@@ -76,13 +87,14 @@ U2PL_API int u2pl_weight_split3_f32(const float* w, long zw, int rows, int K, in
 // ---------------------------------------------------------------------------------------------------------------
 // PW: pointwise gather (1x1, stride 1, no padding -- the GEMM view: 1x1 convolutions and the Winograd component
 // products): the A addresses are a per-row constant plus a wave-uniform chunk offset, no per-chunk address arithmetic.
-#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-#define SG_VALU 0x2
-#define SG_MFMA 0x8
-#define SG_VMEM_R 0x20
-#define SG_DS_R 0x100
-#define SG_DS_W 0x200
-template <int TM, int TN, int WM, int WN, bool PW, int SCH>
+#ifdef U2PL_WS_STAMPS
+// debug build (python -m u2pl_amd.build_ext --variant stamps -DU2PL_WS_STAMPS): s_memtime stamps every 4th slot of the pinned
+// main loop, chunks 8..11 of blocks 0 and 100, waves 0 (plan 0) and NW/2 (plan 1): [block][plan][chunk][14] uint64
+__device__ unsigned long long* d_ws_stamps;
+static unsigned long long* g_ws_stamps = nullptr;
+U2PL_API int u2pl_igemm_ws_set_stamp_buffer(void* p) { g_ws_stamps = (unsigned long long*)p; return 0; }
+#endif
+template <int TM, int TN, int WM, int WN, bool PW, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     const float* __restrict__ x, long ldx, const unsigned short* __restrict__ ws, const float* __restrict__ bias,
     float* __restrict__ y, long ldy, ConvGeom g, unsigned xbytes, unsigned wsbytes, int Np, float* __restrict__ stats,
@@ -108,13 +120,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     y += (long)z * zy;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, xbytes), rw = make_rsrc(ws, wsbytes);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef U2PL_WS_STAMPS
+    unsigned long long ph[4];
+    ph[0] = __builtin_readcyclecounter();
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const long M = (long)g.N * g.Hout * g.Wout;
     const int K = g.R * g.S * g.Cin;
     const int nk = K / BK;
-    const int cpt = g.Cin / BK;
     const long m0 = (long)mt_ * BM;
     const int n0 = nt_ * BN;
 
@@ -138,7 +153,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
         nb[i] = (int)n_ * g.Hin * g.Win;
         aoff[i] = mv[i] ? (int)mm * ldxb + kq * 16 : OOB_OFF;
     }
-    float4 ra[RA];
+    // A: TWO register sets (chunks of even / odd index): the activation rows come from HBM and are requested TWO chunks
+    // before they are split (a chunk lasts ~1.5 us, all 256 blocks request at the same moments: one chunk of distance
+    // left 900-2000 cycles of every chunk waiting for them); B (L2-resident weight planes): one set, one chunk ahead.
+    float4 ra[2][RA];
     u32x4 rb[RBU];
     // B: unit u = tid + j * NT of the [3][BN][4] units of a chunk; piece p = u / (BN * 4)
     int boff[RBU];        // byte offset inside the chunk's global image, relative to (chunk, piece 0, row n0)
@@ -150,25 +168,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
         blds[j] = A_ST + p * BN * WS_ROW_B + wi * 16;
     }
     const int chunk_b = 3 * Np * WS_ROW_B;                  // bytes per chunk of the split planes
-    // the chunk the NEXT load_chunk() fetches: index, channel offset and tap, advanced without divisions; past the last
-    // chunk the last one is fetched again (unconditional loads: a load under `if` would be waited for with vmcnt(0))
-    int l_kc = 0, l_c0 = 0, l_r = 0, l_s = 0;
-    auto load_chunk = [&]() {
+    // the chunks the NEXT load_a() / load_b() fetch: index, channel offset and tap, advanced without divisions; past the
+    // last chunk the last one is fetched again (unconditional loads: a load under `if` would be waited for with vmcnt(0))
+    int l_kc = 0, l_c0 = 0, l_r = 0, l_s = 0, lb_kc = 0;
+    auto load_a_row = [&](auto set_c, auto i_c) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value, i = decltype(i_c)::value;
         if constexpr (PW) {
-#pragma unroll
-            for (int i = 0; i < RA; ++i) ra[i] = buf_load4s(rx, aoff[i], l_kc * (BK * 4));
+            ra[SET][i] = buf_load4s(rx, aoff[i], l_kc * (BK * 4));
         } else {
-#pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                int ih, iw;
-                const bool okh = gather_coord(bh[i], l_r, g.step, g.log2div, g.Hin, ih);
-                const bool okw = gather_coord(bw[i], l_s, g.step, g.log2div, g.Win, iw);
-                const int off = (nb[i] + ih * g.Win + iw) * ldxb + kq * 16;
-                ra[i] = buf_load4s(rx, (mv[i] & okh & okw) ? off : OOB_OFF, l_c0 * 4);
-            }
+            int ih, iw;
+            const bool okh = gather_coord(bh[i], l_r, g.step, g.log2div, g.Hin, ih);
+            const bool okw = gather_coord(bw[i], l_s, g.step, g.log2div, g.Win, iw);
+            const int off = (nb[i] + ih * g.Win + iw) * ldxb + kq * 16;
+            ra[SET][i] = buf_load4s(rx, (mv[i] & okh & okw) ? off : OOB_OFF, l_c0 * 4);
         }
-#pragma unroll
-        for (int j = 0; j < RBU; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, boff[j], l_kc * chunk_b, 0);
+    };
+    auto advance_a = [&]() __attribute__((always_inline)) {
         if (l_kc < nk - 1) {
             ++l_kc;
             l_c0 += BK;
@@ -178,6 +193,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
             }
         }
     };
+    auto load_a = [&](auto set_c) __attribute__((always_inline)) {
+        static_for<0, RA>([&](auto i) __attribute__((always_inline)) { load_a_row(set_c, i); });
+        advance_a();
+    };
+    auto load_b_unit = [&](auto j_c) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_c)::value;
+        rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, boff[j], lb_kc * chunk_b, 0);
+    };
+    auto advance_b = [&]() __attribute__((always_inline)) { lb_kc = min(lb_kc + 1, nk - 1); };
+    auto load_b = [&]() __attribute__((always_inline)) {
+        static_for<0, RBU>([&](auto j) __attribute__((always_inline)) { load_b_unit(j); });
+        advance_b();
+    };
     // A piece rows: [piece][BM][64 B], k segment (kq >> 1) of row r at slot seg ^ ((r >> 2) & 3), half (kq & 1)
     int alds[RA];
 #pragma unroll
@@ -185,15 +213,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
         const int r = r0 + RPP * i;
         alds[i] = r * WS_ROW_B + ((((kq >> 1) ^ ((r >> 2) & 3)) << 4) | ((kq & 1) << 3));
     }
-    auto store_a = [&](int stage, int i) {
-        uint2 p0, p1, p2;
-        split3_bf16(ra[i], p0, p1, p2);
-        unsigned char* d = smem + stage * ST + alds[i];
-        *(uint2*)d = p0;
-        *(uint2*)(d + BM * WS_ROW_B) = p1;
-        *(uint2*)(d + 2 * BM * WS_ROW_B) = p2;
-    };
-    auto store_b = [&](int stage, int j) { *(u32x4*)(smem + stage * ST + blds[j]) = rb[j]; };
+    auto store_b = [&](int stage, int j) __attribute__((always_inline)) { *(u32x4*)(smem + stage * ST + blds[j]) = rb[j]; };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -206,150 +226,195 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     const int li = lane & 31, lh = lane >> 5;
     const int sw0 = (lh ^ ((li >> 2) & 3)) << 4;            // slot of k segment lh (gk = 0); gk = 1: ^ 32
     const int afr = (wm * 32 * TM + li) * WS_ROW_B, bfr = A_ST + (wn * 32 * TN + li) * WS_ROW_B;
-    auto lda = [&](int stage, int p, int a, int gk) {
+    auto lda = [&](int stage, int p, int a, int gk) __attribute__((always_inline)) {
         return __builtin_bit_cast(bf16x8, *(const uint4*)(smem + stage * ST + afr + p * (BM * WS_ROW_B) + a * (32 * WS_ROW_B) + (sw0 ^ (gk << 5))));
     };
-    auto ldb = [&](int stage, int p, int b, int gk) {
+    auto ldb = [&](int stage, int p, int b, int gk) __attribute__((always_inline)) {
         return __builtin_bit_cast(bf16x8, *(const uint4*)(smem + stage * ST + bfr + p * (BN * WS_ROW_B) + b * (32 * WS_ROW_B) + (sw0 ^ (gk << 5))));
     };
     struct Frag { bf16x8 a[3][TM], b[3][TN]; };
-    // ---- prologue: chunk 0 into stage 0, chunk 1 in flight
-    load_chunk();
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    // ---- prologue: chunk 0 into stage 0; B(1), A(1), A(2) in flight
+    load_a(C0{});
+    load_b();
 #pragma unroll
-    for (int i = 0; i < RA; ++i) store_a(0, i);
+    for (int i = 0; i < RA; ++i) {
+        uint2 p0, p1, p2;
+        split3_bf16(ra[0][i], p0, p1, p2);
+        unsigned char* d = smem + alds[i];
+        *(uint2*)d = p0;
+        *(uint2*)(d + BM * WS_ROW_B) = p1;
+        *(uint2*)(d + 2 * BM * WS_ROW_B) = p2;
+    }
 #pragma unroll
     for (int j = 0; j < RBU; ++j) store_b(0, j);
-    load_chunk();
+    // (issue order A(1), B(1), A(2) = the order the loop leaves its loads in at every trip: the compiler merges the wait
+    // counters of the loop entry and of the back edge, a different order here costs a vmcnt(0) in the loop)
+    __builtin_amdgcn_sched_barrier(0);      // (... and the scheduler must not interleave the three groups)
+    load_a(C1{});
+    __builtin_amdgcn_sched_barrier(0);
+    load_b();
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(C0{});
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+#ifdef U2PL_WS_STAMPS
+    ph[1] = __builtin_readcyclecounter();
+#endif
 
     constexpr int PER = TM * TN, NMF = 12 * PER;            // matrix instructions per 16-deep block product / per chunk
     constexpr int NRD = 3 * (TM + TN);                      // operand reads per 16-deep block
     Frag f[2];
-    // matrix instruction i of a chunk: k block i / (6 PER), product (i / PER) % 6, accumulator i % PER
-    auto do_mfma = [&](int i) {
+    // matrix instruction I of a chunk: k block I / (6 PER), product (I / PER) % 6, accumulator I % PER
+    auto do_mfma = [&](auto i_c) __attribute__((always_inline)) {
+        constexpr int I = decltype(i_c)::value;
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-        const int gk = i / (6 * PER), q = (i / PER) % 6, ab = i % PER, a = ab / TN, b = ab % TN;
+        constexpr int gk = I / (6 * PER), q = (I / PER) % 6, ab = I % PER, a = ab / TN, b = ab % TN;
         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[gk].a[PA[q]][a], f[gk].b[PB[q]][b], acc[a][b], 0, 0, 0);
     };
-    // operand read j of a k block, in the order the products need them: a2.., b0.., a1.., b1.., a0.., b2..
-    auto do_read = [&](int stage, int gk, int j) {
-        if (j >= NRD) return;
-        const int q = j / (TM + TN), w = j % (TM + TN);
-        if (w < TM) f[gk].a[2 - q][w] = lda(stage, 2 - q, w, gk);
-        else f[gk].b[q][w - TM] = ldb(stage, q, w - TM, gk);
+    // operand read J of a k block, in the order the products need them: a2.., b0.., a1.., b1.., a0.., b2..
+    auto do_read = [&](auto stage_c, auto gk_c, auto j_c) __attribute__((always_inline)) {
+        constexpr int stage = decltype(stage_c)::value, gk = decltype(gk_c)::value, J = decltype(j_c)::value;
+        if constexpr (J < NRD) {
+            constexpr int q = J / (TM + TN), w = J % (TM + TN);
+            if constexpr (w < TM) f[gk].a[2 - q][w] = lda(stage, 2 - q, w, gk);
+            else f[gk].b[q][w - TM] = ldb(stage, q, w - TM, gk);
+        }
     };
 
-    if constexpr (SCH == 0) {
-    // Main loop, compiler-scheduled: the source order is only the data flow, a sched_group_barrier pipeline asks for the
-    // other instruction kinds to be placed into the gaps between the matrix instructions.
-    for (int kc = 0; kc < nk; ++kc) {
-        const int cur = kc & 1, nxt = cur ^ 1;
-#pragma unroll
-        for (int j = 0; j < NRD; ++j) do_read(cur, 0, j);
-#pragma unroll
-        for (int i = 0; i < NMF / 4; ++i) do_mfma(i);
-#pragma unroll
-        for (int j = 0; j < NRD; ++j) do_read(cur, 1, j);
-#pragma unroll
-        for (int i = NMF / 4; i < NMF / 2; ++i) do_mfma(i);
-#pragma unroll
-        for (int i = 0; i < RA; ++i) store_a(nxt, i);       // (past the last chunk: a re-read chunk, never used)
-#pragma unroll
-        for (int j = 0; j < RBU; ++j) store_b(nxt, j);
-        load_chunk();                                       // chunk kc + 2 (clamped)
-#pragma unroll
-        for (int i = NMF / 2; i < NMF; ++i) do_mfma(i);
-        {
-            constexpr int NWR = RA * 3 + RBU, NLD = RA + RBU;
-            constexpr int FIRST = TM + TN;                  // reads the first group of products waits for
-            SGB(SG_DS_R, FIRST);
-            int rd = FIRST, wr = 0, ld = 0;
-#pragma unroll
-            for (int i = 0; i < NMF; ++i) {
-                SGB(SG_MFMA, 1);
-                if (rd < 2 * NRD) {                         // operand reads: two per gap until all are issued
-                    SGB(SG_DS_R, 2);
-                    rd += 2;
-                    SGB(SG_VALU, 1);
-                } else if (i < NMF / 2) {                   // the split's arithmetic
-                    SGB(SG_VALU, 5);
-                } else if (wr < NWR) {                      // piece stores
-                    SGB(SG_DS_W, 1);
-                    ++wr;
-                    SGB(SG_VALU, 3);
-                } else if (ld < NLD) {                      // global loads of chunk kc + 2
-                    SGB(SG_VMEM_R, 1);
-                    ++ld;
-                    SGB(SG_VALU, PW ? 1 : 4);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    } else {
-    // Main loop, issue order pinned (a scheduling barrier after every matrix instruction and the work placed behind it).
+    // Main loop, issue order pinned (a scheduling barrier after every matrix instruction and the work placed behind it);
+    // two chunks per trip so that the LDS stage and the A register set of a chunk are compile-time constants.
     // The barrier of a chunk sits INSIDE the matrix-instruction stream: the last TAIL products of a chunk (operands in
     // registers) are issued after the barrier, in front of the next chunk's, and cover the latency of its first operand
-    // reads.  Per chunk and wave, slot by slot (one matrix instruction each):
-    //   TAIL slots   products NMF-TAIL .. NMF-1 of the PREVIOUS chunk | operand reads of k block 0
-    //   then         products 0 .. NMF/2-1 (k block 0)                | operand reads of k block 1, then the split of
-    //                                                                   chunk kc+1 (two values per slot) + piece stores,
-    //                                                                   the weight-piece stores, the loads of chunk kc+2
-    //   then         products NMF/2 .. NMF-TAIL-1 (k block 1)         | --
-    // Before the first chunk the tail runs on all-zero operands (adds +0 to +0).
-    constexpr int TAIL = 2 * PER, FIRST = TM + TN;
+    // reads.  Before the first chunk the tail runs on all-zero operands (adds +0 to +0).  Per accumulator the order of the
+    // products is: k blocks ascending, six piece products each.
+    // (Tried and dropped: a second wave group half a chunk out of phase -- no gain, 23 more registers; a compiler-scheduled
+    // loop behind a sched_group_barrier pipeline -- same time as the pinned order, no control.)
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
 #pragma unroll
         for (int a = 0; a < TM; ++a) f[1].a[p][a] = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
 #pragma unroll
         for (int b = 0; b < TN; ++b) f[1].b[p][b] = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
+        if constexpr (ABL & 16) {   // (timing experiment: operands never read from LDS)
+#pragma unroll
+            for (int a = 0; a < TM; ++a) f[0].a[p][a] = __builtin_bit_cast(bf16x8, make_uint4(tid, 1, 2, 3));
+#pragma unroll
+            for (int b = 0; b < TN; ++b) f[0].b[p][b] = __builtin_bit_cast(bf16x8, make_uint4(tid, 1, 2, 3));
+        }
     }
     uint2 pc[3];          // pieces of the float4 being split
-    for (int kc = 0; kc < nk; ++kc) {
-        const int cur = kc & 1, nxt = cur ^ 1;
-#pragma unroll
-        for (int j = 0; j < FIRST; ++j) do_read(cur, 0, j);
+    float sp_l = 0.f, sp_h = 0.f;     // the pair being split: residuals after the pieces taken so far
+    auto chunk = [&](auto plan_c, auto par_c, int kc) __attribute__((always_inline)) {
+        constexpr int cur = decltype(par_c)::value, nxt = cur ^ 1;
+        // Per slot (= per matrix instruction) at most one operand read / store / global load and <= 5 VALU operations: a
+        // wave alone then issues its matrix instructions back to back (32 cycles apart) with everything else in the gaps.
+        // With the work in clumps (a whole value pair split in one slot: 11 VALU + 3 stores) the wave that wins the
+        // arbitration for the matrix pipe (the older one) ran its chunk in 2160 cycles instead of 1536 while its SIMD
+        // partner starved, then the partner ran its clumps with nobody's matrix instructions to cover them: 3990 cycles per
+        // chunk for 3072 of matrix work (s_memtime stamps of both waves).
+        //   slots 0 .. TAIL-1           tail products of the previous chunk | operand reads of k block 0
+        //   TAIL .. TAIL+NRD-1          products of k block 0               | operand reads of k block 1, one per slot
+        //   TAIL .. TAIL+6RA-1                                              | split of A(kc+1): 3 steps per value pair (5, 5, 1
+        //                                                                     VALU), the three piece stores behind a float4's last
+        //   then RBU slots                                                  | weight-piece stores, one per slot
+        //   then RBU + RA slots                                             | loads B(kc+2), then A(kc+3), one per slot
+        constexpr int TAIL = 2 * PER, F0_PRE = TM + TN, F0_PER = (NRD - F0_PRE + TAIL - 1) / TAIL;
+        constexpr int F1_START = TAIL, SP_START = TAIL, BS_START = SP_START + 6 * RA, LD_START = BS_START + RBU;
+        static_assert(F1_START + NRD <= NMF && LD_START + RBU + RA <= NMF, "plan does not fit the chunk");
+        using CUR = std::integral_constant<int, cur>;
+#ifdef U2PL_WS_STAMPS
+        unsigned long long ts[14];
+        ts[0] = __builtin_readcyclecounter();
+#endif
+        if constexpr (!(ABL & 16)) static_for<0, F0_PRE>([&](auto j) __attribute__((always_inline)) { do_read(CUR{}, C0{}, j); });
         __builtin_amdgcn_sched_barrier(0);
-        constexpr int R0 = (NRD - FIRST + 1) / 2, R1 = (NRD + 1) / 2;
-        static_assert(R0 <= TAIL, "the first operand reads do not fit behind the tail products");
-#pragma unroll
-        for (int sl = 0; sl < NMF; ++sl) {
-            do_mfma(sl < TAIL ? NMF - TAIL + sl : sl - TAIL);
-            int k = sl;
-            if (k < TAIL) {
-                if (k < R0) { do_read(cur, 0, FIRST + 2 * k); do_read(cur, 0, FIRST + 2 * k + 1); }
-            } else if ((k -= TAIL) < R1) {
-                do_read(cur, 1, 2 * k);
-                do_read(cur, 1, 2 * k + 1);
-            } else if ((k -= R1) < 2 * RA) {                // split of float4 k / 2, values (k & 1) * 2 + {0, 1}
-                const float4 v = ra[k >> 1];
-                const float lo = (k & 1) ? v.z : v.x, hi = (k & 1) ? v.w : v.y;
-                const unsigned w0 = pack2_bf16(lo, hi);
-                const float l1 = lo - bf16_lo_f(w0), h1 = hi - bf16_hi_f(w0);
-                const unsigned w1 = pack2_bf16(l1, h1);
-                const unsigned w2 = pack2_bf16(l1 - bf16_lo_f(w1), h1 - bf16_hi_f(w1));
-                if (k & 1) {
-                    pc[0].y = w0; pc[1].y = w1; pc[2].y = w2;
-                    unsigned char* d = smem + nxt * ST + alds[k >> 1];
-                    *(uint2*)d = pc[0];
-                    *(uint2*)(d + BM * WS_ROW_B) = pc[1];
-                    *(uint2*)(d + 2 * BM * WS_ROW_B) = pc[2];
-                } else {
-                    pc[0].x = w0; pc[1].x = w1; pc[2].x = w2;
+        static_for<0, NMF>([&](auto sl_c) __attribute__((always_inline)) {
+            constexpr int sl = decltype(sl_c)::value;
+#ifdef U2PL_WS_STAMPS
+            if constexpr (sl % 4 == 0 && sl != 0) ts[sl / 4] = __builtin_readcyclecounter();
+#endif
+            do_mfma(std::integral_constant<int, (sl < TAIL ? NMF - TAIL + sl : sl - TAIL)>{});
+            if constexpr (!(ABL & 16)) {
+                if constexpr (sl < TAIL)
+                    static_for<0, F0_PER>([&](auto u) __attribute__((always_inline)) { do_read(CUR{}, C0{}, std::integral_constant<int, F0_PRE + sl * F0_PER + decltype(u)::value>{}); });
+                if constexpr (sl >= F1_START) do_read(CUR{}, C1{}, std::integral_constant<int, sl - F1_START>{});
+            }
+            if constexpr (sl >= SP_START && sl < SP_START + 6 * RA) {
+                constexpr int k = (sl - SP_START) / 3, step = (sl - SP_START) % 3;     // value pair k of A(kc + 1), step
+                if constexpr (step == 0) {
+                    const float4 v = ra[nxt][k >> 1];
+                    sp_l = (k & 1) ? v.z : v.x;
+                    sp_h = (k & 1) ? v.w : v.y;
                 }
-            } else if ((k -= 2 * RA) < RBU) {
-                store_b(nxt, k);
-            } else if ((k -= RBU) == 0) {
-                load_chunk();                               // chunk kc + 2 (clamped): RA + RBU loads
+                unsigned w;
+                if constexpr (ABL & 1) w = (__float_as_uint(sp_h) & 0xffff0000u) | (__float_as_uint(sp_l) >> 16);
+                else {
+                    w = pack2_bf16(sp_l, sp_h);
+                    if constexpr (step < 2) {
+                        sp_l = sp_l - bf16_lo_f(w);
+                        sp_h = sp_h - bf16_hi_f(w);
+                    }
+                }
+                if constexpr (k & 1) pc[step].y = w; else pc[step].x = w;
+                if constexpr ((k & 1) && step == 2) {
+                    if constexpr (ABL & 4) {
+                        asm volatile("" ::"v"(pc[0].x), "v"(pc[0].y), "v"(pc[1].x), "v"(pc[1].y), "v"(pc[2].x), "v"(pc[2].y));
+                    } else {
+                        unsigned char* d = smem + nxt * ST + alds[k >> 1];
+                        *(uint2*)d = pc[0];
+                        *(uint2*)(d + BM * WS_ROW_B) = pc[1];
+                        *(uint2*)(d + 2 * BM * WS_ROW_B) = pc[2];
+                    }
+                }
+            }
+            if constexpr (sl >= BS_START && sl < BS_START + RBU) {
+                constexpr int k = sl - BS_START;
+                if constexpr (ABL & 2) { asm volatile("" ::"v"(rb[k].x), "v"(rb[k].y), "v"(rb[k].z), "v"(rb[k].w)); }
+                else store_b(nxt, k);
+            }
+            if constexpr (!(ABL & 8)) {
+                if constexpr (sl >= LD_START && sl < LD_START + RBU) {              // B(kc + 2), consumed in the next chunk
+                    load_b_unit(std::integral_constant<int, sl - LD_START>{});
+                    if constexpr (sl == LD_START + RBU - 1) advance_b();
+                }
+                if constexpr (sl >= LD_START + RBU && sl < LD_START + RBU + RA) {   // A(kc + 3), consumed two chunks on
+                    load_a_row(std::integral_constant<int, nxt>{}, std::integral_constant<int, sl - LD_START - RBU>{});
+                    if constexpr (sl == LD_START + RBU + RA - 1) advance_a();
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
+        });
+#ifdef U2PL_WS_STAMPS
+        ts[12] = __builtin_readcyclecounter();
+#endif
+        if constexpr (!(ABL & 32)) __syncthreads();
+#ifdef U2PL_WS_STAMPS
+        ts[13] = __builtin_readcyclecounter();
+        {
+            const int bsel = blockIdx.x == 0 ? 0 : blockIdx.x == 100 ? 1 : -1;
+            if (d_ws_stamps && bsel >= 0 && kc >= 8 && kc < 12 && (wave == 0 || wave == (WM * WN) / 2) && lane == 0)
+                for (int i = 0; i < 14; ++i) d_ws_stamps[((bsel * 2 + (wave != 0)) * 4 + (kc - 8)) * 14 + i] = ts[i];
         }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int sl = 0; sl < TAIL; ++sl) do_mfma(NMF - TAIL + sl);
-    }
+#endif
+    };
+    auto main_loop = [&](auto plan_c) __attribute__((always_inline)) {
+        constexpr int TAIL = 2 * PER;
+        // (the back edge comes from the odd chunk ONLY -- with a conditional second half the compiler merges the wait-counter
+        // state "after the even chunk" into the loop header and waits with vmcnt(0) for the loads just issued)
+        int kc = 0;
+        for (; kc + 1 < nk; kc += 2) {
+            chunk(plan_c, C0{}, kc);
+            chunk(plan_c, C1{}, kc + 1);
+        }
+        if (kc < nk) chunk(plan_c, C0{}, kc);
+        static_for<0, TAIL>([&](auto sl) __attribute__((always_inline)) { do_mfma(std::integral_constant<int, NMF - TAIL + decltype(sl)::value>{}); });
+    };
+    main_loop(C0{});
+#ifdef U2PL_WS_STAMPS
+    ph[2] = __builtin_readcyclecounter();
+#endif
 
     // ---- epilogue (as k_conv_igemm): each wave transposes its (32 TM) x (32 TN) block through LDS, 16-byte row stores
     {
@@ -449,9 +514,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
             }
         }
     }
+#ifdef U2PL_WS_STAMPS
+    ph[3] = __builtin_readcyclecounter();
+    if (d_ws_stamps && blockIdx.x < 1024 && tid == 0)
+        for (int i = 0; i < 4; ++i) d_ws_stamps[224 + blockIdx.x * 4 + i] = ph[i];
+#endif
 }
 
-template <int TM, int TN, int WM, int WN, bool PW, int SCH>
+template <int TM, int TN, int WM, int WN, bool PW, int ABL = 0>
 static int launch_igemm_ws(const float* x, long ldx, const void* ws, const float* bias, float* y, long ldy,
                            const ConvGeom& g, hipStream_t stream, float* stats, const float* pivot, int batch, long zx,
                            long zy, const BnEpi* epi) {
@@ -465,7 +535,7 @@ static int launch_igemm_ws(const float* x, long ldx, const void* ws, const float
     const size_t lds = lds_op > lds_epi ? lds_op : lds_epi;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_igemm_ws<TM, TN, WM, WN, PW, SCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_igemm_ws<TM, TN, WM, WN, PW, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const long xb = (((long)g.N * g.Hin * g.Win - 1) * ldx + g.Cin) * 4;
@@ -474,21 +544,23 @@ static int launch_igemm_ws(const float* x, long ldx, const void* ws, const float
     const int mtiles = cdiv(M, BM), ntiles = cdiv(g.Cout, BN);
     const long total = (long)mtiles * ntiles * batch;
     if (total >= (1L << 30)) return U2PL_EINVAL;
-    U2PL_LAUNCH((k_igemm_ws<TM, TN, WM, WN, PW, SCH>), dim3((unsigned)total), dim3(64 * WM * WN), lds, stream, x, ldx,
+#ifdef U2PL_WS_STAMPS
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(d_ws_stamps), &g_ws_stamps, sizeof(void*), 0, hipMemcpyHostToDevice, stream);
+#endif
+    U2PL_LAUNCH((k_igemm_ws<TM, TN, WM, WN, PW, ABL>), dim3((unsigned)total), dim3(64 * WM * WN), lds, stream, x, ldx,
                 (const unsigned short*)ws, bias, y, ldy, g, (unsigned)xb, (unsigned)wsb1, Np, stats, pivot, zx, wsb1 / 2,
                 zy, ep, mtiles, ntiles, (int)total);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
 
-// main-loop variant: 1 (default; U2PL_WS_SCHED) = issue order pinned, 0 = compiler-scheduled behind a sched_group_barrier
-// pipeline.  Same results; u2pl_igemm_ws_set_sched() for A/B runs and tests (returns the previous value).
-static int g_ws_sched = -1;
-static int ws_sched() {
-    if (g_ws_sched < 0) { const char* e = getenv("U2PL_WS_SCHED"); g_ws_sched = (e && *e) ? (atoi(e) != 0) : 1; }
-    return g_ws_sched;
-}
-U2PL_API int u2pl_igemm_ws_set_sched(int v) { const int old = ws_sched(); g_ws_sched = v != 0; return old; }
+#ifdef U2PL_WS_ABLATE
+// timing experiments only (a variant build: python -m u2pl_amd.build_ext --variant abl -DU2PL_WS_ABLATE): bit mask of main-loop
+// ingredients to DROP -- 1 split arithmetic, 2 weight-piece stores, 4 activation-piece stores, 8 global loads, 16 operand
+// reads, 32 the barrier.  Results are garbage; see tools/bench_ws_ablate.py.
+static int g_ws_abl = 0;
+U2PL_API int u2pl_igemm_ws_set_ablate(int v) { const int old = g_ws_abl; g_ws_abl = v; return old; }
+#endif
 
 // tile choice: 128 x 256 on 8 waves where Cout fills it, 128 x 128 (8 waves of 64 x 32) below; Cout <= 64 is not
 // served here (the callers keep those layers -- 1 % of the network's multiplies -- on k_conv_igemm)
@@ -500,15 +572,17 @@ static int run_igemm_ws(const float* x, long ldx, const void* ws, const float* b
     // pointwise: 1x1, stride 1, no padding, forward or data-gradient geometry alike
     const bool pw = g.R == 1 && g.S == 1 && g.mul == 1 && g.off_h == 0 && g.off_w == 0 && g.log2div == 0 &&
                     g.Hin == g.Hout && g.Win == g.Wout;
-    const int sch = ws_sched();
-#define WS_GO(TM_, TN_, PW_, SCH_) \
-    return launch_igemm_ws<TM_, TN_, 2, 4, PW_, SCH_>(x, ldx, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi)
-    if (g.Cout > 128) {
-        if (sch == 0) { if (pw) WS_GO(2, 2, true, 0); else WS_GO(2, 2, false, 0); }
-        if (pw) WS_GO(2, 2, true, 1); else WS_GO(2, 2, false, 1);
+#define WS_GO(TM_, TN_, PW_) \
+    return launch_igemm_ws<TM_, TN_, 2, 4, PW_>(x, ldx, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi)
+#ifdef U2PL_WS_ABLATE
+    if (g_ws_abl && g.Cout > 128 && pw) {
+#define WS_ABL(A_) case A_: return launch_igemm_ws<2, 2, 2, 4, true, A_>(x, ldx, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi)
+        switch (g_ws_abl) { WS_ABL(1); WS_ABL(2); WS_ABL(4); WS_ABL(8); WS_ABL(16); WS_ABL(32); WS_ABL(7); WS_ABL(15); WS_ABL(31); WS_ABL(63); default: return U2PL_EINVAL; }
+#undef WS_ABL
     }
-    if (sch == 0) { if (pw) WS_GO(2, 1, true, 0); else WS_GO(2, 1, false, 0); }
-    if (pw) WS_GO(2, 1, true, 1); else WS_GO(2, 1, false, 1);
+#endif
+    if (g.Cout > 128) { if (pw) WS_GO(2, 2, true); else WS_GO(2, 2, false); }
+    if (pw) WS_GO(2, 1, true); else WS_GO(2, 1, false);
 #undef WS_GO
 }
 

@@ -122,7 +122,6 @@ CONV_ALGO = {"wino": int(os.environ.get("U2PL_CONV_WINO", "4")), "min_gain": flo
 # op (load_state_dict, init) bumps the version.  U2PL_CONV_WS=0 keeps every layer on conv.hip's in-loop split.
 WEIGHT_EPOCH = [0]
 CONV_WS = {"on": os.environ.get("U2PL_CONV_WS", "1") != "0"}
-_WCACHE = {}
 
 
 def bump_weight_epoch():
@@ -131,15 +130,18 @@ def bump_weight_epoch():
 
 def _derived(weight, kind, nbytes, build):
     """-> device buffer (uint8) of `nbytes`, filled by build(buf) when the weight changed since it was last built.  The
-    buffer is allocated once per (weight, kind) and rebuilt in place; readers on other streams wait for the build event,
-    a rebuild waits for the streams that read the previous contents."""
-    key = (weight.data_ptr(), kind)
-    stamp = (WEIGHT_EPOCH[0], weight._version)
-    ent = _WCACHE.get(key)
+    buffer hangs on the weight tensor OBJECT (it dies with it: a freed weight's address can be handed to another tensor),
+    is allocated once per (weight, kind) and rebuilt in place; readers on other streams wait for the build event, a
+    rebuild waits for the streams that read the previous contents."""
+    cache = weight.__dict__.get("_u2pl_derived")
+    if cache is None:
+        cache = weight.__dict__["_u2pl_derived"] = {}
+    stamp = (WEIGHT_EPOCH[0], weight._version, weight.data_ptr())
+    ent = cache.get(kind)
     cur = torch.cuda.current_stream()
-    if ent is None or ent["buf"].numel() != nbytes or ent["buf"].device != weight.device:
-        ent = _WCACHE[key] = {"buf": torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=weight.device), "stamp": None,
-                              "event": torch.cuda.Event(), "stream": cur, "readers": set()}
+    if ent is None or ent["buf"].numel() != max(int(nbytes), 16) or ent["buf"].device != weight.device:
+        ent = cache[kind] = {"buf": torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=weight.device), "stamp": None,
+                             "event": torch.cuda.Event(), "stream": cur, "readers": set()}
     if ent["stamp"] != stamp:
         for st in ent["readers"]:
             cur.wait_stream(st)

@@ -253,6 +253,10 @@ size_t u2pl_conv2d_wgrad_workspace_bytes(int N, int Hout, int Wout, int Cin, int
 int u2pl_conv2d_wgrad_f32(const float* dy, long lddy, const float* x, long ldx, float* dw, void* workspace,
                           int accumulate, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R,
                           int S, int stride, int pad, int dil, hipStream_t stream);
+/* weight-gradient kernel choice under the split arithmetic (A/B switch; env U2PL_WGRAD_TR): 1 (default) = csrc/wgrad_tr.hip
+ * (hardware-transposed LDS operand reads, layers with Cout, Cin >= 128), 0 = conv.hip's kernel.  Returns the previous value.
+ * The workspace / slab-count queries above follow the switch: query and launch under the same setting. */
+int u2pl_wgrad_set_tr(int on);
 int u2pl_im2col_f32(const float* x, long ldx, float* col, int Kp, int N, int Hin, int Win, int Cin, int Hout,
                     int Wout, int R, int S, int stride, int pad, int dil, hipStream_t stream);
 

@@ -23,6 +23,7 @@
 #include "u2pl_hip.h"
 
 #include "conv_geom.h"
+#include "wgrad_tr.h"
 
 template <int TM, int TN, int WM = 2, int BF = 0>
 __global__ __launch_bounds__(128 * WM, WM) void k_conv_igemm(const float* __restrict__ x, long ldx,
@@ -910,6 +911,11 @@ U2PL_API size_t u2pl_conv2d_wgrad_workspace_bytes(int N, int Hout, int Wout, int
     ConvGeom g = {N, 0, 0, Cin, Hout, Wout, Cout, R, S, 1, 0, 0, 1, 0};
     int ct, ns, cps;
     wgrad_plan(g, Cout > 64 ? 128 : 64, Cin > 64 ? 128 : 64, ct, ns, cps);
+    if (wgrad_tr_eligible(g)) {      // (the larger of the two kernels' plans: the arithmetic switch may change between query and launch)
+        int ct2, ns2, cps2;
+        wgrad_tr_plan(g, R * S, ct2, ns2, cps2);
+        if (ns2 > ns) ns = ns2;
+    }
     return (size_t)ns * Cout * R * S * Cin * sizeof(float);
 }
 
@@ -968,7 +974,10 @@ U2PL_API int u2pl_conv2d_wgrad_f32(const float* dy, long lddy, const float* x, l
     wgrad_plan(g, BM, BN, ct, ns, cps);
     float* part = (float*)workspace;
     int rc;
-    if (conv_split()) {
+    if (conv_split() && wgrad_tr_eligible(g)) {
+        wgrad_tr_plan(g, R * S, ct, ns, cps);
+        rc = launch_wgrad_tr(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, 0, 0);
+    } else if (conv_split()) {
         if (BM == 128 && BN == 128) rc = launch_wgrad_bf16<2, 2, 3>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
         else if (BM == 128) rc = launch_wgrad_bf16<2, 1, 3>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
         else if (BN == 128) rc = launch_wgrad_bf16<1, 2, 3>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream);
@@ -1020,7 +1029,8 @@ static ConvGeom batched_wgrad_geom(long M, int Cin, int Cout, int batch) {
 U2PL_API int u2pl_wgrad_batched_splits(long M, int Cin, int Cout, int batch) {
     ConvGeom g = batched_wgrad_geom(M, Cin, Cout, batch);
     int ct, ns, cps;
-    wgrad_plan(g, Cout > 64 ? 128 : 64, Cin > 64 ? 128 : 64, ct, ns, cps);
+    if (conv_split() && wgrad_tr_eligible(g)) wgrad_tr_plan(g, batch, ct, ns, cps);
+    else wgrad_plan(g, Cout > 64 ? 128 : 64, Cin > 64 ? 128 : 64, ct, ns, cps);
     return ns;
 }
 U2PL_API size_t u2pl_wgrad_batched_workspace_bytes(long M, int Cin, int Cout, int batch) {
@@ -1032,6 +1042,10 @@ U2PL_API int u2pl_wgrad_batched_f32(const float* dy, long lddy, long zdy, const 
     ConvGeom g = batched_wgrad_geom(M, Cin, Cout, batch);
     const int BM = Cout > 64 ? 128 : 64, BN = Cin > 64 ? 128 : 64;
     int ct, ns, cps;
+    if (conv_split() && wgrad_tr_eligible(g)) {
+        wgrad_tr_plan(g, batch, ct, ns, cps);
+        return launch_wgrad_tr(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx);
+    }
     wgrad_plan(g, BM, BN, ct, ns, cps);
     if (conv_split()) {
         if (BM == 128 && BN == 128) return launch_wgrad_bf16<2, 2, 3>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx);

@@ -1,0 +1,9 @@
+// csrc/wgrad_tr.hip: split-fp32 weight gradient with hardware-transposed LDS operand reads (see there).
+#pragma once
+#include "conv_geom.h"
+
+bool wgrad_tr_eligible(const ConvGeom& g);
+// slabs of the pixel range: ctiles = Cin tiles, nsplit slabs of cps 32-pixel chunks each; taps = R * S (or the batch)
+void wgrad_tr_plan(const ConvGeom& g, int taps, int& ctiles, int& nsplit, int& cps);
+int launch_wgrad_tr(const float* dy, long lddy, const float* x, long ldx, float* part, const ConvGeom& g, int ctiles, int nsplit,
+                    int cps, hipStream_t stream, long zdy, long zx);

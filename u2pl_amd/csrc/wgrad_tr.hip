@@ -1,0 +1,325 @@
+// Split-fp32 weight gradient with hardware-transposed operand reads (round 4).
+//
+//   dW[co][tap][ci] = sum over pixels m of dY[m][co] * X[gather(m, tap)][ci]          (autograd of nn.Conv2d under
+//   loss.backward(), reference train_semi.py:527; layer shapes resnet.py:120-140, base.py:54-83)
+//
+// is a GEMM whose reduction runs over PIXELS while both operands are stored pixel-major (NHWC rows): the matrix
+// instruction wants, per lane, 8 consecutive pixels of ONE channel.  conv.hip's k_conv_wgrad_bf16<.., 3> transposes while
+// it stages (two pixels packed per 32-bit LDS store: 48 ds_write_b32 and ~180 VALU per thread and chunk) and runs at 0.25
+// of the split form's bound.  Here the tile goes into LDS as it comes from memory -- [pixel][channel] rows of bf16
+// pieces, one ds_write_b64 per float4 and piece -- and the TRANSPOSE IS DONE BY THE LDS: ds_read_b64_tr_b16 (gfx950)
+// hands lane j of a 16-lane group the four pixels of channel j from a [4 pixels][16 channels] block (probe:
+// tools/micro/tr16_probe.hip).  Everything else follows igemm_ws.hip: 8 waves of 64 x 64, two LDS stages and one
+// barrier per 32-pixel chunk, the global loads two chunks ahead in two register sets, the issue order pinned with at most
+// one LDS / memory operation and one split step per matrix instruction, the chunk's barrier inside the matrix stream.
+// Same arithmetic as the other split kernels (three bf16 pieces per operand, six piece products, fp32 accumulate).
+// Block tile 128 (Cout) x 256 (Cin) [128 x 128 for Cin <= 128]; one block per CU, the pixel range split into as many
+// slabs as fill the 256 CUs (conv.hip's k_wgrad_reduce adds them in order: deterministic, no float atomics).
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+#include "conv_geom.h"
+#include "u2pl_hip.h"
+#include "wgrad_tr.h"
+
+template <int B, int E, class F>
+__device__ __forceinline__ void wt_static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        wt_static_for<B + 1, E>(f);
+    }
+}
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+typedef short v8s16 __attribute__((ext_vector_type(8)));
+#define WT_LDS(p) ((__attribute__((address_space(3))) v4s16*)(p))
+
+template <int TN, bool PW>
+__global__ __launch_bounds__(512, 2) void k_wgrad_tr(const float* __restrict__ dy, long lddy, const float* __restrict__ x,
+                                                     long ldx, float* __restrict__ part, ConvGeom g, int ctiles,
+                                                     int chunks_per_split, unsigned dybytes, unsigned xbytes, long zdy,
+                                                     long zx) {
+    constexpr int TM = 2, WN = 4, BM = 128, BN = 32 * TN * WN, CH = BM + BN;
+    constexpr int PITCH = CH * 2 + 64;                    // bytes per pixel row of one piece plane (see the bank note below)
+    constexpr int PL = BK * PITCH, ST = 3 * PL;           // piece plane / stage bytes
+    constexpr int NLA = BM / 64, NLB = BN / 64, NLD = NLA + NLB;      // float4 loads per thread and chunk
+    constexpr int PER = TM * TN, NMF = 12 * PER, NRD = 3 * (TM + TN) * 2;   // per chunk and wave: matrix instr.; tr reads per k block
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    // Bank note: a wave's ds_read_b64_tr_b16 touches, per 32-lane half, two [4 px][16 ch] blocks = 4 rows x 64 bytes; with
+    // PITCH = 2 CH + 64 bytes (CH a multiple of 128) consecutive pixel rows are 16 banks apart, the four rows cover all 64.
+    {
+        const int tap_b = blockIdx.x / ctiles;
+        dy += (long)tap_b * zdy;
+        x += (long)tap_b * zx;
+    }
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, dybytes), rx = make_rsrc(x, xbytes);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const long M = (long)g.N * g.Hout * g.Wout;
+    const int co0 = blockIdx.y * BM;
+    const int tap = blockIdx.x / ctiles, ci0 = (blockIdx.x - tap * ctiles) * BN;
+    const int tr = tap / g.S, ts_ = tap - tr * g.S;
+    const long nchunks = (M + BK - 1) / BK;
+    const long c_begin = (long)blockIdx.z * chunks_per_split;
+    const int nk = (int)(min(nchunks, c_begin + chunks_per_split) - c_begin);     // chunks of this block (>= 1 by the plan)
+
+    // ---- loads: thread (px = tid / 16, q = tid % 16) fetches float4 q + 16 j of pixel px: NLA of dY, NLB of X
+    const int px = tid >> 4, q = tid & 15;
+    const int lddyb = (int)lddy * 4, ldxb = (int)ldx * 4;
+    float4 r[2][NLD];
+    int l_kc = 0;                                         // chunk the NEXT load fetches (clamped to the block's last)
+    auto load_one = [&](auto set_c, auto i_c, int dyo, int xo) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value, i = decltype(i_c)::value;
+        if constexpr (i < NLA) {
+            const int co = co0 + 4 * (q + 16 * i);
+            r[SET][i] = buf_load4(rdy, (dyo != OOB_OFF && co < g.Cout) ? dyo + co * 4 : OOB_OFF);
+        } else {
+            const int ci = ci0 + 4 * (q + 16 * (i - NLA));
+            r[SET][i] = buf_load4(rx, (xo != OOB_OFF && ci < g.Cin) ? xo + ci * 4 : OOB_OFF);
+        }
+    };
+    // row offsets of this thread's pixel in chunk l_kc (OOB_OFF: past M / outside the image for this tap)
+    auto row_offsets = [&](int& dyo, int& xo) __attribute__((always_inline)) {
+        const long m = (c_begin + l_kc) * BK + px;
+        const bool mv = m < M;
+        const unsigned mm = mv ? (unsigned)m : 0u;
+        dyo = mv ? (int)mm * lddyb : OOB_OFF;
+        if constexpr (PW) {
+            xo = mv ? (int)mm * ldxb : OOB_OFF;
+        } else {
+            const unsigned t = mm / (unsigned)g.Wout;
+            const int wo = (int)(mm - t * (unsigned)g.Wout);
+            const unsigned n_ = t / (unsigned)g.Hout;
+            const int ho = (int)(t - n_ * (unsigned)g.Hout);
+            int ih, iw;
+            const bool okh = gather_coord(ho * g.mul + g.off_h, tr, g.step, 0, g.Hin, ih);
+            const bool okw = gather_coord(wo * g.mul + g.off_w, ts_, g.step, 0, g.Win, iw);
+            xo = (mv & okh & okw) ? ((int)n_ * g.Hin * g.Win + ih * g.Win + iw) * ldxb : OOB_OFF;
+        }
+    };
+    auto load_all = [&](auto set_c) __attribute__((always_inline)) {
+        int dyo, xo;
+        row_offsets(dyo, xo);
+        wt_static_for<0, NLD>([&](auto i) __attribute__((always_inline)) { load_one(set_c, i, dyo, xo); });
+        l_kc = min(l_kc + 1, nk - 1);
+    };
+    // LDS byte offset of float4 i of this thread inside a piece plane
+    auto st_off = [&](int i) __attribute__((always_inline)) {
+        const int ch = i < NLA ? 4 * (q + 16 * i) : BM + 4 * (q + 16 * (i - NLA));
+        return px * PITCH + ch * 2;
+    };
+    auto store_f4 = [&](int stage, int i, uint2 p0, uint2 p1, uint2 p2) __attribute__((always_inline)) {
+        unsigned char* d = smem + stage * ST + st_off(i);
+        *(uint2*)d = p0;
+        *(uint2*)(d + PL) = p1;
+        *(uint2*)(d + 2 * PL) = p2;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    // ---- operand fragments: lane (j = lane % 16, blk = (lane / 16) % 2, lh = lane / 32) reads [4 px][16 ch] blocks
+    const int li = lane & 31, lh = lane >> 5, lj = lane & 15, lblk = (lane >> 4) & 1;
+    const int lbase = (8 * lh + (lj >> 2)) * PITCH + (16 * lblk + 4 * (lj & 3)) * 2;
+    const int afr = lbase + (wm * 64) * 2, bfr = lbase + (BM + wn * 32 * TN) * 2;
+    struct Frag { v4s16 a[3][TM][2], b[3][TN][2]; };      // [piece][block][pixel half]
+    Frag f[2];
+    // read J of a k block: product order (a2.., b0.., a1.., b1.., a0.., b2..), two halves each
+    auto do_read = [&](auto stage_c, auto gk_c, auto j_c) __attribute__((always_inline)) {
+        constexpr int stage = decltype(stage_c)::value, gk = decltype(gk_c)::value, J = decltype(j_c)::value;
+        if constexpr (J < NRD) {
+            constexpr int h = J & 1, F = J >> 1, qq = F / (TM + TN), w = F % (TM + TN);
+            constexpr int rowoff = (16 * gk + 4 * h) * PITCH;
+            if constexpr (w < TM)
+                f[gk].a[2 - qq][w][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(WT_LDS(smem + stage * ST + (2 - qq) * PL + rowoff + w * 64 + afr));
+            else
+                f[gk].b[qq][w - TM][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(WT_LDS(smem + stage * ST + qq * PL + rowoff + (w - TM) * 64 + bfr));
+        }
+    };
+    auto frag8 = [&](const v4s16 (&hh)[2]) __attribute__((always_inline)) {
+        v8s16 v = __builtin_shufflevector(hh[0], hh[1], 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto do_mfma = [&](auto i_c) __attribute__((always_inline)) {
+        constexpr int I = decltype(i_c)::value;
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+        constexpr int gk = I / (6 * PER), qq = (I / PER) % 6, ab = I % PER, a = ab / TN, b = ab % TN;
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag8(f[gk].a[PA[qq]][a]), frag8(f[gk].b[PB[qq]][b]), acc[a][b], 0, 0, 0);
+    };
+
+    // ---- prologue: chunk 0 into stage 0; chunks 1 (set 1) and 2 (set 0) in flight, in the loop's own issue order
+    load_all(C0{});
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        uint2 p0, p1, p2;
+        split3_bf16(r[0][i], p0, p1, p2);
+        store_f4(0, i, p0, p1, p2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    load_all(C1{});
+    __builtin_amdgcn_sched_barrier(0);
+    load_all(C0{});
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) f[1].a[p][a][h] = (v4s16){0, 0, 0, 0};
+#pragma unroll
+            for (int b = 0; b < TN; ++b) f[1].b[p][b][h] = (v4s16){0, 0, 0, 0};
+        }
+    }
+
+    // ---- main loop (igemm_ws.hip's structure).  Per chunk kc: the tail products of chunk kc-1, the products of k block 0
+    //      and the first ones of k block 1; meanwhile the operand reads, the split of chunk kc+1 out of register set
+    //      (kc+1) % 2 into the other LDS stage, then that set is reloaded with chunk kc+3.
+    uint2 pc[3];
+    float sp_l = 0.f, sp_h = 0.f;
+    int n_dyo = 0, n_xo = 0;
+    auto chunk = [&](auto par_c) __attribute__((always_inline)) {
+        constexpr int cur = decltype(par_c)::value, nxt = cur ^ 1;
+        using CUR = std::integral_constant<int, cur>;
+        using NXT = std::integral_constant<int, nxt>;
+        constexpr int TAIL = 2 * PER;
+        constexpr int F0_PRE = 2 * (TM + TN), F0_PER = (NRD - F0_PRE + TAIL - 1) / TAIL;       // reads before slot 0; per tail slot
+        constexpr int LD_SLOTS = (NLD + 1) / 2;                                               // two loads per slot
+        constexpr int SPP = (NMF - TAIL - LD_SLOTS) / (2 * NLD) >= 3 ? 3 : 2;                  // slots per value pair (3 steps)
+        constexpr int F1_START = TAIL, SP_START = TAIL, SP_END = SP_START + SPP * 2 * NLD, LD_START = SP_END;
+        static_assert(F1_START + NRD <= NMF, "k block 1 operand reads do not fit");
+        static_assert(LD_START + LD_SLOTS <= NMF, "split + loads do not fit the chunk");
+        wt_static_for<0, F0_PRE>([&](auto j) __attribute__((always_inline)) { do_read(CUR{}, C0{}, j); });
+        __builtin_amdgcn_sched_barrier(0);
+        wt_static_for<0, NMF>([&](auto sl_c) __attribute__((always_inline)) {
+            constexpr int sl = decltype(sl_c)::value;
+            do_mfma(std::integral_constant<int, (sl < TAIL ? NMF - TAIL + sl : sl - TAIL)>{});
+            if constexpr (sl < TAIL)
+                wt_static_for<0, F0_PER>([&](auto u) __attribute__((always_inline)) { do_read(CUR{}, C0{}, std::integral_constant<int, F0_PRE + sl * F0_PER + decltype(u)::value>{}); });
+            if constexpr (sl >= F1_START) do_read(CUR{}, C1{}, std::integral_constant<int, sl - F1_START>{});
+            if constexpr (sl >= SP_START && sl < SP_END) {
+                constexpr int k = (sl - SP_START) / SPP, s_in = (sl - SP_START) % SPP;     // value pair k (float4 k / 2), slot in pair
+                constexpr int st0 = SPP == 3 ? s_in : (s_in == 0 ? 0 : 2), st1 = SPP == 3 ? s_in : (s_in == 0 ? 1 : 2);
+                wt_static_for<st0, st1 + 1>([&](auto step_c) __attribute__((always_inline)) {
+                    constexpr int step = decltype(step_c)::value;
+                    if constexpr (step == 0) {
+                        const float4 v = r[nxt][k >> 1];
+                        sp_l = (k & 1) ? v.z : v.x;
+                        sp_h = (k & 1) ? v.w : v.y;
+                    }
+                    const unsigned w = pack2_bf16(sp_l, sp_h);
+                    if constexpr (step < 2) {
+                        sp_l = sp_l - bf16_lo_f(w);
+                        sp_h = sp_h - bf16_hi_f(w);
+                    }
+                    if constexpr (k & 1) pc[step].y = w; else pc[step].x = w;
+                    if constexpr ((k & 1) && step == 2) store_f4(nxt, k >> 1, pc[0], pc[1], pc[2]);
+                });
+            }
+            if constexpr (sl == LD_START - 1) row_offsets(n_dyo, n_xo);          // address arithmetic one slot ahead of the loads
+            if constexpr (sl >= LD_START && sl < LD_START + LD_SLOTS) {              // chunk kc + 3, two loads per slot
+                constexpr int i0 = 2 * (sl - LD_START);
+                load_one(NXT{}, std::integral_constant<int, i0>{}, n_dyo, n_xo);
+                if constexpr (i0 + 1 < NLD) load_one(NXT{}, std::integral_constant<int, i0 + 1>{}, n_dyo, n_xo);
+                if constexpr (sl == LD_START + LD_SLOTS - 1) l_kc = min(l_kc + 1, nk - 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        __syncthreads();
+    };
+    {
+        int kc = 0;
+        for (; kc + 1 < nk; kc += 2) {
+            chunk(C0{});
+            chunk(C1{});
+        }
+        if (kc < nk) chunk(C0{});
+        wt_static_for<0, 2 * PER>([&](auto sl) __attribute__((always_inline)) { do_mfma(std::integral_constant<int, NMF - 2 * PER + decltype(sl)::value>{}); });
+    }
+
+    // ---- partial slab [split][Cout][R*S*Cin]
+    const long wsz = (long)g.Cout * g.R * g.S * g.Cin;
+    float* out = part + (long)blockIdx.z * wsz;
+    const long rowlen = (long)g.R * g.S * g.Cin;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int ci = ci0 + wn * 32 * TN + b * 32 + li;
+            if (ci >= g.Cin) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + wm * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (co < g.Cout) out[(long)co * rowlen + (long)tap * g.Cin + ci] = acc[a][b][e];
+            }
+        }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+// U2PL_WGRAD_TR = 1 (default) | 0: conv.hip's k_conv_wgrad_bf16 for every layer; u2pl_wgrad_set_tr() for A/B runs and tests
+static int g_wgrad_tr = -1;
+static int wgrad_tr_on() {
+    if (g_wgrad_tr < 0) { const char* e = getenv("U2PL_WGRAD_TR"); g_wgrad_tr = (e && *e) ? (atoi(e) != 0) : 1; }
+    return g_wgrad_tr;
+}
+U2PL_API int u2pl_wgrad_set_tr(int on) { const int old = wgrad_tr_on(); g_wgrad_tr = on != 0; return old; }
+bool wgrad_tr_eligible(const ConvGeom& g) {
+    return wgrad_tr_on() && g.Cout >= 128 && g.Cin >= 128 && !(g.Cout % 4) && !(g.Cin % 4);
+}
+static int wt_bn(const ConvGeom& g) { return g.Cin > 128 ? 256 : 128; }
+// slabs: one block per CU and round; the plan minimises (rounds of 256 blocks) x (chunks per slab + fixed cost per block)
+void wgrad_tr_plan(const ConvGeom& g, int taps, int& ctiles, int& nsplit, int& cps) {
+    const long M = (long)g.N * g.Hout * g.Wout;
+    const long nchunks = (M + BK - 1) / BK;
+    ctiles = cdiv(g.Cin, wt_bn(g));
+    const long tiles = (long)cdiv(g.Cout, 128) * ctiles * taps;
+    long best = 1;
+    double bestc = 1e30;
+    const long maxs = nchunks / 6 > 0 ? nchunks / 6 : 1;
+    for (long s = 1; s <= maxs && s <= 96; ++s) {
+        const long c = (nchunks + s - 1) / s;
+        if ((nchunks + c - 1) / c != s) continue;                      // not a distinct plan
+        const double rounds = (double)cdiv(tiles * s, 256);
+        const double cost = rounds * (c + 5.0) + 0.15 * s;             // 5: prologue + slab write; 0.15 / slab: its share of the reduce
+        if (cost < bestc) { bestc = cost; best = s; }
+    }
+    cps = (int)((nchunks + best - 1) / best);
+    nsplit = (int)((nchunks + cps - 1) / cps);
+}
+
+template <int TN, bool PW>
+static int launch1(const float* dy, long lddy, const float* x, long ldx, float* part, const ConvGeom& g, int ctiles, int nsplit,
+                   int cps, int taps, hipStream_t stream, long zdy, long zx) {
+    constexpr int CH = 128 + 128 * TN, PITCH = CH * 2 + 64;
+    const size_t lds = (size_t)2 * 3 * BK * PITCH;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_wgrad_tr<TN, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const long dyb = (((long)g.N * g.Hout * g.Wout - 1) * lddy + g.Cout) * 4;
+    const long xb = (((long)g.N * g.Hin * g.Win - 1) * ldx + g.Cin) * 4;
+    if (dyb >= (1L << 31) || xb >= (1L << 31)) return U2PL_EINVAL;
+    dim3 grid((unsigned)(ctiles * taps), (unsigned)cdiv(g.Cout, 128), (unsigned)nsplit);
+    U2PL_LAUNCH((k_wgrad_tr<TN, PW>), grid, dim3(512), lds, stream, dy, lddy, x, ldx, part, g, ctiles, cps, (unsigned)dyb,
+                (unsigned)xb, zdy, zx);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+int launch_wgrad_tr(const float* dy, long lddy, const float* x, long ldx, float* part, const ConvGeom& g, int ctiles, int nsplit,
+                    int cps, hipStream_t stream, long zdy, long zx) {
+    const int taps = g.R * g.S;
+    // pointwise: identity gather (1x1 stride 1 without padding; the Winograd component batches pass step = 0, offsets 0)
+    const bool pw = g.mul == 1 && g.off_h == 0 && g.off_w == 0 && g.Hin == g.Hout && g.Win == g.Wout && (g.step == 0 || taps == 1);
+    if (wt_bn(g) == 256)
+        return pw ? launch1<2, true>(dy, lddy, x, ldx, part, g, ctiles, nsplit, cps, taps, stream, zdy, zx)
+                  : launch1<2, false>(dy, lddy, x, ldx, part, g, ctiles, nsplit, cps, taps, stream, zdy, zx);
+    return pw ? launch1<1, true>(dy, lddy, x, ldx, part, g, ctiles, nsplit, cps, taps, stream, zdy, zx)
+              : launch1<1, false>(dy, lddy, x, ldx, part, g, ctiles, nsplit, cps, taps, stream, zdy, zx);
+}

@@ -275,6 +275,9 @@ int u2pl_im2col_f32(const float* x, long ldx, float* col, int Kp, int N, int Hin
 size_t u2pl_weight_split3_bytes(int rows, int K, int batch);
 int u2pl_weight_split3_f32(const float* w, long zw, int rows, int K, int batch, void* out, hipStream_t stream);
 int u2pl_igemm_ws_stat_blocks(int N, int Hout, int Wout);
+/* launch shape of the ws kernel (A/B switch, same results; env U2PL_WS_PERSIST): 1 (default) = persistent, at most one
+ * block per CU working through its tiles; 0 = one block per tile */
+int u2pl_igemm_ws_set_persist(int on);
 int u2pl_conv2d_fwd_ws_f32(const float* x, long ldx, const void* wsplit, const float* bias, float* y, long ldy, int N,
                            int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S, int stride, int pad,
                            int dil, hipStream_t stream);

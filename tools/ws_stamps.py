@@ -6,9 +6,9 @@ from u2pl_amd import _lib
 from u2pl_amd._lib import call, query
 L = _lib.lib().cdll
 DEV = "cuda"
-buf = torch.zeros(2 * 2 * 4 * 14 + 1024 * 4, dtype=torch.int64, device=DEV)
+buf = torch.zeros(2 * 2 * 4 * 14 + 1024 * 4 + 64, dtype=torch.int64, device=DEV)
 L.u2pl_igemm_ws_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
-for (M, K, Nn, batch) in [(32768, 1024, 256, 1)]:
+for (M, K, Nn, batch) in [(10000, 512, 256, 36)]:
     x = torch.randn(batch * M * K, device=DEV)
     w = torch.randn(batch * Nn * K, device=DEV) * (K ** -0.5)
     y = torch.empty(batch * M * Nn, device=DEV)
@@ -29,7 +29,13 @@ for (M, K, Nn, batch) in [(32768, 1024, 256, 1)]:
                         continue
                     d = [int(r[i] - t[b, 0, 0, 0]) for i in range(14)]
                     print(f"  blk{b} wave{4*p} chunk{8+c}: abs stamps (slot 0,4,..,44, pre-barrier, post-barrier): {d}")
-        ph = full[224:].reshape(1024, 4)
+        te = full[224 + 4096:224 + 4096 + 40].reshape(2, 4, 5)
+        for wv in range(2):
+            for n in range(4):
+                r = te[wv, n]
+                if r[0]:
+                    print(f"  tile_end wave{5*wv} #{n}: start+{int(r[0]-te[0,0,0])} tail {int(r[1]-r[0])} stores {int(r[2]-r[1])} stats+zero {int(r[3]-r[2])} drain(vmcnt0) {int(r[4]-r[3])}")
+        ph = full[224:224 + 4096].reshape(1024, 4)
         ph = ph[ph[:, 0] != 0]
         t0 = int(ph[:, 0].min())
         import statistics as st

@@ -97,28 +97,40 @@ U2PL_API int u2pl_igemm_ws_set_stamp_buffer(void* p) { g_ws_stamps = (unsigned l
 template <int TM, int TN, int WM, int WN, bool PW, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     const float* __restrict__ x, long ldx, const unsigned short* __restrict__ ws, const float* __restrict__ bias,
-    float* __restrict__ y, long ldy, ConvGeom g, unsigned xbytes, unsigned wsbytes, int Np, float* __restrict__ stats,
-    const float* __restrict__ pivot, long zx, long zws, long zy, BnEpi epi, int mtiles, int ntiles, int total_tiles) {
+    float* __restrict__ y, long ldy, ConvGeom g, unsigned xbytes, unsigned wsbytes, unsigned ybytes, unsigned resbytes, int Np,
+    float* __restrict__ stats, const float* __restrict__ pivot, long zx, long zws, long zy, BnEpi epi, int mtiles, int ntiles,
+    int total_tiles) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
     constexpr int RPP = NT / 8, RA = BM / RPP;              // A: 8 threads x float4 per 32-deep row
     constexpr int UB = 3 * BN * 4, RBU = UB / NT;           // B: 16-byte units per chunk, per thread
     static_assert(BM % RPP == 0 && UB % NT == 0, "tile / thread-count mismatch");
     constexpr int A_ST = 3 * BM * WS_ROW_B, B_ST = 3 * BN * WS_ROW_B, ST = A_ST + B_ST;    // bytes per stage
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
 
-    // ---- tile of this block (XCD-aware: block b runs on XCD b % 8; each XCD takes a contiguous range of tiles, N tiles
-    //      fastest so that blocks that are neighbours in time on one L2 share their A rows)
-    int t;
-    {
-        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+    // PERSISTENT: block b works through the tiles v = b, b + G, b + 2G, ... (G = gridDim.x <= 256, one block per CU) as ONE
+    // stream of (tile, chunk) pairs: the loads of the next tile's first chunks are in flight while the last chunks of
+    // this tile are multiplied, and the tile's results leave straight from the accumulator registers (plain dword
+    // stores, a 128-byte row segment per half wave) while the next tile's products are already being issued.  With one
+    // tile per launch slot the 256 blocks ran their load / multiply / store phases in lockstep: for the K = 256 GEMMs
+    // (Winograd components, conv3, conv1's data gradient) 13k of every 45k cycles were prologue + epilogue and the
+    // output of a whole round (33 MB) hit the memory at once.
+    // Virtual tile id -> tile: XCD-aware (block b runs on XCD b % 8 and v = b mod 8; each XCD takes a contiguous range of
+    // tiles, N tiles fastest so that neighbours in time on one L2 share their A rows).
+    const int G = gridDim.x;
+    auto tile_of = [&](int v, int& mt, int& nt, int& z) __attribute__((always_inline)) {
+        const int xcd = v & 7, j = v >> 3;
         const int q = total_tiles >> 3, r = total_tiles & 7;
-        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-    const int nt_ = t % ntiles, rest = t / ntiles;
-    const int mt_ = rest % mtiles, z = rest / mtiles;
-    x += (long)z * zx;
-    ws += (long)z * zws;
-    y += (long)z * zy;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, xbytes), rw = make_rsrc(ws, wsbytes);
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        nt = t % ntiles;
+        const int rest = t / ntiles;
+        mt = rest % mtiles;
+        z = rest / mtiles;
+    };
+    // buffer descriptors cover ONE matrix of the batch (the range check is the row / column mask of loads and stores) and
+    // are rebuilt when a stream enters a tile of another matrix.  (A batch offset in the instructions' scalar offset does
+    // not work: the range check adds it to the lane offset -- measured: every access to matrix z > 0 was dropped.)
+    __amdgpu_buffer_rsrc_t rx = make_rsrc(x, xbytes), rw = make_rsrc(ws, wsbytes), ry = make_rsrc(y, ybytes);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef U2PL_WS_STAMPS
     unsigned long long ph[4];
@@ -130,78 +142,109 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     const long M = (long)g.N * g.Hout * g.Wout;
     const int K = g.R * g.S * g.Cin;
     const int nk = K / BK;
-    const long m0 = (long)mt_ * BM;
-    const int n0 = nt_ * BN;
+    // chunks per tile, made EVEN (an odd K / 32 gets one all-zero chunk: out-of-range offsets load zeros, the products add
+    // +0): stage and register-set parity then restart at every tile and the tile loop below has ONE epilogue instance
+    const int nk2 = (nk + 1) & ~1;
+    const int n_my = (total_tiles - (int)blockIdx.x + G - 1) / G;      // tiles of this block (>= 1: G <= total_tiles)
 
-    // ---- A gather state (as k_conv_igemm)
+    // ---- A load stream (two chunks ahead of the products): its tile, its chunk / tap state, the rows' addresses
     const int kq = tid & 7, r0 = tid >> 3;
+    const int ldxb = (int)ldx * 4;
+    int a_v = blockIdx.x, a_kc = 0, a_c0 = 0, a_r = 0, a_s = 0;
     int bh[RA], bw[RA], nb[RA];
     bool mv[RA];
     int aoff[RA];         // PW: byte offset of the row's first chunk (OOB_OFF for rows past M)
-    const int ldxb = (int)ldx * 4;
+    auto a_tile_setup = [&]() __attribute__((always_inline)) {
+        int mt, nt, z;
+        tile_of(a_v, mt, nt, z);
+        rx = make_rsrc(x + (long)__builtin_amdgcn_readfirstlane(z) * zx, xbytes);
 #pragma unroll
-    for (int i = 0; i < RA; ++i) {
-        const long m = m0 + r0 + RPP * i;
-        mv[i] = m < M;
-        const unsigned mm = mv[i] ? (unsigned)m : 0u;
-        const unsigned tq = mm / (unsigned)g.Wout;
-        const int wo = (int)(mm - tq * (unsigned)g.Wout);
-        const unsigned n_ = tq / (unsigned)g.Hout;
-        const int ho = (int)(tq - n_ * (unsigned)g.Hout);
-        bh[i] = ho * g.mul + g.off_h;
-        bw[i] = wo * g.mul + g.off_w;
-        nb[i] = (int)n_ * g.Hin * g.Win;
-        aoff[i] = mv[i] ? (int)mm * ldxb + kq * 16 : OOB_OFF;
-    }
+        for (int i = 0; i < RA; ++i) {
+            const long m = (long)mt * BM + r0 + RPP * i;
+            mv[i] = m < M;
+            const unsigned mm = mv[i] ? (unsigned)m : 0u;
+            if constexpr (PW) {
+                aoff[i] = mv[i] ? (int)mm * ldxb + kq * 16 : OOB_OFF;
+            } else {
+                const unsigned tq = mm / (unsigned)g.Wout;
+                const int wo = (int)(mm - tq * (unsigned)g.Wout);
+                const unsigned n_ = tq / (unsigned)g.Hout;
+                const int ho = (int)(tq - n_ * (unsigned)g.Hout);
+                bh[i] = ho * g.mul + g.off_h;
+                bw[i] = wo * g.mul + g.off_w;
+                nb[i] = (int)n_ * g.Hin * g.Win;
+            }
+        }
+    };
+    a_tile_setup();
     // A: TWO register sets (chunks of even / odd index): the activation rows come from HBM and are requested TWO chunks
     // before they are split (a chunk lasts ~1.5 us, all 256 blocks request at the same moments: one chunk of distance
     // left 900-2000 cycles of every chunk waiting for them); B (L2-resident weight planes): one set, one chunk ahead.
     float4 ra[2][RA];
     u32x4 rb[RBU];
-    // B: unit u = tid + j * NT of the [3][BN][4] units of a chunk; piece p = u / (BN * 4)
-    int boff[RBU];        // byte offset inside the chunk's global image, relative to (chunk, piece 0, row n0)
-    int blds[RBU];        // byte offset inside the stage's B region
-#pragma unroll
-    for (int j = 0; j < RBU; ++j) {
-        const int u = tid + j * NT, p = u / (BN * 4), wi = u - p * (BN * 4);
-        boff[j] = (p * Np + n0) * WS_ROW_B + wi * 16;
-        blds[j] = A_ST + p * BN * WS_ROW_B + wi * 16;
-    }
-    const int chunk_b = 3 * Np * WS_ROW_B;                  // bytes per chunk of the split planes
-    // the chunks the NEXT load_a() / load_b() fetch: index, channel offset and tap, advanced without divisions; past the
-    // last chunk the last one is fetched again (unconditional loads: a load under `if` would be waited for with vmcnt(0))
-    int l_kc = 0, l_c0 = 0, l_r = 0, l_s = 0, lb_kc = 0;
     auto load_a_row = [&](auto set_c, auto i_c) __attribute__((always_inline)) {
         constexpr int SET = decltype(set_c)::value, i = decltype(i_c)::value;
+        const bool live = a_kc < nk;
         if constexpr (PW) {
-            ra[SET][i] = buf_load4s(rx, aoff[i], l_kc * (BK * 4));
+            ra[SET][i] = buf_load4s(rx, live ? aoff[i] : OOB_OFF, a_kc * (BK * 4));
         } else {
             int ih, iw;
-            const bool okh = gather_coord(bh[i], l_r, g.step, g.log2div, g.Hin, ih);
-            const bool okw = gather_coord(bw[i], l_s, g.step, g.log2div, g.Win, iw);
+            const bool okh = gather_coord(bh[i], a_r, g.step, g.log2div, g.Hin, ih);
+            const bool okw = gather_coord(bw[i], a_s, g.step, g.log2div, g.Win, iw);
             const int off = (nb[i] + ih * g.Win + iw) * ldxb + kq * 16;
-            ra[SET][i] = buf_load4s(rx, (mv[i] & okh & okw) ? off : OOB_OFF, l_c0 * 4);
+            ra[SET][i] = buf_load4s(rx, (live & mv[i] & okh & okw) ? off : OOB_OFF, a_c0 * 4);
         }
     };
+    // next chunk of the stream; after a tile's last chunk the next tile of this block; after the last tile: stay (the loads
+    // are unconditional -- a load under `if` would be waited for with vmcnt(0) --, what they fetch then is never used)
     auto advance_a = [&]() __attribute__((always_inline)) {
-        if (l_kc < nk - 1) {
-            ++l_kc;
-            l_c0 += BK;
-            if (l_c0 == g.Cin) {
-                l_c0 = 0;
-                if (++l_s == g.S) { l_s = 0; ++l_r; }
+        if (a_kc + 1 < nk2) {
+            ++a_kc;
+            a_c0 += BK;
+            if (a_c0 == g.Cin) {
+                a_c0 = 0;
+                if (++a_s == g.S) { a_s = 0; ++a_r; }
             }
+        } else if (a_v + G < total_tiles) {
+            a_v += G;
+            a_kc = a_c0 = a_r = a_s = 0;
+            a_tile_setup();
         }
     };
     auto load_a = [&](auto set_c) __attribute__((always_inline)) {
         static_for<0, RA>([&](auto i) __attribute__((always_inline)) { load_a_row(set_c, i); });
         advance_a();
     };
+    // ---- B load stream (one chunk ahead): unit u = tid + j * NT of the [3][BN][4] 16-byte units of a chunk; piece u / (BN * 4)
+    int boff[RBU];        // byte offset inside the chunk's global image, relative to (chunk, piece 0, row 0 of the tile)
+    int blds[RBU];        // byte offset inside the stage's B region
+#pragma unroll
+    for (int j = 0; j < RBU; ++j) {
+        const int u = tid + j * NT, p = u / (BN * 4), wi = u - p * (BN * 4);
+        boff[j] = p * Np * WS_ROW_B + wi * 16;
+        blds[j] = A_ST + p * BN * WS_ROW_B + wi * 16;
+    }
+    const int chunk_b = 3 * Np * WS_ROW_B;                  // bytes per chunk of the split planes
+    int b_v = blockIdx.x, b_kc = 0, b_toff = 0;
+    auto b_tile_setup = [&]() __attribute__((always_inline)) {
+        int mt, nt, z;
+        tile_of(b_v, mt, nt, z);
+        rw = make_rsrc(ws + (long)__builtin_amdgcn_readfirstlane(z) * zws, wsbytes);
+        b_toff = __builtin_amdgcn_readfirstlane(nt * BN * WS_ROW_B);
+    };
+    b_tile_setup();
     auto load_b_unit = [&](auto j_c) __attribute__((always_inline)) {
         constexpr int j = decltype(j_c)::value;
-        rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, boff[j], lb_kc * chunk_b, 0);
+        rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_kc < nk ? boff[j] : OOB_OFF, b_toff + b_kc * chunk_b, 0);
     };
-    auto advance_b = [&]() __attribute__((always_inline)) { lb_kc = min(lb_kc + 1, nk - 1); };
+    auto advance_b = [&]() __attribute__((always_inline)) {
+        if (b_kc + 1 < nk2) ++b_kc;
+        else if (b_v + G < total_tiles) {
+            b_v += G;
+            b_kc = 0;
+            b_tile_setup();
+        }
+    };
     auto load_b = [&]() __attribute__((always_inline)) {
         static_for<0, RBU>([&](auto j) __attribute__((always_inline)) { load_b_unit(j); });
         advance_b();
@@ -233,9 +276,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
         return __builtin_bit_cast(bf16x8, *(const uint4*)(smem + stage * ST + bfr + p * (BN * WS_ROW_B) + b * (32 * WS_ROW_B) + (sw0 ^ (gk << 5))));
     };
     struct Frag { bf16x8 a[3][TM], b[3][TN]; };
-    using C0 = std::integral_constant<int, 0>;
-    using C1 = std::integral_constant<int, 1>;
-    // ---- prologue: chunk 0 into stage 0; B(1), A(1), A(2) in flight
+    // ---- prologue: chunk 0 into stage 0; A(1), B(1), A(2) in flight
     load_a(C0{});
     load_b();
 #pragma unroll
@@ -250,8 +291,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
 #pragma unroll
     for (int j = 0; j < RBU; ++j) store_b(0, j);
     // (issue order A(1), B(1), A(2) = the order the loop leaves its loads in at every trip: the compiler merges the wait
-    // counters of the loop entry and of the back edge, a different order here costs a vmcnt(0) in the loop)
-    __builtin_amdgcn_sched_barrier(0);      // (... and the scheduler must not interleave the three groups)
+    // counters of the loop entry and of the back edge, a different order here costs a vmcnt(0) in the loop; and the
+    // scheduler must not interleave the three groups)
+    __builtin_amdgcn_sched_barrier(0);
     load_a(C1{});
     __builtin_amdgcn_sched_barrier(0);
     load_b();
@@ -265,6 +307,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
 
     constexpr int PER = TM * TN, NMF = 12 * PER;            // matrix instructions per 16-deep block product / per chunk
     constexpr int NRD = 3 * (TM + TN);                      // operand reads per 16-deep block
+    constexpr int TAIL = 2 * PER;
     Frag f[2];
     // matrix instruction I of a chunk: k block I / (6 PER), product (I / PER) % 6, accumulator I % PER
     auto do_mfma = [&](auto i_c) __attribute__((always_inline)) {
@@ -282,22 +325,28 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
             else f[gk].b[q][w - TM] = ldb(stage, q, w - TM, gk);
         }
     };
+    auto zero_tail_operands = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) f[1].a[p][a] = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
+#pragma unroll
+            for (int b = 0; b < TN; ++b) f[1].b[p][b] = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
+        }
+    };
 
     // Main loop, issue order pinned (a scheduling barrier after every matrix instruction and the work placed behind it);
     // two chunks per trip so that the LDS stage and the A register set of a chunk are compile-time constants.
     // The barrier of a chunk sits INSIDE the matrix-instruction stream: the last TAIL products of a chunk (operands in
     // registers) are issued after the barrier, in front of the next chunk's, and cover the latency of its first operand
-    // reads.  Before the first chunk the tail runs on all-zero operands (adds +0 to +0).  Per accumulator the order of the
-    // products is: k blocks ascending, six piece products each.
+    // reads.  Before a tile's first chunk the tail runs on all-zero operands (adds +0 to +0).  Per accumulator the order of
+    // the products is: k blocks ascending, six piece products each.
     // (Tried and dropped: a second wave group half a chunk out of phase -- no gain, 23 more registers; a compiler-scheduled
     // loop behind a sched_group_barrier pipeline -- same time as the pinned order, no control.)
+    zero_tail_operands();
+    if constexpr (ABL & 16) {   // (timing experiment: operands never read from LDS)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-#pragma unroll
-        for (int a = 0; a < TM; ++a) f[1].a[p][a] = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
-#pragma unroll
-        for (int b = 0; b < TN; ++b) f[1].b[p][b] = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
-        if constexpr (ABL & 16) {   // (timing experiment: operands never read from LDS)
+        for (int p = 0; p < 3; ++p) {
 #pragma unroll
             for (int a = 0; a < TM; ++a) f[0].a[p][a] = __builtin_bit_cast(bf16x8, make_uint4(tid, 1, 2, 3));
 #pragma unroll
@@ -306,7 +355,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     }
     uint2 pc[3];          // pieces of the float4 being split
     float sp_l = 0.f, sp_h = 0.f;     // the pair being split: residuals after the pieces taken so far
-    auto chunk = [&](auto plan_c, auto par_c, int kc) __attribute__((always_inline)) {
+    int kc = 0;                       // chunk of the current tile (the products' stream; debug stamps only)
+    auto chunk = [&](auto par_c) __attribute__((always_inline)) {
         constexpr int cur = decltype(par_c)::value, nxt = cur ^ 1;
         // Per slot (= per matrix instruction) at most one operand read / store / global load and <= 5 VALU operations: a
         // wave alone then issues its matrix instructions back to back (32 cycles apart) with everything else in the gaps.
@@ -320,7 +370,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
         //                                                                     VALU), the three piece stores behind a float4's last
         //   then RBU slots                                                  | weight-piece stores, one per slot
         //   then RBU + RA slots                                             | loads B(kc+2), then A(kc+3), one per slot
-        constexpr int TAIL = 2 * PER, F0_PRE = TM + TN, F0_PER = (NRD - F0_PRE + TAIL - 1) / TAIL;
+        constexpr int F0_PRE = TM + TN, F0_PER = (NRD - F0_PRE + TAIL - 1) / TAIL;
         constexpr int F1_START = TAIL, SP_START = TAIL, BS_START = SP_START + 6 * RA, LD_START = BS_START + RBU;
         static_assert(F1_START + NRD <= NMF && LD_START + RBU + RA <= NMF, "plan does not fit the chunk");
         using CUR = std::integral_constant<int, cur>;
@@ -399,128 +449,152 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
         }
 #endif
     };
-    auto main_loop = [&](auto plan_c) __attribute__((always_inline)) {
-        constexpr int TAIL = 2 * PER;
-        // (the back edge comes from the odd chunk ONLY -- with a conditional second half the compiler merges the wait-counter
-        // state "after the even chunk" into the loop header and waits with vmcnt(0) for the loads just issued)
-        int kc = 0;
-        for (; kc + 1 < nk; kc += 2) {
-            chunk(plan_c, C0{}, kc);
-            chunk(plan_c, C1{}, kc + 1);
-        }
-        if (kc < nk) chunk(plan_c, C0{}, kc);
-        static_for<0, TAIL>([&](auto sl) __attribute__((always_inline)) { do_mfma(std::integral_constant<int, NMF - TAIL + decltype(sl)::value>{}); });
-    };
-    main_loop(C0{});
-#ifdef U2PL_WS_STAMPS
-    ph[2] = __builtin_readcyclecounter();
-#endif
 
-    // ---- epilogue (as k_conv_igemm): each wave transposes its (32 TM) x (32 TN) block through LDS, 16-byte row stores
-    {
-        constexpr int WNC = 32 * TN, PWD = WNC + 4;
-        float* ws_ = (float*)smem + (long)wave * (32 * TM) * PWD;
+    // ---- end of a tile: the chunk's tail products, then the results leave from the accumulator registers.
+    //      (Measured alternatives: swapped matrix operands put four consecutive COLUMNS of one row into a lane -- 16-byte stores,
+    //      but one 16-byte piece per row and lane: 14k cycles for the tile's stores against 6.3k for these dword stores with a
+    //      128-byte row segment per half wave; the LDS-transposed 16-byte stores of conv.hip's epilogue cost ~9k with their drain.)
+    //      Store offsets: element (row m, column c) at (m * ldy + c) * 4 in the matrix's descriptor; a row past M lies past the
+    //      descriptor's extent (ldy >= Cout) and a column past Cout is given OOB_OFF: the hardware drops both, no compares.
+    int c_v = blockIdx.x;
+    const int ldyb = (int)ldy * 4;
+    float* red = (float*)(smem + 2 * ST);   // [4][2][BN] statistics scratch BEHIND the two stages (stage `nxt` already holds the next tile)
+#ifdef U2PL_WS_STAMPS
+    int te_n = 0;
+#endif
+    auto tile_end = [&]() __attribute__((always_inline)) {
+#ifdef U2PL_WS_STAMPS
+        unsigned long long te[5];
+        te[0] = __builtin_readcyclecounter();
+#endif
+        static_for<0, TAIL>([&](auto sl) __attribute__((always_inline)) { do_mfma(std::integral_constant<int, NMF - TAIL + decltype(sl)::value>{}); });
+#ifdef U2PL_WS_STAMPS
+        te[1] = __builtin_readcyclecounter();
+#endif
+        int mt, nt, z;
+        tile_of(c_v, mt, nt, z);
+        const long m0 = (long)mt * BM;
+        const int n0 = nt * BN;
+        ry = make_rsrc(y + (long)__builtin_amdgcn_readfirstlane(z) * zy, ybytes);
+        const bool bn_all = epi.mean != nullptr;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = n0 + wn * 32 * TN + b * 32 + li;
+            const bool cv = col < g.Cout;
+            const float bias_v = (bias && cv) ? bias[col] : 0.f;
+            float mu = 0.f, is = 0.f, ga = 0.f, be = 0.f;
+            if (bn_all && cv) { mu = epi.mean[col]; is = epi.invstd[col]; ga = epi.gamma[col]; be = epi.beta[col]; }
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const long mb = m0 + wm * 32 * TM + a * 32 + 4 * lh;              // row of element e = 0
+                // (mb * ldy fits 32 bits: the tensor's bytes < 2^31, host check)
+                const int vbase = cv ? ((int)mb * (int)ldy + col) * 4 : OOB_OFF;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    constexpr int dummy = 0;
+                    const int ro = (e & 3) + 8 * (e >> 2);
+                    float v = acc[a][b][e] + bias_v;
+                    if (bn_all) {       // eval-mode BatchNorm (+ residual, ReLU): the operations of k_bn_apply, in its order
+                        v = (v - mu) * is * ga + be;
+                        if (epi.res) {
+                            const long m = mb + ro;
+                            const float rv = (cv && m < M) ? epi.res[m * epi.ldr + col] : 0.f;
+                            v += rv;
+                        }
+                        if (epi.relu) v = fmaxf(v, 0.f);
+                    }
+                    (void)dummy;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, vbase + ro * ldyb, 0, 0);
+                }
+            }
+        }
+#ifdef U2PL_WS_STAMPS
+        te[2] = __builtin_readcyclecounter();
+#endif
+        // fused BatchNorm statistics: per 128-row tile pivot-shifted column sums [tile][2][Cout].  The additions are made in
+        // the order of k_conv_igemm<1, 2, 4, 3> (per 32-row wave block: 16 register values, the two lane halves, then the
+        // four 32-row blocks of the tile in ascending order) so the partial sums are the same bits.
+        if (stats) {
+            static_assert(BM == 128, "statistics blocks are 128 rows");
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int cl = wn * 32 * TN + b * 32 + li, co = n0 + cl;
+                const bool cv = co < g.Cout;
+                const float sh = (cv ? (bias ? bias[co] : 0.f) : 0.f) - (cv && pivot ? pivot[co] : 0.f);
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const long m = m0 + wm * 32 * TM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                        const float v = m < M ? acc[a][b][e] + sh : 0.f;
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                    s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                    if (lh == 0) {
+                        red[((wm * TM + a) * 2 + 0) * BN + cl] = s1;
+                        red[((wm * TM + a) * 2 + 1) * BN + cl] = s2;
+                    }
+                }
+            }
+            __syncthreads();
+            float* out = stats + (long)mt * 2 * g.Cout;
+            for (int c = tid; c < BN; c += NT) {
+                const int co = n0 + c;
+                if (co < g.Cout) {
+                    float a1 = red[0 * BN + c], a2 = red[1 * BN + c];
+#pragma unroll
+                    for (int r = 1; r < 4; ++r) { a1 += red[(2 * r) * BN + c]; a2 += red[(2 * r + 1) * BN + c]; }
+                    out[co] = a1;
+                    out[g.Cout + co] = a2;
+                }
+            }
+            // (the next write of `red` is a whole tile -- at least one chunk barrier -- away)
+        }
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int b = 0; b < TN; ++b)
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    ws_[(a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * PWD + b * 32 + li] = acc[a][b][e];
-        constexpr int C4 = WNC / 4, RPI = 64 / C4;
-        const int cq = lane % C4, rr = lane / C4;
-        const int cbase = n0 + wn * WNC + cq * 4;
-        float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias) {
-            bv4.x = cbase + 0 < g.Cout ? bias[cbase + 0] : 0.f;
-            bv4.y = cbase + 1 < g.Cout ? bias[cbase + 1] : 0.f;
-            bv4.z = cbase + 2 < g.Cout ? bias[cbase + 2] : 0.f;
-            bv4.w = cbase + 3 < g.Cout ? bias[cbase + 3] : 0.f;
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+        zero_tail_operands();
+        c_v += G;
+#ifdef U2PL_WS_STAMPS
+        te[3] = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        te[4] = __builtin_readcyclecounter();
+        if (d_ws_stamps && blockIdx.x == 0 && (wave == 0 || wave == 5) && lane == 0 && te_n < 4)
+            for (int i = 0; i < 5; ++i) d_ws_stamps[224 + 4096 + ((wave != 0) * 4 + te_n) * 5 + i] = te[i];
+        ++te_n;
+#endif
+    };
+    // (the inner loop's back edge comes from the odd chunk only and its entry states -- prologue, end of a tile -- leave the
+    // loads in the same order: the compiler merges the wait-counter states at the loop header)
+    for (int it = 0; it < n_my; ++it) {
+        for (kc = 0; kc < nk2; kc += 2) {
+            chunk(C0{});
+            chunk(C1{});
         }
-        const bool vec_ok = ((ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-        const bool bn_on = epi.mean != nullptr && cbase < g.Cout;
-        float4 mu4 = bv4, is4 = bv4, ga4 = bv4, be4 = bv4;
-        if (bn_on) {
-            mu4 = *(const float4*)(epi.mean + cbase); is4 = *(const float4*)(epi.invstd + cbase);
-            ga4 = *(const float4*)(epi.gamma + cbase); be4 = *(const float4*)(epi.beta + cbase);
-        }
-#pragma unroll
-        for (int it = 0; it < 32 * TM / RPI; ++it) {
-            const int row = it * RPI + rr;
-            const long m = m0 + wm * 32 * TM + row;
-            float4 v = *(const float4*)(ws_ + row * PWD + cq * 4);
-            v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
-            if (bn_on && m < M) {
-                v.x = (v.x - mu4.x) * is4.x * ga4.x + be4.x; v.y = (v.y - mu4.y) * is4.y * ga4.y + be4.y;
-                v.z = (v.z - mu4.z) * is4.z * ga4.z + be4.z; v.w = (v.w - mu4.w) * is4.w * ga4.w + be4.w;
-                if (epi.res) {
-                    const float4 rv = *(const float4*)(epi.res + m * epi.ldr + cbase);
-                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-                }
-                if (epi.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            }
-            if (m < M) {
-                float* dst = y + m * ldy + cbase;
-                if (vec_ok && cbase + 3 < g.Cout) *(float4*)dst = v;
-                else {
-                    if (cbase + 0 < g.Cout) dst[0] = v.x;
-                    if (cbase + 1 < g.Cout) dst[1] = v.y;
-                    if (cbase + 2 < g.Cout) dst[2] = v.z;
-                    if (cbase + 3 < g.Cout) dst[3] = v.w;
-                }
-            }
-        }
-        if (stats) __syncthreads();
-    }
-    // ---- fused BatchNorm statistics: per 128-row tile pivot-shifted column sums [tile][2][Cout].  The additions are
-    //      made in the order of k_conv_igemm<1, 2, 4, 3> (per 32-row wave block: 16 register values, the two lane
-    //      halves, then the four 32-row blocks of the tile in ascending order) so the partial sums are the same bits.
-    if (stats) {
-        static_assert(BM == 128, "statistics blocks are 128 rows");
-        float* red = (float*)smem;   // [4][2][BN]
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int cl = wn * 32 * TN + b * 32 + li, co = n0 + cl;
-            const bool cv = co < g.Cout;
-            const float sh = (cv ? (bias ? bias[co] : 0.f) : 0.f) - (cv && pivot ? pivot[co] : 0.f);
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const long m = m0 + wm * 32 * TM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    const float v = m < M ? acc[a][b][e] + sh : 0.f;
-                    s1 += v;
-                    s2 += v * v;
-                }
-                s1 += __shfl_xor(s1, 32, 64);
-                s2 += __shfl_xor(s2, 32, 64);
-                if (lh == 0) {
-                    red[((wm * TM + a) * 2 + 0) * BN + cl] = s1;
-                    red[((wm * TM + a) * 2 + 1) * BN + cl] = s2;
-                }
-            }
-        }
-        __syncthreads();
-        float* out = stats + (long)mt_ * 2 * g.Cout;
-        for (int c = tid; c < BN; c += NT) {
-            const int co = n0 + c;
-            if (co < g.Cout) {
-                float a1 = red[0 * BN + c], a2 = red[1 * BN + c];
-#pragma unroll
-                for (int r = 1; r < 4; ++r) { a1 += red[(2 * r) * BN + c]; a2 += red[(2 * r + 1) * BN + c]; }
-                out[co] = a1;
-                out[g.Cout + co] = a2;
-            }
-        }
+        tile_end();
     }
 #ifdef U2PL_WS_STAMPS
-    ph[3] = __builtin_readcyclecounter();
+    ph[2] = ph[3] = __builtin_readcyclecounter();
     if (d_ws_stamps && blockIdx.x < 1024 && tid == 0)
         for (int i = 0; i < 4; ++i) d_ws_stamps[224 + blockIdx.x * 4 + i] = ph[i];
 #endif
 }
 
+#define WS_NUM_CUS 256
+// U2PL_WS_PERSIST = 1 (default): at most one block per CU, each working through its tiles; 0: one block per tile (A/B switch,
+// same results; u2pl_igemm_ws_set_persist returns the previous value)
+static int g_ws_persist = -1;
+static int ws_persist() {
+    if (g_ws_persist < 0) { const char* e = getenv("U2PL_WS_PERSIST"); g_ws_persist = (e && *e) ? (atoi(e) != 0) : 1; }
+    return g_ws_persist;
+}
+U2PL_API int u2pl_igemm_ws_set_persist(int on) { const int old = ws_persist(); g_ws_persist = on != 0; return old; }
 template <int TM, int TN, int WM, int WN, bool PW, int ABL = 0>
 static int launch_igemm_ws(const float* x, long ldx, const void* ws, const float* bias, float* y, long ldy,
                            const ConvGeom& g, hipStream_t stream, float* stats, const float* pivot, int batch, long zx,
@@ -530,26 +604,31 @@ static int launch_igemm_ws(const float* x, long ldx, const void* ws, const float
     if (M <= 0) return 0;
     const int K = g.R * g.S * g.Cin, Np = ws_pad_rows(g.Cout);
     const BnEpi ep = epi ? *epi : BnEpi{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
-    const size_t lds_op = (size_t)2 * 3 * (BM + BN) * WS_ROW_B;
-    const size_t lds_epi = (size_t)(WM * WN) * (32 * TM) * (32 * TN + 4) * sizeof(float);
-    const size_t lds = lds_op > lds_epi ? lds_op : lds_epi;
+    const size_t lds = (size_t)2 * 3 * (BM + BN) * WS_ROW_B + (size_t)8 * BN * sizeof(float);      // two stages + statistics scratch
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_igemm_ws<TM, TN, WM, WN, PW, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const long xb = (((long)g.N * g.Hin * g.Win - 1) * ldx + g.Cin) * 4;
+    const long yb = ((M - 1) * ldy + g.Cout) * 4;
     const long wsb1 = (long)(K / 32) * 3 * Np * WS_ROW_B;           // one matrix
-    if (xb >= (1L << 31) || wsb1 >= (1L << 31)) return U2PL_EINVAL;
+    // every tensor of the batch within 2 GiB: 32-bit byte offsets (per-matrix extents in the descriptors, the batch stride in
+    // the scalar offset)
+    if (xb >= (1L << 31) || wsb1 >= (1L << 31) || yb >= (1L << 31)) return U2PL_EINVAL;
+    if ((batch - 1) * zx * 4 + xb >= (1L << 31) || (batch - 1) * zy * 4 + yb >= (1L << 31) || (long)batch * wsb1 >= (1L << 31))
+        return U2PL_EINVAL;
+    if (ep.res && ((M - 1) * ep.ldr + g.Cout) * 4 >= (1L << 31)) return U2PL_EINVAL;
     const int mtiles = cdiv(M, BM), ntiles = cdiv(g.Cout, BN);
     const long total = (long)mtiles * ntiles * batch;
     if (total >= (1L << 30)) return U2PL_EINVAL;
+    const unsigned grid = (unsigned)((total < WS_NUM_CUS || !ws_persist()) ? total : WS_NUM_CUS);
 #ifdef U2PL_WS_STAMPS
     (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(d_ws_stamps), &g_ws_stamps, sizeof(void*), 0, hipMemcpyHostToDevice, stream);
 #endif
-    U2PL_LAUNCH((k_igemm_ws<TM, TN, WM, WN, PW, ABL>), dim3((unsigned)total), dim3(64 * WM * WN), lds, stream, x, ldx,
-                (const unsigned short*)ws, bias, y, ldy, g, (unsigned)xb, (unsigned)wsb1, Np, stats, pivot, zx, wsb1 / 2,
-                zy, ep, mtiles, ntiles, (int)total);
+    U2PL_LAUNCH((k_igemm_ws<TM, TN, WM, WN, PW, ABL>), dim3(grid), dim3(64 * WM * WN), lds, stream, x, ldx,
+                (const unsigned short*)ws, bias, y, ldy, g, (unsigned)xb, (unsigned)wsb1, (unsigned)yb, 0u, Np, stats, pivot, zx,
+                wsb1 / 2, zy, ep, mtiles, ntiles, (int)total);
     U2PL_LAUNCH_CHECK();
     return 0;
 }

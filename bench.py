@@ -98,6 +98,35 @@ def calibrate(model, teacher, calib, batches, sharpen):
     return out
 
 
+_WD = {"timer": None, "phase": "setup", "step": -1}
+
+
+def _watchdog_arm(args, rank, world):
+    """If the run has not finished after U2PL_BENCH_WATCHDOG_S seconds (default 900; multi-GPU runs only), print ONE JSON line
+    that says where it stopped -- phase, step, collectives issued by this rank, the communicator configuration -- and exit:
+    a hang (e.g. a collective order mismatch on RCCL) then costs minutes, not the whole lease, and leaves a record."""
+    import threading
+    if world <= 1:
+        return
+
+    def fire():
+        from u2pl_amd import nn as KN
+        line = {"metric": "train images/sec at 769x769 (R101-DeepLabv3+)", "value": None, "unit": "images/s", "n_gpus": world,
+                "error": "watchdog: no progress", "rank": rank, "phase": _WD["phase"], "step": _WD["step"],
+                "collectives_issued_by_this_rank": KN.COMM_DEBUG["issued"], "comm_stats": dict(KN.COMM_STATS),
+                "teacher_communicator": os.environ.get("U2PL_TEACHER_COMM", "0"),
+                "bucket_overlap": os.environ.get("U2PL_NO_BUCKET_OVERLAP") is None,
+                "hint": "rerun with U2PL_COMM_DEBUG=1 (per-step comparison of the ranks' collective sequences) and "
+                        "U2PL_NO_BUCKET_OVERLAP=1 (all gradient buckets after backward)"}
+        print(json.dumps(line), flush=True)
+        os._exit(3)
+
+    t = threading.Timer(float(os.environ.get("U2PL_BENCH_WATCHDOG_S", "900")), fire)
+    t.daemon = True
+    t.start()
+    _WD["timer"] = t
+
+
 def main():
     args = parse()
     from u2pl_amd import configs
@@ -117,9 +146,17 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        import datetime
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # a first run on RCCL must not be able to hang the lease silently: collectives time out, RCCL reports what it was doing,
+        # and a host watchdog (below) prints a diagnostic JSON line and exits if the run stops making progress
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        os.environ.setdefault("TORCH_NCCL_DUMP_ON_TIMEOUT", "1")
         # "nccl" is RCCL on ROCm; U2PL_DIST_BACKEND=gloo only for the shared-GPU functional test
-        dist.init_process_group(os.environ.get("U2PL_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("U2PL_DIST_BACKEND", "nccl"), rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=float(os.environ.get("U2PL_COLLECTIVE_TIMEOUT_S", "120"))))
+    _watchdog_arm(args, rank, world)
 
     from u2pl_amd.models.model_helper import ModelBuilder
     from u2pl_amd.trainer import SemiTrainer
@@ -159,8 +196,10 @@ def main():
 
     def step(i):
         il, ll, iu = batches[i % len(batches)]
+        _WD["step"] = i
         return trainer.train_step(il, ll, iu, epoch=0)
 
+    _WD["phase"] = "warmup"
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -175,6 +214,7 @@ def main():
     torch.cuda.synchronize()
     comm0 = dict(KN.COMM_STATS)
     route0 = HO.split_route_stats()
+    _WD["phase"] = "timed"
     t0 = time.perf_counter()
     for i in range(args.steps):
         meters = step(args.warmup + i)
@@ -187,10 +227,11 @@ def main():
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt)
+    _WD["phase"] = "diagnostics"
     ms = dt / args.steps * 1e3
     imgs = world * 2 * args.batch
     value = imgs / (ms / 1e3)
-    comm = {k: (KN.COMM_STATS[k] - comm0[k]) / args.steps for k in comm0}
+    comm = {k: (KN.COMM_STATS.get(k, 0) - comm0.get(k, 0)) / args.steps for k in set(comm0) | set(KN.COMM_STATS)}
     route1 = HO.split_route_stats()
     from u2pl_amd import roofline as RL
 

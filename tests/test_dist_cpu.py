@@ -173,3 +173,36 @@ def test_use_process_group_routes_every_batchnorm():
     K.use_process_group(net, token)
     bns = [m for m in net.modules() if isinstance(m, K.BatchNorm2d)]
     assert len(bns) == 2 and all(m.group is token for m in bns)
+
+
+def _comm_sequence_case(rank, world):
+    """U2PL_COMM_DEBUG: identical sequences pass, a rank that issues its collectives in another order is caught with the
+    index of the first difference (on RCCL that order would deadlock or mix up the buffers)"""
+    from u2pl_amd import nn as K
+    K.COMM_DEBUG["on"] = True
+    K.COMM_DEBUG["log"].clear()
+    a, b = torch.ones(5, dtype=torch.float64), torch.ones(7)
+    # (1) same order on both ranks: SyncBN-style exchange, a bucket, a meter
+    K._all_reduce(a, "syncbn_allreduce")
+    K._all_reduce(b, "bucket_allreduce")
+    K._all_reduce(torch.ones(3), "meter_allreduce")
+    ok = K.check_comm_sequence()
+    # (2) rank 1 LOGS the bucket before the exchange (the collectives themselves are issued in a matching order here --
+    # gloo would hang otherwise -- only the bookkeeping is swapped, as if the hooks had fired in another order)
+    order = [("syncbn_allreduce", 5), ("bucket_allreduce", 7)] if rank == 0 else [("bucket_allreduce", 7), ("syncbn_allreduce", 5)]
+    for kind, n in order:
+        K.COMM_DEBUG["log"].append((kind, n, 0))
+    err = None
+    try:
+        K.check_comm_sequence()
+    except RuntimeError as e:
+        err = str(e)
+    K.COMM_DEBUG["on"] = False
+    return ok, err
+
+
+def test_comm_sequence_check_accepts_equal_and_reports_differing_orders():
+    r0, r1 = _run(_comm_sequence_case)
+    assert r0[0] and r1[0]
+    for r in (r0, r1):
+        assert r[1] is not None and "rank 1 differs from rank 0 at #0" in r[1] and "bucket_allreduce" in r[1]

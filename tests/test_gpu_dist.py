@@ -89,13 +89,18 @@ def _train_case(rank, world):
     tr = SemiTrainer(cfg, model, teacher, get_criterion(cfg), steps_per_epoch=4)
     g = torch.Generator().manual_seed(10 + rank)     # different data per rank, same weights/seeds
     meters = []
+    from u2pl_amd import nn as K
+    K.COMM_DEBUG["on"] = True       # every step ends with the cross-rank comparison of the collective sequences (raises on a mismatch)
+    issued0 = K.COMM_DEBUG["issued"]
     for step in range(3):
         il, iu = torch.randn(2, 3, 97, 97, generator=g), torch.randn(2, 3, 97, 97, generator=g)
         ll = torch.randint(0, 19, (2, 97, 97), generator=g)
         ll[:, :6] = 255
         meters.append(tr.train_step(il.to(dev), ll.to(dev), iu.to(dev), epoch=0).cpu().numpy())
     torch.cuda.synchronize()
-    return dict(meters=np.stack(meters), w=tr.arena.flat.double().sum().item(), w2=(tr.arena.flat.double() ** 2).sum().item(),
+    K.COMM_DEBUG["on"] = False
+    return dict(collectives=K.COMM_DEBUG["issued"] - issued0,
+                meters=np.stack(meters), w=tr.arena.flat.double().sum().item(), w2=(tr.arena.flat.double() ** 2).sum().item(),
                 t=tr.t_arena.flat.double().sum().item(), bank_len=list(tr.memobank.length),
                 bank_sum=[float(tr.memobank.logical(c).double().sum()) for c in range(19)],
                 rm=float(model.encoder.bn1.running_mean.double().sum()))
@@ -108,6 +113,8 @@ def test_two_rank_training_keeps_replicas_and_banks_identical():
     assert r0["w"] == r1["w"] and r0["w2"] == r1["w2"] and r0["t"] == r1["t"]   # weights stay replicated bit-for-bit
     assert r0["bank_len"] == r1["bank_len"] and r0["bank_sum"] == r1["bank_sum"] and sum(r0["bank_len"]) > 0
     assert r0["rm"] == r1["rm"]                                  # SyncBN running stats identical
+    # one communicator by default: both ranks issued the same number of collectives (their ORDER was compared inside every step)
+    assert r0["collectives"] == r1["collectives"] > 0
 
 
 def _pack_case(rank, world):

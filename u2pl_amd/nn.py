@@ -24,6 +24,75 @@ from ._lib import HipError, call, query
 _CL = torch.channels_last
 # collectives issued by this process since the last reset (bench.py reports them per step)
 COMM_STATS = {"syncbn_allreduce": 0, "bucket_allreduce": 0}
+# U2PL_COMM_DEBUG=1: every collective this process issues is logged as (kind, elements, group id) in issue order; a rank
+# whose sequence differs from rank 0's would deadlock or corrupt an RCCL communicator (collectives of one communicator must
+# be issued in the same order everywhere), so check_comm_sequence() compares the ranks' logs once per step and raises with the
+# first differing entry instead.
+COMM_DEBUG = {"on": os.environ.get("U2PL_COMM_DEBUG", "0") not in ("", "0"), "log": [], "issued": 0}
+
+
+def _all_reduce(t, kind, group=None, async_op=False, op=None):
+    """the ONE place this package issues a collective from"""
+    COMM_STATS[kind] = COMM_STATS.get(kind, 0) + 1
+    COMM_DEBUG["issued"] += 1
+    if COMM_DEBUG["on"]:
+        COMM_DEBUG["log"].append((kind, int(t.numel()), 0 if group is None else id(group) & 0xffff))
+    kw = {} if op is None else {"op": op}
+    return dist.all_reduce(t, group=group, async_op=async_op, **kw)
+
+
+def note_collective(kind, numel):
+    """bookkeeping for a collective issued elsewhere in the package (the memory bank's key all-gathers)"""
+    COMM_STATS[kind] = COMM_STATS.get(kind, 0) + 1
+    COMM_DEBUG["issued"] += 1
+    if COMM_DEBUG["on"]:
+        COMM_DEBUG["log"].append((kind, int(numel), 0))
+
+
+def comm_sequence_digest():
+    """order-sensitive 62-bit hash of (kind, elements) of the logged collectives (the group id is process-local: left out)"""
+    h = 1469598103934665603
+    for kind, n, _ in COMM_DEBUG["log"]:
+        for b in (kind + ":" + str(n)).encode():
+            h = ((h ^ b) * 1099511628211) & ((1 << 62) - 1)
+    return h
+
+
+def check_comm_sequence(clear=True):
+    """(debug mode) all ranks must have issued the same sequence of collectives since the last check"""
+    if not (COMM_DEBUG["on"] and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        if clear:
+            COMM_DEBUG["log"].clear()
+        return True
+    log = list(COMM_DEBUG["log"])
+    if clear:
+        COMM_DEBUG["log"].clear()
+    mine = torch.tensor([comm_sequence_digest() if not clear else _digest_of(log), len(log)], dtype=torch.int64)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    mine = mine.to(dev)
+    allv = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(allv, mine)
+    vals = [tuple(int(v) for v in a.cpu()) for a in allv]
+    if any(v != vals[0] for v in vals):
+        logs = [None] * dist.get_world_size()
+        dist.all_gather_object(logs, [(k, n) for k, n, _ in log])
+        ref = logs[0]
+        for r, lg in enumerate(logs):
+            for i in range(max(len(ref), len(lg))):
+                a = ref[i] if i < len(ref) else None
+                b = lg[i] if i < len(lg) else None
+                if a != b:
+                    raise RuntimeError(f"collective sequence of rank {r} differs from rank 0 at #{i}: {b} vs {a} "
+                                       f"({len(lg)} vs {len(ref)} collectives this step)")
+    return True
+
+
+def _digest_of(log):
+    h = 1469598103934665603
+    for kind, n, _ in log:
+        for b in (kind + ":" + str(n)).encode():
+            h = ((h ^ b) * 1099511628211) & ((1 << 62) - 1)
+    return h
 
 
 # ------------------------------------------------------------------ layout helpers
@@ -466,8 +535,7 @@ class _BNFn(torch.autograd.Function):
             count = float(M)
             if sync:
                 sums[2 * C] = float(M)
-                dist.all_reduce(sums, group=mod.group)
-                COMM_STATS["syncbn_allreduce"] += 1
+                _all_reduce(sums, "syncbn_allreduce", group=mod.group)
                 count = float(M * _world())  # equal per-rank shapes (drop_last loaders)
             mean = torch.empty(C, dtype=torch.float32, device=dev)
             invstd = torch.empty(C, dtype=torch.float32, device=dev)
@@ -509,8 +577,7 @@ class _BNFn(torch.autograd.Function):
                 call("u2pl_sums_to_f32", sums[C:], C, 1.0, 0, dgamma)
                 call("u2pl_sums_to_f32", sums, C, 1.0, 0, dbeta)
         if sync and training:
-            dist.all_reduce(sums, group=ctx.group)
-            COMM_STATS["syncbn_allreduce"] += 1
+            _all_reduce(sums, "syncbn_allreduce", group=ctx.group)
         dx = new_act(N, C, H, W, dev) if ctx.needs_input_grad[0] else None
         dres = new_act(N, C, H, W, dev) if has_res and ctx.needs_input_grad[3] else None
         if dx is not None:
@@ -582,8 +649,7 @@ class _BNGroupFn(torch.autograd.Function):
         for (x, ldx, N, C, H, W, gamma, beta, drop, pre), (mod, relu, gs, bs) in zip(units, meta):
             _bn_local_sums(x, ldx, N * H * W, C, mod, pre, packed[off:off + 2 * C + 1])
             off += 2 * C + 1
-        dist.all_reduce(packed, group=group)
-        COMM_STATS["syncbn_allreduce"] += 1
+        _all_reduce(packed, "syncbn_allreduce", group=group)
         outs, saved, ctx.meta, off = [], [], [], 0
         W_ = _world()
         for (x, ldx, N, C, H, W, gamma, beta, drop, pre), (mod, relu, gs, bs) in zip(units, meta):
@@ -618,8 +684,7 @@ class _BNGroupFn(torch.autograd.Function):
             call("u2pl_bn_bwd_sums_f32", gy, ldg, x, ldx, y, C, mean, invstd, drop, H * W, M, C, wsb, sums)
             dg, db = _param_grads(sums, C, gs, bs, ctx.needs_input_grad[1 + 5 * i + 1], dev)
             work.append((gy, ldg, x, ldx, y, mean, invstd, gamma, drop, N, C, H, W, count, sums, dg, db))
-        dist.all_reduce(packed, group=ctx.group)
-        COMM_STATS["syncbn_allreduce"] += 1
+        _all_reduce(packed, "syncbn_allreduce", group=ctx.group)
         grads = [None]
         for i, (gy, ldg, x, ldx, y, mean, invstd, gamma, drop, N, C, H, W, count, sums, dg, db) in enumerate(work):
             dx = None
@@ -647,8 +712,7 @@ class _BNResPairFn(torch.autograd.Function):
         packed = torch.empty(2 * (2 * C + 1), dtype=torch.float64, device=dev)
         _bn_local_sums(xa, lda, M, C, mod_a, pre_a, packed[:2 * C + 1])
         _bn_local_sums(xb, ldb, M, C, mod_b, pre_b, packed[2 * C + 1:])
-        dist.all_reduce(packed, group=mod_a.group)
-        COMM_STATS["syncbn_allreduce"] += 1
+        _all_reduce(packed, "syncbn_allreduce", group=mod_a.group)
         count = float(M * _world())
         mean_a, inv_a = _bn_finalize(packed[:2 * C + 1], count, mod_a, C, dev)
         mean_b, inv_b = _bn_finalize(packed[2 * C + 1:], count, mod_b, C, dev)
@@ -674,8 +738,7 @@ class _BNResPairFn(torch.autograd.Function):
         call("u2pl_bn_bwd_sums_f32", gy, ldg, xb, ldb, y, C, mean_b, inv_b, None, H * W, M, C, wsb2, sb)
         dga, dba = _param_grads(sa, C, gsa, bsa, ctx.needs_input_grad[1], dev)
         dgb, dbb = _param_grads(sb, C, gsb, bsb, ctx.needs_input_grad[5], dev)
-        dist.all_reduce(packed, group=group)
-        COMM_STATS["syncbn_allreduce"] += 1
+        _all_reduce(packed, "syncbn_allreduce", group=group)
         dxa = dxb = None
         if ctx.needs_input_grad[0]:
             dxa = new_act(N, C, H, W, dev)
@@ -1110,9 +1173,8 @@ class ParamArena:
             for st in self._producer_streams():
                 if st != cur:
                     cur.wait_stream(st)
-        self._works[b] = dist.all_reduce(self.grad[lo:hi], async_op=True)
+        self._works[b] = _all_reduce(self.grad[lo:hi], "bucket_allreduce", async_op=True)
         _lib.SIDE_WORK.add("buckets")
-        COMM_STATS["bucket_allreduce"] += 1
 
     def mark_ready(self, pidx):
         if _world() <= 1 or not self.buckets or os.environ.get("U2PL_NO_BUCKET_OVERLAP") is not None:
@@ -1131,7 +1193,7 @@ class ParamArena:
         if _world() <= 1:
             return
         if not self.buckets:
-            dist.all_reduce(self.grad)
+            _all_reduce(self.grad, "bucket_allreduce")
             return
         while self._next >= 0:      # same descending order as the hooks
             self._launch(self._next)

@@ -119,9 +119,12 @@ class SemiTrainer:
         for p in model_teacher.parameters():
             p.requires_grad = False
         if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-                and os.environ.get("U2PL_TEACHER_COMM", "1") != "0"):
-            # the teacher's train-mode forward runs on the side HIP stream next to the student's forward: its ~105 SyncBN
-            # all-reduces get their own communicator (every rank builds the trainer, so new_group is collective-safe)
+                and os.environ.get("U2PL_TEACHER_COMM", "0") == "1"):
+            # OPT-IN (U2PL_TEACHER_COMM=1): the teacher's train-mode forward runs on the side HIP stream next to the student's
+            # forward; its ~105 SyncBN all-reduces then get their own communicator so that they do not queue in front of the
+            # student's.  Two communicators driven concurrently from one process are a documented NCCL / RCCL deadlock hazard
+            # and this build has never run on RCCL: the DEFAULT is one communicator -- every collective of the step in one
+            # host-issued order, identical on all ranks (U2PL_COMM_DEBUG=1 checks it), which cannot deadlock.
             K.use_process_group(model_teacher, dist.new_group())
         C = cfg["net"]["num_classes"]
         self.num_classes = C
@@ -357,9 +360,10 @@ class SemiTrainer:
         meters = torch.stack((sup_loss.detach(), unsup_loss.detach(), contra_loss.detach()))
         if _world() > 1:
             cv = contra_loss.detach().clone()
-            dist.all_reduce(cv)        # contra value = cross-rank mean (train_semi.py:514-519)
+            K._all_reduce(cv, "loss_allreduce")        # contra value = cross-rank mean (train_semi.py:514-519)
             meters[2] = cv
-            dist.all_reduce(meters)    # logged meters are cross-rank SUMS (train_semi.py:551-561)
+            K._all_reduce(meters, "meter_allreduce")    # logged meters are cross-rank SUMS (train_semi.py:551-561)
+            K.check_comm_sequence()     # (U2PL_COMM_DEBUG=1: every rank issued the same collectives in the same order)
         return meters
 
 
@@ -408,5 +412,6 @@ class SupTrainer:
         z = torch.zeros((), device=loss.device)
         meters = torch.stack((loss.detach(), z, z))
         if W > 1:
-            dist.all_reduce(meters)
+            K._all_reduce(meters, "meter_allreduce")
+            K.check_comm_sequence()
         return meters

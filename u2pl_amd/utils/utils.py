@@ -16,6 +16,11 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _note(kind, numel):
+    from .. import nn as K      # (collective bookkeeping / U2PL_COMM_DEBUG sequence log)
+    K.note_collective(kind, numel)
+
+
 def gather_keys(keys):
     """Rank-major concatenation of variable-length key blocks (utils.py:16-24,31-32)
     as ONE padded device all-gather instead of barrier + pickled all_gather_object."""
@@ -24,6 +29,7 @@ def gather_keys(keys):
         return keys
     n = H.h2d(torch.tensor([keys.shape[0]], dtype=torch.int64), keys.device)
     ns = [torch.zeros_like(n) for _ in range(W)]
+    _note("key_allgather", 1)
     dist.all_gather(ns, n)
     ns = [int(x) for x in torch.cat(ns).cpu()]
     m = max(ns)
@@ -32,6 +38,7 @@ def gather_keys(keys):
     pad = torch.zeros((m, keys.shape[1]), dtype=keys.dtype, device=keys.device)
     pad[: keys.shape[0]] = keys
     outs = [torch.empty_like(pad) for _ in range(W)]
+    _note("key_allgather", pad.numel())
     dist.all_gather(outs, pad)
     return torch.cat([o[:k] for o, k in zip(outs, ns)])
 
@@ -43,6 +50,7 @@ def exchange_counts(counts_dev, C):
     if W == 1:
         return counts_dev.cpu().numpy(), None
     outs = [torch.empty_like(counts_dev) for _ in range(W)]
+    _note("key_allgather", counts_dev.numel())
     dist.all_gather(outs, counts_dev)
     host = torch.stack(outs).cpu().numpy()                   # [W][3][32]: the one sync
     return host[dist.get_rank()], host[:, 2, :C].astype(np.int64)
@@ -65,6 +73,7 @@ def enqueue_all_classes(bank, rows, ld, idx, counts_c, C, all_counts=None):
     else:
         cnt = H.h2d(torch.tensor(n_loc, dtype=torch.int64), dev)
         cnts = [torch.zeros_like(cnt) for _ in range(W)]
+        _note("key_allgather", cnt.numel())
         dist.all_gather(cnts, cnt)
         cnts = torch.stack(cnts).cpu().numpy()             # [W][C]
     m = int(cnts.sum(1).max())
@@ -78,6 +87,7 @@ def enqueue_all_classes(bank, rows, ld, idx, counts_c, C, all_counts=None):
             call("u2pl_gather_rows_f32", rows, ld, D, idx[c], n_loc[c], pad[off:])
             off += n_loc[c]
     outs = [torch.empty_like(pad) for _ in range(W)]
+    _note("key_allgather", pad.numel())
     dist.all_gather(outs, pad)
     offs = np.concatenate([np.zeros((W, 1), np.int64), np.cumsum(cnts, 1)[:, :-1]], 1)
     entries = []

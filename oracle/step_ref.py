@@ -33,16 +33,20 @@ class CpuStepRef:
     def __init__(self, arch="resnet101", num_classes=19, aux=True, epochs=200, steps_per_epoch=163, lr=0.01,
                  momentum=0.9, weight_decay=0.0005, ema_decay=0.99, sup_only_epoch=0, drop_percent=80,
                  ohem=(0.7, 100000), contra=CONTRA, p_drop=0.0, lr_times=1, queue=(50000, 30000), state_dict=None,
-                 apply_aug="cutmix", dropout_masks=None):
-        self.student = RefNet(arch, num_classes, aux, p_drop)
-        self.teacher = RefNet(arch, num_classes, aux, p_drop)
+                 apply_aug="cutmix", dropout_masks=None, dtype=torch.float32):
+        # dtype=torch.float64: the ARBITER of the multi-step parity tests -- the same step evaluated in double precision
+        # (network, losses, thresholds, bank), against which both the fp32 port and the HIP path are measured
+        self.dtype = dtype
+        self.np_dtype = np.float64 if dtype == torch.float64 else np.float32
+        self.student = RefNet(arch, num_classes, aux, p_drop).to(dtype)
+        self.teacher = RefNet(arch, num_classes, aux, p_drop).to(dtype)
         # parity mode with dropout ON: both sides take their keep-masks from oracle/parity_dropout.KeyedMasks
         self.dropout_masks = dropout_masks
         if dropout_masks is not None:
             tag_model(self.student, "student")
             tag_model(self.teacher, "teacher")
         if state_dict is not None:
-            self.student.load_state_dict(state_dict)
+            self.student.load_state_dict(state_dict)      # (copy_ converts fp32 checkpoints to the arbiter's dtype)
             self.teacher.load_state_dict(state_dict)
         for p in self.teacher.parameters():
             p.requires_grad = False
@@ -55,7 +59,7 @@ class CpuStepRef:
         self.C, self.aux = num_classes, aux
         self.epochs, self.spe, self.ema_decay, self.sup_only_epoch = epochs, steps_per_epoch, ema_decay, sup_only_epoch
         self.drop_percent, self.ohem, self.contra, self.apply_aug = drop_percent, ohem, contra, apply_aug   # ohem=None: plain CE
-        self.bank = [[np.zeros((0, 256), np.float32)] for _ in range(num_classes)]
+        self.bank = [[np.zeros((0, 256), self.np_dtype)] for _ in range(num_classes)]
         self.ptr = [[0] for _ in range(num_classes)]
         self.qsize = [queue[0]] + [queue[1]] * (num_classes - 1)
         self.cur_iter = 0
@@ -89,7 +93,7 @@ class CpuStepRef:
         info = dict(new_keys=new_keys, valid=valid, njobs=0)
         if len(valid) <= 1:
             return 0 * rep.sum(), info
-        loss = torch.tensor(0.0)
+        loss = torch.tensor(0.0, dtype=self.dtype)
         Q, K = cfg["num_queries"], cfg["num_negatives"]
         for i in range(len(valid)):  # Q1 index mismatch reproduced
             cand, bank = ph1[i]["anchor_idx"], self.bank[valid[i]][0]
@@ -100,7 +104,7 @@ class CpuStepRef:
             anchor = rows[torch.from_numpy(cand[ia])]
             inn = randint(bank.shape[0], Q * K)
             neg = torch.from_numpy(bank[inn]).reshape(Q, K, D)
-            pos = torch.from_numpy(ph1[i]["proto"].astype(np.float32)).reshape(1, 1, D).repeat(Q, 1, 1)
+            pos = torch.from_numpy(ph1[i]["proto"].astype(self.np_dtype)).reshape(1, 1, D).repeat(Q, 1, 1)
             logits = torch.cosine_similarity(anchor.unsqueeze(1), torch.cat((pos, neg), 1), dim=2)
             loss = loss + F.cross_entropy(logits / cfg["temperature"], torch.zeros(Q).long())
             info["njobs"] += 1
@@ -118,6 +122,7 @@ class CpuStepRef:
             def randint(high, n):
                 return torch.randint(high, size=(n,)).numpy()
         B, h, w = label_l.shape
+        image_l, image_u = image_l.to(self.dtype), image_u.to(self.dtype)
         max_iter = self.epochs * self.spe
         for g, b in zip(self.opt.param_groups, self.base_lr):
             g["lr"] = R.poly_lr(b, self.cur_iter, max_iter)

@@ -169,6 +169,75 @@ def test_split_fp32_products_are_as_accurate_as_the_fp32_matrix_instruction(C, O
         assert errs[1][n] < 1e-5, (n, errs)
 
 
+@pytest.mark.parametrize("kind", ["relu_heavy_tail", "mixed_magnitudes", "cancellation"])
+@pytest.mark.parametrize("C,O,k,d,H,W", [(256, 256, 1, 1, 33, 29), (128, 128, 3, 1, 25, 25), (1024, 256, 1, 1, 21, 21)])
+def test_split_fp32_products_on_adversarial_operands(kind, C, O, k, d, H, W):
+    """The split arithmetic away from N(0,1) data, forward / data gradient / weight gradient against
+    float64, measured like fp32 arithmetic should be -- against the CONDITION of the sums, sum |a||b| -- and compared with the
+    fp32 matrix instruction on the same kernels:
+      relu_heavy_tail   post-ReLU activations: 60 % exact zeros, the rest |N(0,1)|^3 (a few values carry the sums)
+      mixed_magnitudes  input channels scaled 10^U(-6, 6), the weights of a channel by the inverse: every product is O(1)
+                        but each operand spans 12 decades inside one reduction (pieces of very different exponents)
+      cancellation      weights +w, -w on neighbouring input channels with nearly equal activations: the sums are ~1e-4 of
+                        their terms (the Winograd-domain weight gradient's regime)
+    Dropped piece products are <= 2^-23 |ab| each, so the error bound is a small multiple of eps32 * sum |a||b| -- the bound of
+    an fp32 dot product."""
+    from u2pl_amd import _lib
+    Kn = K()
+    L = _lib.lib().cdll
+    g = torch.Generator().manual_seed(len(kind) * 1000 + C + O + k)
+    N = 2
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(O, C, k, k, generator=g) / (k * k * C) ** 0.5
+    gy = torch.randn(N, O, H, W, generator=g)
+    if kind == "relu_heavy_tail":
+        x = torch.relu(x - 0.25) ** 3
+        gy = gy * (torch.rand(gy.shape, generator=g) < 0.3)
+    elif kind == "mixed_magnitudes":
+        sc = 10.0 ** (torch.rand(C, generator=g) * 12 - 6)
+        x = x * sc.view(1, C, 1, 1)
+        w = w / sc.view(1, C, 1, 1)
+    else:
+        base = torch.randn(N, C // 2, H, W, generator=g)
+        x = torch.stack((base, base * (1 + 1e-4 * torch.randn(base.shape, generator=g))), 2).reshape(N, C, H, W)
+        wh = torch.randn(O, C // 2, k, k, generator=g) / (k * k * C) ** 0.5
+        w = torch.stack((wh, -wh), 2).reshape(O, C, k, k)
+    pad = d * (k // 2)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, padding=pad, dilation=d)
+    yd.backward(gy.double())
+    ref = dict(y=yd.detach(), dx=xd.grad, dw=wd.grad)
+    # condition of each sum: the same convolutions on absolute values
+    xa, wa = x.double().abs().requires_grad_(True), w.double().abs().requires_grad_(True)
+    ya = F.conv2d(xa, wa, padding=pad, dilation=d)
+    ya.backward(gy.double().abs())
+    cond = dict(y=ya.detach(), dx=xa.grad, dw=wa.grad)
+    saved, old = dict(Kn.CONV_ALGO), L.u2pl_conv_get_split()
+    errs = {}
+    try:
+        Kn.CONV_ALGO.update(wino=0)
+        for mode in (0, 1):
+            L.u2pl_conv_set_split(mode)
+            conv = Kn.Conv2d(C, O, k, padding=pad, dilation=d, bias=False).to(DEV)
+            with torch.no_grad():
+                conv.weight.copy_(w.to(DEV))
+            xg = x.to(DEV).contiguous(memory_format=CL).requires_grad_(True)
+            y = conv(xg)
+            y.backward(gy.to(DEV).contiguous(memory_format=CL))
+            got = dict(y=y.detach(), dx=xg.grad, dw=conv.weight.grad)
+            assert all(torch.isfinite(v).all() for v in got.values())
+            # error in units of eps32 * sum |a||b| (the size of ONE fp32 rounding of the largest partial sum)
+            errs[mode] = {n: ((got[n].cpu().double() - ref[n]).abs() / (cond[n] * 2.0 ** -24 + 1e-300)).max().item() for n in ref}
+    finally:
+        L.u2pl_conv_set_split(old)
+        Kn.CONV_ALGO.update(saved)
+    print(kind, "max error in eps32 * sum|a||b| (0: fp32 MFMA, 1: split):", errs)
+    for n in ("y", "dx", "dw"):
+        # an fp32 dot product of length K is good to ~sqrt(K) .. K roundings; both arithmetics measured 1 .. 30 here
+        assert errs[1][n] <= 1.5 * errs[0][n] + 4.0, (kind, n, errs)
+        assert errs[1][n] < 64.0, (kind, n, errs)
+
+
 def test_conv_large_pixel_count_splitk():
     """many pixels (split-K wgrad with several slabs) and M not a multiple of the tile"""
     Kn = K()

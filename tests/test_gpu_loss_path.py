@@ -682,6 +682,60 @@ def test_fused_split_single_barrier_gather_is_exact_on_a_reused_workspace():
             _self_consistent(keep, lu, pcts, (s, s))
 
 
+def test_fused_split_coherence_stress_alternating_inputs_with_a_busy_second_stream():
+    """the one-barrier split hands its cross-block data (sorted runs, bin prefixes, totals) from block to
+    block with write-through stores / L1-bypassing loads and NO agent-scope fence pair -- outside the HIP memory model, so
+    the evidence has to be empirical and large: 1500 launches on ONE reused workspace, the input switching between four
+    tensors in an irregular pattern (a stale line anywhere returns the PREVIOUS launch's statistics), while a second stream
+    keeps the memory system and the L2s busy with unrelated traffic; every launch's thresholds, kept-pixel count and masks
+    must be the bits of the five-launch path for THAT input.  (U2PL_RF_FENCES=1 restores the fences.)"""
+    H = hip()
+    B, C, S = 2, 19, 769
+    s = (S - 1) // 4 + 1
+    g = torch.Generator(device=DEV).manual_seed(5)
+    lows = [(torch.randn(B, C, s, s, device=DEV, generator=g) * sc).contiguous(memory_format=torch.channels_last)
+            for sc in (3.0, 5.0, 1.5, 4.0)]
+    lab_u = torch.randint(0, C, (B, S, S), device=DEV, generator=g)
+    lab_l = torch.randint(0, C, (B, S, S), device=DEV, generator=g)
+    lab_l[:, :8] = 255
+    pcts = [80.0, 20.0, 80.0]
+    want, first = [], []
+    for low in lows:       # reference: the five-launch path, and the fused kernel's own first (quiescent) result for this input
+        u = H.reliability_split(low, (S, S), lab_l, lab_u, (s, s), pcts, fused=False)
+        want.append({kk: (v.clone() if torch.is_tensor(v) else v) for kk, v in u.items()})
+        torch.cuda.synchronize()
+        f = H.reliability_split(low, (S, S), lab_l, lab_u, (s, s), pcts, fused=True)
+        keep = {kk: (v.clone() if torch.is_tensor(v) else v) for kk, v in f.items()}
+        torch.cuda.synchronize()
+        assert int(keep["err"]) == 0
+        _split_equal(keep, want[-1], len(pcts))
+        first.append(keep)
+    side = torch.cuda.Stream()
+    big = torch.randn(64 << 20, device=DEV)          # 256 MB: sweeps every L2 and the Infinity Cache
+    junk = torch.empty_like(big)
+    rng = np.random.RandomState(3)
+    ks, thrs, nks, lows_m = [], [], [], []
+    for it in range(1500):
+        k = int(rng.randint(0, 4))
+        if it % 8 == 0:
+            with torch.cuda.stream(side):
+                junk.copy_(big)
+                big.mul_(1.0000001)
+        f = H.reliability_split(lows[k], (S, S), lab_l, lab_u, (s, s), pcts, fused=True)
+        ks.append(k)
+        thrs.append(f["thr"].clone())               # (views of the reused workspace: copy in stream order)
+        nks.append(f["nkept"].clone())
+        lows_m.append(f["low_mask"].sum(dtype=torch.float64).reshape(1))
+    torch.cuda.synchronize()
+    thrs, nks, lows_m = torch.stack(thrs).cpu(), torch.cat(nks).cpu(), torch.cat(lows_m).cpu()
+    bad = 0
+    for it, k in enumerate(ks):
+        ok = (torch.equal(thrs[it], first[k]["thr"].cpu()) and int(nks[it]) == int(first[k]["nkept"])
+              and float(lows_m[it]) == float(first[k]["low_mask"].sum(dtype=torch.float64)))
+        bad += int(not ok)
+    assert bad == 0, f"{bad} of 1500 launches returned statistics that are not their input's (stale cross-block data)"
+
+
 # ------------------------------------------------------------------ row-sparse ordered InfoNCE gradient
 @pytest.mark.parametrize("n_cand", [3000, 40, 2])
 def test_infonce_gradient_scatter_is_row_sparse_ordered_and_reproducible(n_cand):

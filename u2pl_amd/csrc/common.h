@@ -16,10 +16,13 @@
 // every kernel launch of the library goes through this macro: u2pl_kernel_launches() lets the bench report kernel
 // launches per step next to the C-ABI calls per step (an entry point may issue several launches: tile planner bodies
 // and tails, split-K reduces, Winograd component batches)
-extern unsigned long long u2pl_kernel_launch_count;
+// (entry points are called concurrently from the main thread and autograd's backward thread -- ctypes releases the GIL --: the
+// counter is a relaxed atomic)
+#include <atomic>
+extern std::atomic<unsigned long long> u2pl_kernel_launch_count;
 #define U2PL_LAUNCH(...)                        \
     do {                                        \
-        ++u2pl_kernel_launch_count;             \
+        u2pl_kernel_launch_count.fetch_add(1, std::memory_order_relaxed);             \
         hipLaunchKernelGGL(__VA_ARGS__);        \
     } while (0)
 

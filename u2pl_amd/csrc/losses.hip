@@ -5,8 +5,8 @@
 #include "common.h"
 #include "u2pl_hip.h"
 
-unsigned long long u2pl_kernel_launch_count = 0;
-U2PL_API size_t u2pl_kernel_launches(void) { return (size_t)u2pl_kernel_launch_count; }
+std::atomic<unsigned long long> u2pl_kernel_launch_count{0};
+U2PL_API size_t u2pl_kernel_launches(void) { return (size_t)u2pl_kernel_launch_count.load(std::memory_order_relaxed); }
 
 // per-pixel log-softmax pick; block partial sums in double -> partial[2*blk+{0,1}]
 __global__ void k_ce_fwd(const float* __restrict__ z, const long long* __restrict__ target, int ignore, int N,

@@ -231,8 +231,11 @@ def reliability_split(logits_low, size, label_l, label_u_aug, out_hw, percents, 
     _chk_cuda(logits_low, label_l, label_u_aug)
     if _lib.SIDE_WORK:
         # the device-wide barrier needs all G blocks resident: every side stream of this process must have been joined
-        # (stream order then guarantees that none of its kernels can still occupy a CU when this one starts)
-        raise _lib.HipError("u2pl_reliability_fused launched with un-joined side-stream work: %s" % sorted(_lib.SIDE_WORK))
+        # (stream order then guarantees that none of its kernels can still occupy a CU when this one starts).  A ledger entry
+        # that is still here (e.g. left behind by an exception the caller caught between add and discard) is not fatal: the
+        # five-launch path has no such requirement and gives the same thresholds / masks
+        return reliability_split(logits_low, size, label_l, label_u_aug, out_hw, percents,
+                                 negative_high_entropy=negative_high_entropy, ignore=ignore, fused=False)
     q32 = np.array([percentile_q32(p) for p in percents], dtype=np.float32)
     ent = torch.empty((B, H, W), dtype=torch.float32, device=dev)
     target = torch.empty((B, H, W), dtype=torch.int64, device=dev)

@@ -155,23 +155,26 @@ def _assert_step(r, first):
     evaluation of the same step by a comparable number of pixels (oracle/mask_noise_floor.py ->
     profiles/r02_mask_noise_floor_*.json); the Tier-A tests (tests/test_gpu_loss_path.py) hold every mask kernel to
     bit-exactness given identical inputs."""
-    tol = 1e-4 if first else 2e-3
-    # supervised / unsupervised losses never depend on the sampling: always within the north_star tolerance
+    # measured + margin (round 4, profiles/r04_full_size_parity.json): step 0 losses 9e-8 .. 1.6e-6, VOC step 1 5.4e-6 / 5.7e-6
+    # (the north_star tolerance is 1e-4; the float64 arbiter of tests/test_gpu_train_step.py shows what the later steps'
+    # deviations consist of)
+    tol = 1e-5 if first else 5e-5
+    # supervised / unsupervised losses never depend on the sampling
     for j in (0, 1):
         assert r["loss_err_vs_reference"][j] <= tol and r["loss_err_vs_port"][j] <= tol, r
     if "px" not in r:
         return
-    assert r["entropy_max_err_vs_port"] <= (3e-4 if first else 3e-3), r       # measured 4e-5 / 1e-4 (step 0), 4.5e-4 (VOC step 1)
+    assert r["entropy_max_err_vs_port"] <= (3e-4 if first else 1e-3), r       # measured 4e-5 / 9e-5 (step 0), 3.7e-4 / 4.3e-4 (VOC step 1)
     assert r["label_u_diff_vs_reference"] <= (0 if first else 4), r            # measured 0 / 0
-    assert r["target_u_diff_vs_reference"] <= (16 if first else 96), r         # measured 2 / 6 (step 0), 34 / 47 (VOC step 1)
-    mask_max = 4 if first else 8                                               # measured 0 (step 0), 1-4 (VOC step 1)
+    assert r["target_u_diff_vs_reference"] <= (16 if first else 64), r         # measured 2 / 4 (step 0), 32 / 36 (VOC step 1)
+    mask_max = 4 if first else 6                                               # measured 0 (step 0), 1-3 (VOC step 1)
     assert r["low_mask_diff_vs_reference"] <= mask_max and r["high_mask_diff_vs_reference"] <= mask_max, r
     assert r["lbits_diff_vs_reference"] <= 2, r                                # measured 0 everywhere
     same_counts = (r["low_mask_diff_vs_reference"] + r["high_mask_diff_vs_reference"] + r["lbits_diff_vs_reference"]) == 0
     # the contrastive loss samples anchors / negatives with torch.randint(n_candidates): one flipped mask pixel can
     # shift every later draw, so the 1e-4 bound applies when the masks agree; otherwise the two estimates of the
     # same expectation agree statistically
-    assert r["loss_err_vs_reference"][2] <= (tol if same_counts else 3e-2), r
+    assert r["loss_err_vs_reference"][2] <= ((1e-5 if first else 1e-4) if same_counts else 3e-2), r
 
 
 @pytest.mark.parametrize("wino", [0, 4], ids=["direct_conv", "winograd_default"])

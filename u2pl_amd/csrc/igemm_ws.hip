@@ -372,7 +372,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
         //   then RBU + RA slots                                             | loads B(kc+2), then A(kc+3), one per slot
         constexpr int F0_PRE = TM + TN, F0_PER = (NRD - F0_PRE + TAIL - 1) / TAIL;
         constexpr int F1_START = TAIL, SP_START = TAIL, BS_START = SP_START + 6 * RA, LD_START = BS_START + RBU;
-        static_assert(F1_START + NRD <= NMF && LD_START + RBU + RA <= NMF, "plan does not fit the chunk");
+        static_assert(F1_START + NRD <= TAIL + 6 * PER, "k block 1 operands would be read after their first use");
+        static_assert(LD_START + RBU + RA <= NMF, "plan does not fit the chunk");
         using CUR = std::integral_constant<int, cur>;
 #ifdef U2PL_WS_STAMPS
         unsigned long long ts[14];

@@ -192,8 +192,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_tr(const float* __restrict__ d
         constexpr int F0_PRE = 2 * (TM + TN), F0_PER = (NRD - F0_PRE + TAIL - 1) / TAIL;       // reads before slot 0; per tail slot
         constexpr int LD_SLOTS = (NLD + 1) / 2;                                               // two loads per slot
         constexpr int SPP = (NMF - TAIL - LD_SLOTS) / (2 * NLD) >= 3 ? 3 : 2;                  // slots per value pair (3 steps)
-        constexpr int F1_START = TAIL, SP_START = TAIL, SP_END = SP_START + SPP * 2 * NLD, LD_START = SP_END;
-        static_assert(F1_START + NRD <= NMF, "k block 1 operand reads do not fit");
+        constexpr int F1_START = TAIL, F1_PER = (NRD + 6 * PER - 1) / (6 * PER);               // all of them BEFORE k block 1's products
+        constexpr int SP_START = TAIL, SP_END = SP_START + SPP * 2 * NLD, LD_START = SP_END;
+        static_assert(F1_START + (NRD + F1_PER - 1) / F1_PER <= TAIL + 6 * PER, "k block 1 operands would be read after their first use");
         static_assert(LD_START + LD_SLOTS <= NMF, "split + loads do not fit the chunk");
         wt_static_for<0, F0_PRE>([&](auto j) __attribute__((always_inline)) { do_read(CUR{}, C0{}, j); });
         __builtin_amdgcn_sched_barrier(0);
@@ -202,7 +203,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_tr(const float* __restrict__ d
             do_mfma(std::integral_constant<int, (sl < TAIL ? NMF - TAIL + sl : sl - TAIL)>{});
             if constexpr (sl < TAIL)
                 wt_static_for<0, F0_PER>([&](auto u) __attribute__((always_inline)) { do_read(CUR{}, C0{}, std::integral_constant<int, F0_PRE + sl * F0_PER + decltype(u)::value>{}); });
-            if constexpr (sl >= F1_START) do_read(CUR{}, C1{}, std::integral_constant<int, sl - F1_START>{});
+            if constexpr (sl >= F1_START)
+                wt_static_for<0, F1_PER>([&](auto u) __attribute__((always_inline)) { do_read(CUR{}, C1{}, std::integral_constant<int, (sl - F1_START) * F1_PER + decltype(u)::value>{}); });
             if constexpr (sl >= SP_START && sl < SP_END) {
                 constexpr int k = (sl - SP_START) / SPP, s_in = (sl - SP_START) % SPP;     // value pair k (float4 k / 2), slot in pair
                 constexpr int st0 = SPP == 3 ? s_in : (s_in == 0 ? 0 : 2), st1 = SPP == 3 ? s_in : (s_in == 0 ? 1 : 2);
@@ -272,7 +274,12 @@ U2PL_API int u2pl_wgrad_set_tr(int on) { const int old = wgrad_tr_on(); g_wgrad_
 bool wgrad_tr_eligible(const ConvGeom& g) {
     return wgrad_tr_on() && g.Cout >= 128 && g.Cin >= 128 && !(g.Cout % 4) && !(g.Cin % 4);
 }
-static int wt_bn(const ConvGeom& g) { return g.Cin > 128 ? 256 : 128; }
+static int wt_bn(const ConvGeom& g) {
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("U2PL_WT_BN"); force = (e && *e) ? atoi(e) : 0; }
+    if (force == 128 || force == 256) return force;
+    return g.Cin > 128 ? 256 : 128;
+}
 // slabs: one block per CU and round; the plan minimises (rounds of 256 blocks) x (chunks per slab + fixed cost per block)
 void wgrad_tr_plan(const ConvGeom& g, int taps, int& ctiles, int& nsplit, int& cps) {
     const long M = (long)g.N * g.Hout * g.Wout;

@@ -661,7 +661,24 @@ static int run_igemm_ws(const float* x, long ldx, const void* ws, const float* b
 #undef WS_ABL
     }
 #endif
-    if (g.Cout > 128) { if (pw) WS_GO(2, 2, true); else WS_GO(2, 2, false); }
+    // 128 x 256 or 128 x 128 tiles?  One persistent block per CU: a launch costs (tiles of the busiest block) x (time per tile).
+    // Narrow tiles halve the work per tile at ~15 % more time per product (the activation split is amortised over half the
+    // matrix instructions) and fill the last round better: 295 row tiles x 256 columns take 2 rounds of wide tiles but only
+    // 3 rounds of half-size ones (measured 146 -> 125 us for the 1024 -> 256 1x1 convolution at 4 x 97^2; where the wide
+    // tiling divides well -- the 2048 -> 256 Winograd batch, 256 -> 1024 -- the wide tile stays).  Times in units of one
+    // 32-deep chunk of a wide tile; 4 / 2 = fixed cost per tile (prologue, epilogue), fitted to tools/bench_igemm_ws.py.
+    // U2PL_WS_NARROW = 0 (never) | 1 (always, where Cout <= 256) | unset (the model).
+    bool narrow_tiles = g.Cout <= 128;
+    if (g.Cout > 128) {
+        static int force = -2;
+        if (force == -2) { const char* e = getenv("U2PL_WS_NARROW"); force = (e && *e) ? atoi(e) : -1; }
+        const long M_ = (long)g.N * g.Hout * g.Wout;
+        const long mt = cdiv(M_, 128), nkc = (long)(g.R * g.S * g.Cin) / BK;
+        const long tw = mt * cdiv(g.Cout, 256) * batch, tn = mt * cdiv(g.Cout, 128) * batch;
+        const double cw = (double)cdiv(tw, WS_NUM_CUS) * (nkc + 4.0), cn = (double)cdiv(tn, WS_NUM_CUS) * (0.5 * 1.15 * nkc + 2.0);
+        narrow_tiles = force == 1 ? g.Cout <= 256 : force == 0 ? false : cn < 0.97 * cw;
+    }
+    if (!narrow_tiles) { if (pw) WS_GO(2, 2, true); else WS_GO(2, 2, false); }
     if (pw) WS_GO(2, 1, true); else WS_GO(2, 1, false);
 #undef WS_GO
 }

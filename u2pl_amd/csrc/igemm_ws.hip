@@ -468,67 +468,56 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
         unsigned long long te[5];
         te[0] = __builtin_readcyclecounter();
 #endif
-        static_for<0, TAIL>([&](auto sl) __attribute__((always_inline)) { do_mfma(std::integral_constant<int, NMF - TAIL + decltype(sl)::value>{}); });
-#ifdef U2PL_WS_STAMPS
-        te[1] = __builtin_readcyclecounter();
-#endif
         int mt, nt, z;
         tile_of(c_v, mt, nt, z);
-        const long m0 = (long)mt * BM;
         const int n0 = nt * BN;
-        ry = make_rsrc(y + (long)__builtin_amdgcn_readfirstlane(z) * zy, ybytes);
+        const long m0 = (long)mt * BM;
+        const int zs = __builtin_amdgcn_readfirstlane(z);
+        ry = make_rsrc(y + (long)zs * zy, ybytes);
         const bool bn_all = epi.mean != nullptr;
+        // Every memory READ of the epilogue comes before its first STORE: loads and stores retire through one in-order
+        // counter, so a load behind the tile's 64 stores -- a per-column parameter, a residual value, even the reload of a
+        // spilled address -- waits for 128 KB per CU to drain (measured: +10 us per tile for the statistics variant of the
+        // 256 -> 1024 convolution, whose row indices had been spilled; +170 us per launch for per-element residual loads).
+        // Per-column parameters through range-checked descriptors (a column past Cout reads 0).
+        const unsigned cbytes = (unsigned)g.Cout * 4u;
+        auto colparam = [&](const float* p, int col) __attribute__((always_inline)) {
+            return p ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(p, cbytes), col * 4, 0, 0)) : 0.f;
+        };
+        float bias_v[TN], mu[TN], is[TN], ga[TN], be[TN], pv[TN];
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int col = n0 + wn * 32 * TN + b * 32 + li;
-            const bool cv = col < g.Cout;
-            const float bias_v = (bias && cv) ? bias[col] : 0.f;
-            float mu = 0.f, is = 0.f, ga = 0.f, be = 0.f;
-            if (bn_all && cv) { mu = epi.mean[col]; is = epi.invstd[col]; ga = epi.gamma[col]; be = epi.beta[col]; }
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                const long mb = m0 + wm * 32 * TM + a * 32 + 4 * lh;              // row of element e = 0
-                // (mb * ldy fits 32 bits: the tensor's bytes < 2^31, host check)
-                const int vbase = cv ? ((int)mb * (int)ldy + col) * 4 : OOB_OFF;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    constexpr int dummy = 0;
-                    const int ro = (e & 3) + 8 * (e >> 2);
-                    float v = acc[a][b][e] + bias_v;
-                    if (bn_all) {       // eval-mode BatchNorm (+ residual, ReLU): the operations of k_bn_apply, in its order
-                        v = (v - mu) * is * ga + be;
-                        if (epi.res) {
-                            const long m = mb + ro;
-                            const float rv = (cv && m < M) ? epi.res[m * epi.ldr + col] : 0.f;
-                            v += rv;
-                        }
-                        if (epi.relu) v = fmaxf(v, 0.f);
-                    }
-                    (void)dummy;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, vbase + ro * ldyb, 0, 0);
-                }
-            }
+            bias_v[b] = colparam(bias, col);
+            mu[b] = is[b] = ga[b] = be[b] = pv[b] = 0.f;
+            if (bn_all) { mu[b] = colparam(epi.mean, col); is[b] = colparam(epi.invstd, col); ga[b] = colparam(epi.gamma, col); be[b] = colparam(epi.beta, col); }
+            if (stats) pv[b] = colparam(pivot, col);
         }
+        // (the parameter loads are in flight under the chunk's tail products)
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, TAIL>([&](auto sl) __attribute__((always_inline)) { do_mfma(std::integral_constant<int, NMF - TAIL + decltype(sl)::value>{}); });
 #ifdef U2PL_WS_STAMPS
-        te[2] = __builtin_readcyclecounter();
+        te[1] = te[2] = __builtin_readcyclecounter();
 #endif
-        // fused BatchNorm statistics: per 128-row tile pivot-shifted column sums [tile][2][Cout].  The additions are made in
-        // the order of k_conv_igemm<1, 2, 4, 3> (per 32-row wave block: 16 register values, the two lane halves, then the
-        // four 32-row blocks of the tile in ascending order) so the partial sums are the same bits.
+        __builtin_amdgcn_sched_barrier(0);
+        // fused BatchNorm statistics, BEFORE the stores (see above): per 128-row tile pivot-shifted column sums
+        // [tile][2][Cout].  The additions are made in the order of k_conv_igemm<1, 2, 4, 3> (per 32-row wave block: 16
+        // register values, the two lane halves, then the four 32-row blocks of the tile in ascending order) so the partial
+        // sums are the same bits.
         if (stats) {
             static_assert(BM == 128, "statistics blocks are 128 rows");
+            const long left = M - m0;                                                  // rows of this tile inside the matrix
+            const int lim = (int)(left < BM ? left : BM) - (wm * 32 * TM + 4 * lh);    // row a * 32 + ro of this lane counts iff < lim
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
-                const int cl = wn * 32 * TN + b * 32 + li, co = n0 + cl;
-                const bool cv = co < g.Cout;
-                const float sh = (cv ? (bias ? bias[co] : 0.f) : 0.f) - (cv && pivot ? pivot[co] : 0.f);
+                const int cl = wn * 32 * TN + b * 32 + li;
+                const float sh = bias_v[b] - pv[b];
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const long m = m0 + wm * 32 * TM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                        const float v = m < M ? acc[a][b][e] + sh : 0.f;
+                        const float v = (a * 32 + (e & 3) + 8 * (e >> 2)) < lim ? acc[a][b][e] + sh : 0.f;
                         s1 += v;
                         s2 += v * v;
                     }
@@ -553,6 +542,57 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
                 }
             }
             // (the next write of `red` is a whole tile -- at least one chunk barrier -- away)
+        }
+        // bias / eval-mode BatchNorm (+ residual, ReLU) in place: the operations of k_bn_apply, in its order.  Element (row m,
+        // column c) lies at (m * ld + c) * 4 in its matrix's descriptor; a row past M lies past the descriptor's extent
+        // (ld >= Cout) and a column past Cout is given OOB_OFF: the hardware drops / zero-fills both, no compares.
+        const int mrow = (int)m0 + wm * 32 * TM + 4 * lh;          // row of (a = 0, e = 0); (m * ld fits 32 bits: host check)
+        if (bn_all) {
+            const int ldrb = (int)epi.ldr * 4;
+            const __amdgpu_buffer_rsrc_t rr = make_rsrc(epi.res, resbytes);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int col = n0 + wn * 32 * TN + b * 32 + li;
+                float rv[TM][16];
+                if (epi.res) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        const int rbase = col < g.Cout ? ((mrow + a * 32) * (int)epi.ldr + col) * 4 : OOB_OFF;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            rv[a][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, rbase + ((e & 3) + 8 * (e >> 2)) * ldrb, 0, 0));
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float v = acc[a][b][e] + bias_v[b];
+                        v = (v - mu[b]) * is[b] * ga[b] + be[b];
+                        if (epi.res) v += rv[a][e];
+                        if (epi.relu) v = fmaxf(v, 0.f);
+                        acc[a][b][e] = v;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[a][b][e] = acc[a][b][e] + bias_v[b];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // (no store may move in front of a load)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = n0 + wn * 32 * TN + b * 32 + li;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int vbase = col < g.Cout ? ((mrow + a * 32) * (int)ldy + col) * 4 : OOB_OFF;
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[a][b][e]), ry, vbase + ((e & 3) + 8 * (e >> 2)) * ldyb, 0, 0);
+            }
         }
 #pragma unroll
         for (int a = 0; a < TM; ++a)
@@ -619,7 +659,8 @@ static int launch_igemm_ws(const float* x, long ldx, const void* ws, const float
     if (xb >= (1L << 31) || wsb1 >= (1L << 31) || yb >= (1L << 31)) return U2PL_EINVAL;
     if ((batch - 1) * zx * 4 + xb >= (1L << 31) || (batch - 1) * zy * 4 + yb >= (1L << 31) || (long)batch * wsb1 >= (1L << 31))
         return U2PL_EINVAL;
-    if (ep.res && ((M - 1) * ep.ldr + g.Cout) * 4 >= (1L << 31)) return U2PL_EINVAL;
+    const long resb = ep.res ? ((M - 1) * ep.ldr + g.Cout) * 4 : 0;
+    if (resb >= (1L << 31)) return U2PL_EINVAL;
     const int mtiles = cdiv(M, BM), ntiles = cdiv(g.Cout, BN);
     const long total = (long)mtiles * ntiles * batch;
     if (total >= (1L << 30)) return U2PL_EINVAL;
@@ -628,7 +669,7 @@ static int launch_igemm_ws(const float* x, long ldx, const void* ws, const float
     (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(d_ws_stamps), &g_ws_stamps, sizeof(void*), 0, hipMemcpyHostToDevice, stream);
 #endif
     U2PL_LAUNCH((k_igemm_ws<TM, TN, WM, WN, PW, ABL>), dim3(grid), dim3(64 * WM * WN), lds, stream, x, ldx,
-                (const unsigned short*)ws, bias, y, ldy, g, (unsigned)xb, (unsigned)wsb1, (unsigned)yb, 0u, Np, stats, pivot, zx,
+                (const unsigned short*)ws, bias, y, ldy, g, (unsigned)xb, (unsigned)wsb1, (unsigned)yb, (unsigned)resb, Np, stats, pivot, zx,
                 wsb1 / 2, zy, ep, mtiles, ntiles, (int)total);
     U2PL_LAUNCH_CHECK();
     return 0;

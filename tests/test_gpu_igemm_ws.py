@@ -39,6 +39,7 @@ CASES = [
     (320, 320, 1, 1, 1, 19, 17, 1, True),       # Cout not a multiple of the tile, rows padded in the split planes
     (64, 256, 1, 1, 1, 40, 40, 1, False),       # K = 64: two chunks (prologue / clamped prefetch only)
     (32, 96, 1, 1, 1, 21, 21, 1, False),        # K = 32: a single chunk
+    (128, 130, 1, 1, 1, 23, 19, 1, True),       # Cout not a multiple of 4: dword result stores
 ]
 
 

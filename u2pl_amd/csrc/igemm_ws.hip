@@ -458,7 +458,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     //      Store offsets: element (row m, column c) at (m * ldy + c) * 4 in the matrix's descriptor; a row past M lies past the
     //      descriptor's extent (ldy >= Cout) and a column past Cout is given OOB_OFF: the hardware drops both, no compares.
     int c_v = blockIdx.x;
-    const int ldyb = (int)ldy * 4;
     float* red = (float*)(smem + 2 * ST);   // [4][2][BN] statistics scratch BEHIND the two stages (stage `nxt` already holds the next tile)
 #ifdef U2PL_WS_STAMPS
     int te_n = 0;
@@ -472,6 +471,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
         tile_of(c_v, mt, nt, z);
         const int n0 = nt * BN;
         const long m0 = (long)mt * BM;
+        // lane-derived values are recomputed per tile from an opaque copy of the thread index: hoisted out of the tile loop they
+        // would live across the main loop, whose register budget is full -- they were spilled, and a spill reload behind the
+        // stores waits for the stores
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+        (void)lane;
         const int zs = __builtin_amdgcn_readfirstlane(z);
         ry = make_rsrc(y + (long)zs * zy, ybytes);
         const bool bn_all = epi.mean != nullptr;
@@ -500,11 +506,63 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
         te[1] = te[2] = __builtin_readcyclecounter();
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        // fused BatchNorm statistics, BEFORE the stores (see above): per 128-row tile pivot-shifted column sums
-        // [tile][2][Cout].  The additions are made in the order of k_conv_igemm<1, 2, 4, 3> (per 32-row wave block: 16
+        // Results.  Element (row m, column c) lies at (m * ld + c) * 4 in its matrix's descriptor; a row past M lies past the
+        // descriptor's extent (ld >= Cout) and a column past Cout is given OOB_OFF: the hardware drops / zero-fills both, no
+        // compares.  (m * ld fits 32 bits: host check.)
+        //   (Measured and dropped: transposing the accumulators within each quad of lanes -- two rounds of quad-permute DPP
+        //   moves + selects -- so that a lane holds four consecutive columns of one row and an instruction stores 8 rows x 128
+        //   contiguous bytes as 16-byte pieces: 121 us against 110 us for these dword stores on 256 -> 1024 at 4 x 97^2.)
+        const int ldyb = (int)ldy * 4;
+        const int mrow = (int)m0 + wm * 32 * TM + 4 * lh;          // row of (a = 0, e = 0)
+        if (bn_all) {       // eval-mode BatchNorm (+ residual, ReLU) in place: the operations of k_bn_apply, in its order
+            const int ldrb = (int)epi.ldr * 4;
+            const __amdgpu_buffer_rsrc_t rr = make_rsrc(epi.res, resbytes);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int col = n0 + wn * 32 * TN + b * 32 + li;
+                float rv[TM][16];
+                if (epi.res) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        const int rbase = col < g.Cout ? ((mrow + a * 32) * (int)epi.ldr + col) * 4 : OOB_OFF;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            rv[a][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, rbase + ((e & 3) + 8 * (e >> 2)) * ldrb, 0, 0));
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float v = acc[a][b][e] + bias_v[b];
+                        v = (v - mu[b]) * is[b] * ga[b] + be[b];
+                        if (epi.res) v += rv[a][e];
+                        if (epi.relu) v = fmaxf(v, 0.f);
+                        acc[a][b][e] = v;
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // (no store may move in front of a load)
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = n0 + wn * 32 * TN + b * 32 + li;
+            const float badd = bn_all ? 0.f : bias_v[b];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int vbase = col < g.Cout ? ((mrow + a * 32) * (int)ldy + col) * 4 : OOB_OFF;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = bn_all ? acc[a][b][e] : acc[a][b][e] + badd;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, vbase + ((e & 3) + 8 * (e >> 2)) * ldyb, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // fused BatchNorm statistics: per 128-row tile pivot-shifted column sums [tile][2][Cout], computed BEHIND the stores
+        // (register and LDS work only -- no load, no spill reload: checked in the ISA -- so it runs while the stores drain).  The additions are made in the order of k_conv_igemm<1, 2, 4, 3> (per 32-row wave block: 16
         // register values, the two lane halves, then the four 32-row blocks of the tile in ascending order) so the partial
         // sums are the same bits.
-        if (stats) {
+        if (stats && !bn_all) {
             static_assert(BM == 128, "statistics blocks are 128 rows");
             const long left = M - m0;                                                  // rows of this tile inside the matrix
             const int lim = (int)(left < BM ? left : BM) - (wm * 32 * TM + 4 * lh);    // row a * 32 + ro of this lane counts iff < lim
@@ -542,57 +600,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
                 }
             }
             // (the next write of `red` is a whole tile -- at least one chunk barrier -- away)
-        }
-        // bias / eval-mode BatchNorm (+ residual, ReLU) in place: the operations of k_bn_apply, in its order.  Element (row m,
-        // column c) lies at (m * ld + c) * 4 in its matrix's descriptor; a row past M lies past the descriptor's extent
-        // (ld >= Cout) and a column past Cout is given OOB_OFF: the hardware drops / zero-fills both, no compares.
-        const int mrow = (int)m0 + wm * 32 * TM + 4 * lh;          // row of (a = 0, e = 0); (m * ld fits 32 bits: host check)
-        if (bn_all) {
-            const int ldrb = (int)epi.ldr * 4;
-            const __amdgpu_buffer_rsrc_t rr = make_rsrc(epi.res, resbytes);
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                const int col = n0 + wn * 32 * TN + b * 32 + li;
-                float rv[TM][16];
-                if (epi.res) {
-#pragma unroll
-                    for (int a = 0; a < TM; ++a) {
-                        const int rbase = col < g.Cout ? ((mrow + a * 32) * (int)epi.ldr + col) * 4 : OOB_OFF;
-#pragma unroll
-                        for (int e = 0; e < 16; ++e)
-                            rv[a][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, rbase + ((e & 3) + 8 * (e >> 2)) * ldrb, 0, 0));
-                    }
-                }
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        float v = acc[a][b][e] + bias_v[b];
-                        v = (v - mu[b]) * is[b] * ga[b] + be[b];
-                        if (epi.res) v += rv[a][e];
-                        if (epi.relu) v = fmaxf(v, 0.f);
-                        acc[a][b][e] = v;
-                    }
-            }
-        } else {
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[a][b][e] = acc[a][b][e] + bias_v[b];
-        }
-        __builtin_amdgcn_sched_barrier(0);      // (no store may move in front of a load)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int col = n0 + wn * 32 * TN + b * 32 + li;
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                const int vbase = col < g.Cout ? ((mrow + a * 32) * (int)ldy + col) * 4 : OOB_OFF;
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[a][b][e]), ry, vbase + ((e & 3) + 8 * (e >> 2)) * ldyb, 0, 0);
-            }
         }
 #pragma unroll
         for (int a = 0; a < TM; ++a)

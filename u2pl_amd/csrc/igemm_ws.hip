@@ -726,6 +726,9 @@ static int run_igemm_ws(const float* x, long ldx, const void* ws, const float* b
         const double cw = (double)cdiv(tw, WS_NUM_CUS) * (nkc + 4.0), cn = (double)cdiv(tn, WS_NUM_CUS) * (0.5 * 1.15 * nkc + 2.0);
         narrow_tiles = force == 1 ? g.Cout <= 256 : force == 0 ? false : cn < 0.97 * cw;
     }
+    // (Measured and dropped: the 128 x 256 tile on FOUR waves of 128 x 64 -- one wave per SIMD with 512 registers, 18 operand
+    // reads per 48 matrix instructions instead of 12 per 24: bit-identical, 5-13 % slower on every wide-tile shape of
+    // tools/bench_igemm_ws.py; the second wave of a SIMD does cover stalls of the first.)
     if (!narrow_tiles) { if (pw) WS_GO(2, 2, true); else WS_GO(2, 2, false); }
     if (pw) WS_GO(2, 1, true); else WS_GO(2, 1, false);
 #undef WS_GO

@@ -216,9 +216,14 @@ def main():
     route0 = HO.split_route_stats()
     _WD["phase"] = "timed"
     t0 = time.perf_counter()
+    host_s = 0.0       # time the Python thread spends inside train_step (enqueue + the step's one blocking read)
     for i in range(args.steps):
+        th = time.perf_counter()
         meters = step(args.warmup + i)
+        host_s += time.perf_counter() - th
+    host_tail = time.perf_counter()
     torch.cuda.synchronize()
+    host_tail = time.perf_counter() - host_tail      # GPU work still queued when the host left the last step
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -305,20 +310,27 @@ def main():
             "syncbn_collectives_per_step": comm["syncbn_allreduce"], "bucket_allreduces_per_step": comm["bucket_allreduce"],
             "rccl_ranks": rccl_ranks,
             "split_launches_timed": route1[0] - route0[0], "split_second_barrier_launches_timed": route1[1] - route0[1],
+            # host side of the timed steps (rank 0): wall time inside train_step per step -- the enqueue of ~3000 C-ABI calls plus
+            # the step's one blocking device-to-host read -- and the GPU work still queued when the host left the last step
+            # (tools/host_overhead.py has the cProfile breakdown).  host_enqueue_ms close to ms_per_step with a small tail =
+            # the host is the bound; well below it = the GPU is
+            "host_enqueue_ms": round(host_s / args.steps * 1e3, 2), "gpu_tail_after_last_enqueue_ms": round(host_tail * 1e3, 2),
         }
         out.update(diag)
         out.update(roof)
         if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N=1 only (the checker's port, never the product)
             from oracle import step_ref
             out["cpu_baseline"] = step_ref.timed_cpu_baseline(crop=args.crop, arch=args.arch, batch=args.batch)
-            ref_t = os.path.join(ROOT, "profiles", "r02_cpu_reference_timing.json")
+            import glob
+            ref_ts = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_cpu_reference_timing.json")))
+            ref_t = ref_ts[-1] if ref_ts else ""
             if os.path.exists(ref_t):
                 rt = json.load(open(ref_t))
                 if rt.get("port_images_per_s") and rt.get("reference_images_per_s"):
                     # bridge between the two CPU numbers: port / reference on the SAME machine (build container)
                     out["cpu_baseline"]["port_over_reference"] = round(rt["port_images_per_s"] / rt["reference_images_per_s"], 3)
                 out["cpu_baseline"]["reference_train_in_build_container"] = {
-                    "images_per_s": round(rt["reference_images_per_s"], 5), "cores": rt["cores"],
+                    "images_per_s": round(rt["reference_images_per_s"], 5), "cores": rt["cores"], "file": "profiles/" + os.path.basename(ref_t),
                     "note": "the reference's own train_semi.train() through oracle/ref_shim.py, 1 warm-up + 2 timed steps, "
                             "same configuration; /root/reference does not exist on the GPU box"}
         print(json.dumps(out))

@@ -274,6 +274,17 @@ int u2pl_im2col_f32(const float* x, long ldx, float* col, int Kp, int N, int Hin
  * included; stats_partial has u2pl_igemm_ws_stat_blocks rows).  Cout > 64 only (narrower layers stay on conv.hip). */
 size_t u2pl_weight_split3_bytes(int rows, int K, int batch);
 int u2pl_weight_split3_f32(const float* w, long zw, int rows, int K, int batch, void* out, hipStream_t stream);
+/* All weight splits / all Winograd filter transforms of a model in ONE launch each (after the optimizer / EMA update; the
+ * per-weight entry points above remain the lazy path).  jobs: DEVICE arrays of
+ *   struct { const float* src; unsigned short* out; long seg_begin; int rows, Np, K, kind, RS, batch; }   (48 bytes)
+ *     kind 0: src = [batch][rows][K]; kind 1: src = conv weight [Cout][RS][Cin] read as [rows = Cin][K = RS * Cout] (the data
+ *     gradient's operand); Np = u2pl_weight_split3_pad_rows(rows); seg_begin = prefix sum of batch * Np * K / 8; total = the sum
+ *   struct { const float* w; float* U; long begin; int O, C, transposed, mt; }                             (40 bytes)
+ *     begin = prefix sum of O * C; total = the sum.
+ * Same bits as the per-weight calls. */
+int u2pl_weight_split3_multi_f32(const void* jobs, int njobs, long total, hipStream_t stream);
+int u2pl_weight_split3_pad_rows(int rows);
+int u2pl_wino_weight_multi_f32(const void* jobs, int njobs, long total, hipStream_t stream);
 int u2pl_igemm_ws_stat_blocks(int N, int Hout, int Wout);
 /* launch shape of the ws kernel (A/B switch, same results; env U2PL_WS_PERSIST): 1 (default) = persistent, at most one
  * block per CU working through its tiles; 0 = one block per tile */

@@ -5,7 +5,7 @@ bank, dropout on), 1 warm-up + 2 timed optimizer steps, and the port (oracle/ste
 the same thread count.  /root/reference exists only in the build container, so this runs HERE; bench.py's
 `cpu_baseline` leg times the port on the GPU box (kind "port") and quotes this file's reference figure next to it.
 
-    python oracle/cpu_reference_bench.py [reference|port|both]  ->  profiles/r02_cpu_reference_timing.json
+    python oracle/cpu_reference_bench.py [reference|port|both]  ->  profiles/r04_cpu_reference_timing.json (U2PL_CPU_TIMING_FILE: other name)
 """
 import json
 import os
@@ -17,7 +17,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-OUT = os.path.join(ROOT, "profiles", "r02_cpu_reference_timing.json")
+OUT = os.path.join(ROOT, "profiles", os.environ.get("U2PL_CPU_TIMING_FILE", "r04_cpu_reference_timing.json"))
 
 
 def time_reference(threads):

@@ -171,6 +171,77 @@ def test_ws_operand_cache_follows_the_weights(ws_switch):
     assert torch.equal(y3, y3_ref) and not torch.equal(y3, y2)
 
 
+def test_presplit_rebuilds_every_operand_in_batched_launches_with_the_lazy_paths_bits(ws_switch):
+    """ParamArena.sgd_step -> presplit: forward planes, transposed (data-gradient) planes and both Winograd filter forms of
+    every weight the model used are rebuilt by ONE transform + ONE split launch and stamped current -- the next step's layer
+    calls launch nothing -- and hold exactly the bytes the per-weight lazy path builds"""
+    from u2pl_amd._lib import query
+    Kn = ws_switch
+    Kn.CONV_ALGO.update(wino=4, min_gain=0.0)
+    Kn.CONV_WS["on"] = True
+    saved = Kn.PRESPLIT["on"]
+    torch.manual_seed(21)
+    convs = [Kn.Conv2d(128, 256, 1, bias=False).to(DEV), Kn.Conv2d(256, 128, 3, padding=2, dilation=2, bias=False).to(DEV),
+             Kn.Conv2d(128, 160, 3, stride=2, padding=1, bias=False).to(DEV), Kn.Conv2d(160, 96, 1, bias=True).to(DEV)]
+    arena = Kn.ParamArena([[p for c in convs for p in c.parameters()]])
+    x = torch.randn(2, 128, 21, 19, device=DEV).contiguous(memory_format=CL)
+
+    def step():
+        h = x.clone().requires_grad_(True)
+        y = h
+        for c in convs:
+            y = c(y)
+        y.square().mean().backward()
+        torch.cuda.synchronize()
+        return y.detach().clone(), h.grad.clone()
+
+    try:
+        Kn.PRESPLIT["on"] = False
+        step()                                             # builds and registers every operand (lazy path)
+        kinds = sorted(k for c in convs for k in c.weight._u2pl_derived)
+        assert kinds == sorted(["f", "d", "wf4", "wd4", "f", "d", "f", "d"]), kinds
+        arena.grad.normal_(0, 1.0)
+        arena.sgd_step([0.05], 0.9, 1e-4)
+        y_lazy, dx_lazy = step()                           # lazy rebuild after the update
+        lazy = {(i, k): e["buf"].clone() for i, c in enumerate(convs) for k, e in c.weight._u2pl_derived.items()}
+        # same update again from the same state, this time through presplit
+        Kn.PRESPLIT["on"] = True
+        for c in convs:
+            for e in c.weight._u2pl_derived.values():
+                e["buf"].zero_()
+        Kn.bump_weight_epoch()
+        k0 = query("u2pl_kernel_launches")
+        n = Kn.presplit(arena.params, arena)
+        assert n == 8 and query("u2pl_kernel_launches") - k0 == 2
+        torch.cuda.synchronize()
+        for (i, k), b in lazy.items():
+            e = convs[i].weight._u2pl_derived[k]
+            assert torch.equal(e["buf"], b), (i, k)
+            assert e["stamp"] == (Kn.WEIGHT_EPOCH[0], convs[i].weight._version, convs[i].weight.data_ptr())
+        k1 = query("u2pl_kernel_launches")
+        y_pre, dx_pre = step()
+        assert torch.equal(y_pre, y_lazy) and torch.equal(dx_pre, dx_lazy)
+        launches_pre = query("u2pl_kernel_launches") - k1
+        Kn.PRESPLIT["on"] = False
+        Kn.bump_weight_epoch()
+        k2 = query("u2pl_kernel_launches")
+        step()
+        assert query("u2pl_kernel_launches") - k2 > launches_pre, "the lazy path should have launched the per-weight builds"
+        # and through the arena hook
+        Kn.PRESPLIT["on"] = True
+        arena.grad.normal_(0, 1.0)
+        arena.sgd_step([0.05], 0.9, 1e-4)
+        for c in convs:
+            for e in c.weight._u2pl_derived.values():
+                assert e["stamp"] == (Kn.WEIGHT_EPOCH[0], c.weight._version, c.weight.data_ptr())
+        y_a, dx_a = step()
+        Kn.CONV_WS["on"] = False
+        y_b, dx_b = step()
+        assert torch.equal(y_a, y_b) and torch.equal(dx_a, dx_b)
+    finally:
+        Kn.PRESPLIT["on"] = saved
+
+
 def test_ws_nonfinite_operands_give_nonfinite_outputs(ws_switch):
     """documented semantics of the split arithmetic: an Inf or NaN operand makes every output
     it contributes to NaN (the fp32 matrix instruction would keep +-Inf for Inf * finite) -- never a finite value"""

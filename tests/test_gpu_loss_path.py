@@ -736,6 +736,69 @@ def test_fused_split_coherence_stress_alternating_inputs_with_a_busy_second_stre
     assert bad == 0, f"{bad} of 1500 launches returned statistics that are not their input's (stale cross-block data)"
 
 
+def test_infonce_fused_ticket_reduction_stress_alternating_inputs_with_a_busy_second_stream():
+    """ADVICE r3 (medium), second half: u2pl_infonce_fused_f32 reduces the loss in the launch that computes it -- every block
+    publishes its partial sum with a write-through store, takes a ticket (sharded counters), the last block adds the
+    partials in fixed order -- again without an agent-scope fence pair.  400 evaluations on ONE reused workspace, the
+    features alternating irregularly between three tensors (a stale partial is the PREVIOUS call's value), the ring bank
+    restored before every call, a second stream sweeping the caches: every loss must be the bits of the two-launch form
+    (u2pl_infonce_f32 + u2pl_infonce_reduce_f32) for that input, every gradient the bits of its first evaluation."""
+    from u2pl_amd.utils.loss_helper import compute_contra_memobank_loss
+    H = hip()
+    g = golden("contra_65_prefill")
+    C, D = 19, int(g["D"])
+    qs = [int(x) for x in g["queue_size"]]
+    fill = [int(x) for x in g["fill"]] if "fill" in g else [int(g["prefill"]) + 3 * c for c in range(C)]
+    init = [formula_bank(c, fill[c], D).to(DEV) for c in range(C)]
+    p = "s0_"
+    B = g[p + "label_l"].shape[0]
+    prob = T(g[p + "prob_all"])
+    rep0 = T(g[p + "rep"]).contiguous(memory_format=torch.channels_last)
+    rep_t = T(g[p + "rep_teacher"]).contiguous(memory_format=torch.channels_last)
+    reps = [rep0, rep0.roll(3, dims=1).contiguous(memory_format=torch.channels_last), rep0.flip(0).contiguous(memory_format=torch.channels_last)]
+    args = (T(g[p + "label_l_small"], torch.int64), T(g[p + "label_u_small"], torch.int64), prob[:B], prob[B:],
+            T(g[p + "low_mask_all"], torch.float32), T(g[p + "high_mask_all"], torch.float32))
+    rng0 = torch.from_numpy(g[p + "rng_state"])
+    bank = H.DeviceMemoryBank(C, qs, D, DEV)
+
+    def evaluate(k):
+        for c in range(C):
+            bank.load_logical(c, init[c])
+        ptrs = [torch.zeros(1, dtype=torch.long) for _ in range(C)]
+        rep = reps[k].clone().requires_grad_(True)
+        torch.set_rng_state(rng0)
+        _, loss = compute_contra_memobank_loss(rep, *args, CONTRA_CFG, bank, ptrs, qs, rep_t)
+        loss.backward()
+        return loss.detach().reshape(1).clone(), rep.grad.abs().sum(dtype=torch.float64).reshape(1)
+
+    saved = H.NCE_FUSED
+    try:
+        H.NCE_FUSED = False
+        want = [evaluate(k) for k in range(3)]
+        torch.cuda.synchronize()
+        H.NCE_FUSED = True
+        side = torch.cuda.Stream()
+        big = torch.randn(64 << 20, device=DEV)
+        junk = torch.empty_like(big)
+        rng = np.random.RandomState(11)
+        ks, got = [], []
+        for it in range(400):
+            k = int(rng.randint(0, 3))
+            if it % 8 == 0:
+                with torch.cuda.stream(side):
+                    junk.copy_(big)
+                    big.mul_(1.0000001)
+            ks.append(k)
+            got.append(evaluate(k))
+        torch.cuda.synchronize()
+    finally:
+        H.NCE_FUSED = saved
+    wl = [(float(a), float(b)) for a, b in want]
+    bad = sum(1 for k, (a, b) in zip(ks, got) if (float(a), float(b)) != wl[k])
+    assert len({x[0] for x in wl}) == 3, "the three inputs must give three different losses"
+    assert bad == 0, f"{bad} of 400 fused evaluations differ from the two-launch form of their input"
+
+
 # ------------------------------------------------------------------ row-sparse ordered InfoNCE gradient
 @pytest.mark.parametrize("n_cand", [3000, 40, 2])
 def test_infonce_gradient_scatter_is_row_sparse_ordered_and_reproducible(n_cand):

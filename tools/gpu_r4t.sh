@@ -1,0 +1,14 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/r4t
+mkdir -p $O
+timeout 600 python -m pytest tests/test_gpu_igemm_ws.py "tests/test_gpu_loss_path.py::test_infonce_fused_ticket_reduction_stress_alternating_inputs_with_a_busy_second_stream" -q -x < /dev/null > $O/tests.log 2>&1; echo "tests rc=$?"
+tail -n 12 $O/tests.log | cut -c1-300
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline < /dev/null > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+python - <<'P'
+import json,os
+d=json.loads(open(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/r4t/bench.json").read().strip().splitlines()[-1])
+print(d["ms_per_step"], d["value"], "igemm", d["roofline"]["frac"], d["roofline"]["ms_per_step"], "wgrad", d["roofline_wgrad"]["frac"], d["roofline_wgrad"]["ms_per_step"], "hbm", d["roofline_hbm"]["frac"])
+print({k: d[k] for k in d if k.startswith("kernel_ms") or k in ("abi_calls_per_step","kernel_launches_per_step","host_enqueue_ms","gpu_tail_after_last_enqueue_ms")})
+print(d["roofline"].get("traffic_source"))
+P

@@ -1,6 +1,6 @@
 """frac of the fp32 MFMA peak from a rocprofv3 --kernel-trace CSV of tools/dense_replay.py:
     python tools/parse_dense_trace.py <kernel_trace.csv> <dense_replay.json> [out.json]
-takes the LAST `kernel_launches` k_conv_igemm rows (the final replay), span = max End - min Start."""
+takes the LAST `kernel_launches` k_conv_igemm / k_igemm_ws rows (the final replay), span = max End - min Start."""
 import csv
 import json
 import sys
@@ -8,7 +8,7 @@ import sys
 
 def main(trace, meta, out=None):
     m = json.loads([l for l in open(meta).read().splitlines() if l.startswith("{")][-1])
-    rows = [r for r in csv.DictReader(open(trace)) if "k_conv_igemm" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(trace)) if "k_conv_igemm" in r["Kernel_Name"] or "k_igemm_ws" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     n = int(m["kernel_launches"])
     last = rows[-n:]
@@ -18,6 +18,8 @@ def main(trace, meta, out=None):
     res = dict(kernel_launches=n, igemm_rows_in_trace=len(rows), span_ms=span_ms, sum_of_durations_ms=busy / 1e6,
                executed_tflop=m["executed_tflop"], tflops_from_span=m["executed_tflop"] / span_ms * 1e3,
                frac_from_span=m["executed_tflop"] / span_ms * 1e3 / 157.3,
+               frac_of_split_bound_from_span=m["executed_tflop"] / span_ms * 1e3 / (2500.0 / 6.0),
+               frac_of_split_bound_from_sum_of_durations=m["executed_tflop"] / (busy / 1e6) * 1e3 / (2500.0 / 6.0),
                frac_from_sum_of_durations=m["executed_tflop"] / (busy / 1e6) * 1e3 / 157.3,
                hip_event_ms=m["hip_event_ms"], frac_from_hip_events=m["frac_of_157.3"])
     print(json.dumps(res, indent=1))

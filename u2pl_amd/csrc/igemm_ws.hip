@@ -66,6 +66,71 @@ __global__ void k_weight_split3(const float* __restrict__ w, long zw, unsigned s
     }
 }
 
+// every split of a model in ONE launch (u2pl_amd/nn.py presplit, after the optimizer / EMA update).  Job j covers the 16-byte
+// output segments [seg_begin_j, seg_begin_j+1) of `batch` matrices; kind 0: src = [batch][rows][K] row-major; kind 1: src =
+// the convolution weight [Cout][RS][Cin] read as its transpose [rows = Cin][K = RS * Cout] (the data gradient's operand: what
+// u2pl_weight_transpose_f32 + u2pl_weight_split3_f32 produce, without the intermediate).  Same pieces, same layout.
+struct SplitJob { const float* src; unsigned short* out; long seg_begin; int rows, Np, K, kind, RS, batch; };
+__global__ void k_weight_split3_multi(const SplitJob* __restrict__ jobs, int njobs, long total) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = njobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].seg_begin <= i) lo = mid; else hi = mid - 1;
+        }
+        const SplitJob j = jobs[lo];
+        const int nseg = j.K / 8;
+        const long per = (long)j.Np * nseg;
+        long r = i - j.seg_begin;
+        const int z = (int)(r / per);
+        r -= (long)z * per;
+        int sg, n;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (j.kind == 0) {
+            sg = (int)(r % nseg);
+            n = (int)(r / nseg);
+            if (n < j.rows) {
+                const float4* src = (const float4*)(j.src + ((long)z * j.rows + n) * j.K + sg * 8);
+                v0 = src[0];
+                v1 = src[1];
+            }
+        } else {          // n fastest: neighbouring lanes read neighbouring input channels
+            n = (int)(r % j.Np);
+            sg = (int)(r / j.Np);
+            if (n < j.rows) {
+                const int Cout = j.K / j.RS;
+                float e[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int k = sg * 8 + q, rs = k / Cout, co = k - rs * Cout;
+                    e[q] = j.src[((long)co * j.RS + rs) * j.rows + n];
+                }
+                v0 = make_float4(e[0], e[1], e[2], e[3]);
+                v1 = make_float4(e[4], e[5], e[6], e[7]);
+            }
+        }
+        uint2 a0, a1, a2, b0, b1, b2;
+        split3_bf16(v0, a0, a1, a2);
+        split3_bf16(v1, b0, b1, b2);
+        const int c = sg >> 2, s = sg & 3;
+        const long pl = (long)j.Np * 32;
+        unsigned short* out = j.out + (long)z * (j.K / 32) * 3 * pl;
+        const long base = (((long)c * 3) * j.Np + n) * 32 + ((s ^ ((n >> 2) & 3)) << 3);       // in bf16 elements
+        *(uint4*)(out + base) = make_uint4(a0.x, a0.y, b0.x, b0.y);
+        *(uint4*)(out + base + pl) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+        *(uint4*)(out + base + 2 * pl) = make_uint4(a2.x, a2.y, b2.x, b2.y);
+    }
+}
+// jobs: device array of njobs SplitJob (48 bytes each: src, out, seg_begin, rows, Np = u2pl_weight_split3_pad_rows(rows), K,
+// kind, RS, batch); total = sum over jobs of batch * Np * K / 8
+U2PL_API int u2pl_weight_split3_multi_f32(const void* jobs, int njobs, long total, hipStream_t stream) {
+    if (njobs <= 0 || total <= 0) return njobs == 0 ? 0 : U2PL_EINVAL;
+    U2PL_LAUNCH(k_weight_split3_multi, dim3(grid_for(total, 256, 4096)), dim3(256), 0, stream, (const SplitJob*)jobs, njobs, total);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+U2PL_API int u2pl_weight_split3_pad_rows(int rows) { return ws_pad_rows(rows); }
+
 U2PL_API size_t u2pl_weight_split3_bytes(int rows, int K, int batch) {
     return (size_t)batch * (K / 32) * 3 * ws_pad_rows(rows) * WS_ROW_B;
 }

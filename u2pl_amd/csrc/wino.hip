@@ -176,10 +176,8 @@ __global__ __launch_bounds__(256) U2PL_HBM_KERNEL void k_wino_input(const float*
 // w: [O][3][3][C] (channels_last OIHW).  transposed = 0: U[comp][O][C] = G g G^T
 // transposed = 1 (data gradient): taps rotated 180 degrees, U[comp][C][O]
 template <int MT>
-__global__ void k_wino_weight(const float* __restrict__ w, int O, int C, int transposed, float* __restrict__ U) {
+__device__ __forceinline__ void wino_weight_one(const float* __restrict__ w, int O, int C, int transposed, float* __restrict__ U, long idx) {
     constexpr int A = WinoT<MT>::A;
-    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (idx >= (long)O * C) return;
     // forward: c fastest (coalesced reads and writes); transposed: o fastest (coalesced U' writes, 4x the volume
     // of the reads)
     const int c = transposed ? (int)(idx / O) : (int)(idx % C), o = transposed ? (int)(idx % O) : (int)(idx / C);
@@ -207,6 +205,27 @@ __global__ void k_wino_weight(const float* __restrict__ w, int O, int C, int tra
         WinoT<MT>::gg(t[i], r);
 #pragma unroll
         for (int j = 0; j < A; ++j) U[(long)(i * A + j) * comp_stride + base] = r[j];
+    }
+}
+template <int MT>
+__global__ void k_wino_weight(const float* __restrict__ w, int O, int C, int transposed, float* __restrict__ U) {
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= (long)O * C) return;
+    wino_weight_one<MT>(w, O, C, transposed, U, idx);
+}
+// every filter transform of a model in ONE launch (the transforms of a step's optimizer update: u2pl_amd/nn.py presplit):
+// job j covers the (o, c) pairs [begin_j, begin_j+1); same arithmetic per pair as k_wino_weight
+struct WinoWeightJob { const float* w; float* U; long begin; int O, C, transposed, mt; };
+__global__ void k_wino_weight_multi(const WinoWeightJob* __restrict__ jobs, int njobs, long total) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = njobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].begin <= i) lo = mid; else hi = mid - 1;
+        }
+        const WinoWeightJob j = jobs[lo];
+        if (j.mt == 4) wino_weight_one<4>(j.w, j.O, j.C, j.transposed, j.U, i - j.begin);
+        else wino_weight_one<2>(j.w, j.O, j.C, j.transposed, j.U, i - j.begin);
     }
 }
 
@@ -454,6 +473,13 @@ U2PL_API int u2pl_wino_input_f32(const float* x, long ldx, int N, int H, int W, 
     return 0;
 }
 
+// jobs: device array of njobs WinoWeightJob {w, U, begin, O, C, transposed, mt} (begin = prefix sum of O * C), total = sum of O * C
+U2PL_API int u2pl_wino_weight_multi_f32(const void* jobs, int njobs, long total, hipStream_t stream) {
+    if (njobs <= 0 || total <= 0) return njobs == 0 ? 0 : U2PL_EINVAL;
+    U2PL_LAUNCH(k_wino_weight_multi, dim3(grid_for(total, 256, 4096)), dim3(256), 0, stream, (const WinoWeightJob*)jobs, njobs, total);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
 U2PL_API int u2pl_wino_weight_f32(const float* w, int O, int C, int transposed, int mt, float* U, hipStream_t stream) {
     if (mt != 2 && mt != 4) return U2PL_EINVAL;
     const dim3 grid((unsigned)cdiv((long)O * C, 256)), block(256);

@@ -232,19 +232,24 @@ def _ws_ok(n_cols, k_depth):
             and query("u2pl_conv_get_split") == 1)
 
 
-def _split_of(weight, kind, rows, K, batch, src):
-    """split planes of `batch` matrices [rows][K]; src() -> the fp32 source tensor (a temporary is fine)"""
+def _split_of(weight, kind, rows, K, batch, src, spec):
+    """split planes of `batch` matrices [rows][K]; src() -> the fp32 source tensor (a temporary is fine); spec: how presplit()
+    rebuilds the same planes in its batched launches"""
     nbytes = query("u2pl_weight_split3_bytes", rows, K, batch)
 
     def build(buf):
         w = src()
         call("u2pl_weight_split3_f32", w, rows * K, rows, K, batch, buf)
-    return _derived(weight, kind, nbytes, build)
+    buf = _derived(weight, kind, nbytes, build)
+    ent = weight.__dict__["_u2pl_derived"][kind]
+    if "spec" not in ent:
+        ent["spec"] = dict(spec, rows=rows, K=K, batch=batch)
+    return buf
 
 
 def ws_forward(weight):
     Cout, Cin, R, S = weight.shape
-    return _split_of(weight, "f", Cout, R * S * Cin, 1, lambda: weight)
+    return _split_of(weight, "f", Cout, R * S * Cin, 1, lambda: weight, dict(how="plain"))
 
 
 def ws_dgrad(weight):
@@ -254,7 +259,7 @@ def ws_dgrad(weight):
         wT = torch.empty(Cin * R * S * Cout, dtype=torch.float32, device=weight.device)
         call("u2pl_weight_transpose_f32", weight, wT, Cout, R * S, Cin)
         return wT
-    return _split_of(weight, "d", Cin, R * S * Cout, 1, src)
+    return _split_of(weight, "d", Cin, R * S * Cout, 1, src, dict(how="transposed", RS=R * S))
 
 
 def ws_wino(weight, transposed, mt):
@@ -266,7 +271,78 @@ def ws_wino(weight, transposed, mt):
         U = torch.empty(a2 * Cout * Cin, dtype=torch.float32, device=weight.device)
         call("u2pl_wino_weight_f32", weight, Cout, Cin, int(transposed), mt, U)
         return U
-    return _split_of(weight, ("wd" if transposed else "wf") + str(mt), rows, K, a2, src)
+    return _split_of(weight, ("wd" if transposed else "wf") + str(mt), rows, K, a2, src,
+                     dict(how="wino", transposed=int(transposed), mt=mt, O=Cout, C=Cin))
+
+
+# ---- all derived operands of a model rebuilt in two launches ----------------------------------------------------
+# The lazy path above costs two to four tiny launches per weight and step (~660 per step for student + teacher: transposes,
+# Winograd filter transforms, splits).  After the first step every operand a model uses is known: presplit(params), called
+# by the arena right after its optimizer / EMA kernel, rebuilds ALL stale ones with one u2pl_wino_weight_multi_f32 and one
+# u2pl_weight_split3_multi_f32 launch (job tables on the device, re-uploaded only when the set of operands changes) and
+# stamps them current, so the layer calls of the next step find them valid.  Same bits as the lazy path (tested).
+# U2PL_PRESPLIT=0: off.
+PRESPLIT = {"on": os.environ.get("U2PL_PRESPLIT", "1") != "0", "tables": {}}
+
+
+def presplit(params, owner=None):
+    import numpy as np
+    if not (PRESPLIT["on"] and CONV_WS["on"]):
+        return 0
+    todo = []
+    for w in params:
+        cache = w.__dict__.get("_u2pl_derived")
+        if not cache:
+            continue
+        stamp = (WEIGHT_EPOCH[0], w._version, w.data_ptr())
+        for kind, ent in cache.items():
+            if "spec" in ent and ent["stamp"] is not None and ent["stamp"] != stamp:
+                todo.append((w, ent, stamp))
+    if not todo:
+        return 0
+    cur = torch.cuda.current_stream()
+    for st in {s_ for _, e, _ in todo for s_ in (list(e["readers"]) + [e["stream"]]) if s_ != cur}:
+        cur.wait_stream(st)          # nobody reads the old planes any more, the previous build is complete
+    key = tuple((w.data_ptr(), e["buf"].data_ptr(), e["spec"]["how"]) for w, e, _ in todo)
+    tab = PRESPLIT["tables"].get(id(owner))
+    if tab is None or tab["key"] != key:
+        dev = todo[0][0].device
+        sj = np.zeros(len(todo), dtype=np.dtype([("src", "<u8"), ("out", "<u8"), ("seg", "<i8"), ("rows", "<i4"), ("Np", "<i4"),
+                                                 ("K", "<i4"), ("kind", "<i4"), ("RS", "<i4"), ("batch", "<i4")]))
+        wino = [(w, e) for w, e, _ in todo if e["spec"]["how"] == "wino"]
+        wj = np.zeros(max(len(wino), 1), dtype=np.dtype([("w", "<u8"), ("U", "<u8"), ("begin", "<i8"), ("O", "<i4"), ("C", "<i4"),
+                                                         ("tr", "<i4"), ("mt", "<i4")]))
+        # one scratch arena for the Winograd-domain filters (read by the split launch right behind the transform launch)
+        u_off, acc = {}, 0
+        for w, e in wino:
+            sp = e["spec"]
+            u_off[id(e)] = acc
+            acc += sp["batch"] * sp["rows"] * sp["K"]
+        scratch = torch.empty(max(acc, 1), dtype=torch.float32, device=dev)
+        begin = 0
+        for i, (w, e) in enumerate(wino):
+            sp = e["spec"]
+            wj[i] = (w.data_ptr(), scratch.data_ptr() + 4 * u_off[id(e)], begin, sp["O"], sp["C"], sp["transposed"], sp["mt"])
+            begin += sp["O"] * sp["C"]
+        seg = 0
+        for i, (w, e, _) in enumerate(todo):
+            sp = e["spec"]
+            Np = query("u2pl_weight_split3_pad_rows", sp["rows"])
+            src = scratch.data_ptr() + 4 * u_off[id(e)] if sp["how"] == "wino" else w.data_ptr()
+            sj[i] = (src, e["buf"].data_ptr(), seg, sp["rows"], Np, sp["K"], 1 if sp["how"] == "transposed" else 0,
+                     sp.get("RS", 1), sp["batch"])
+            seg += sp["batch"] * Np * (sp["K"] // 8)
+        tab = PRESPLIT["tables"][id(owner)] = dict(
+            key=key, scratch=scratch, n_split=len(todo), seg=seg, n_wino=len(wino), wino_total=begin,
+            sj=torch.from_numpy(sj.view(np.uint8).copy()).to(dev), wj=torch.from_numpy(wj.view(np.uint8).copy()).to(dev))
+    if tab["n_wino"]:
+        call("u2pl_wino_weight_multi_f32", tab["wj"], tab["n_wino"], tab["wino_total"])
+    call("u2pl_weight_split3_multi_f32", tab["sj"], tab["n_split"], tab["seg"])
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    for w, e, stamp in todo:
+        e["event"], e["stream"], e["stamp"], e["readers"] = ev, cur, stamp, set()
+    return len(todo)
 
 
 def wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W):
@@ -1213,6 +1289,7 @@ class ParamArena:
              float(lr[1]), float(lr[2]), float(momentum), float(weight_decay), int(self.steps == 0),
              float(grad_scale))
         self.steps += 1
+        presplit(self.params, self)
 
     def adam_step(self, lrs, betas, eps, weight_decay, grad_scale=1.0):
         """torch.optim.Adam(betas, eps, weight_decay; amsgrad off) semantics with per-group lr (lr_helper.py:20-21)."""
@@ -1227,6 +1304,7 @@ class ParamArena:
         call("u2pl_adam_step_f32", self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.n, b[0], b[1], float(lr[0]),
              float(lr[1]), float(lr[2]), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), float(bc1),
              float(bc2s), float(grad_scale))
+        presplit(self.params, self)
 
     def adam_views(self, p):
         """(exp_avg, exp_avg_sq) views shaped / strided like parameter p (allocated on first use)"""
@@ -1240,7 +1318,9 @@ class ParamArena:
         """self = decay*self + (1-decay)*other  (train_semi.py:543-548)."""
         bump_weight_epoch()
         call("u2pl_ema_update_f32", self.flat, other.flat, self.n, float(decay), float(1 - decay))
+        presplit(self.params, self)
 
     def copy_from(self, other):
         bump_weight_epoch()
         self.flat.copy_(other.flat)
+        presplit(self.params, self)

@@ -226,6 +226,21 @@ def split_phase_table():
     return out
 
 
+def kernel_source_hash():
+    """sha256 (first 12 hex digits) over the HIP sources and headers of the library: ties a profile to the kernels it measured
+    (the GPU box has no .git)"""
+    import hashlib
+    root = os.path.dirname(os.path.abspath(__file__))
+    hs = hashlib.sha256()
+    files = []
+    for d in (os.path.join(root, "csrc"), os.path.join(os.path.dirname(root), "include")):
+        files += [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h"))]
+    for f in files:
+        hs.update(os.path.basename(f).encode())
+        hs.update(open(f, "rb").read())
+    return hs.hexdigest()[:12]
+
+
 def hbm_algorithmic_bytes(B, C, H, W, h, w, D, stats):
     """entropy+reliability 4C+24 B/pixel + low-res outputs; contrastive with
     the Q0 skip (only images {0,B} referenced) from the measured counts."""
@@ -352,12 +367,22 @@ def measure(trainer, batch, args, ms_per_step):
     if os.path.exists(tj) and "roofline" in out:
         import json
         tr = json.load(open(tj))
-        out["roofline"]["traffic"] = tr.get("k_conv_igemm_bytes_per_launch")
-        out["roofline"]["traffic_source"] = "static: profiles/%s (rocprofv3 PMC passes at commit %s), not measured in this run" % (
-            os.path.basename(tj), tr.get("commit", "?"))
-        if "roofline_hbm" in out and tr.get("hbm_group_bytes_per_step") is not None:
-            out["roofline_hbm"]["traffic"] = tr["hbm_group_bytes_per_step"]
-            out["roofline_hbm"]["traffic_source"] = out["roofline"]["traffic_source"]
+        sha = kernel_source_hash()
+        if tr.get("kernel_sources_sha") != sha:
+            # a PMC record of OTHER kernel sources is not this build's traffic: refuse it rather than quote a stale number
+            out["roofline"]["traffic_source"] = ("none: profiles/%s was taken with kernel sources %s (commit %s), this build is %s; "
+                                                 "re-run tools/gpu_r4_profiles.sh" % (os.path.basename(tj), tr.get("kernel_sources_sha", "?"),
+                                                                                      tr.get("commit", "?"), sha))
+            if "roofline_hbm" in out:
+                out["roofline_hbm"]["traffic_source"] = out["roofline"]["traffic_source"]
+        else:
+            out["roofline"]["traffic"] = tr.get("igemm_bytes_per_launch", tr.get("k_conv_igemm_bytes_per_launch"))
+            out["roofline"]["traffic_per_step"] = tr.get("igemm_bytes_per_step")
+            out["roofline"]["traffic_source"] = ("static: profiles/%s (rocprofv3 PMC passes at commit %s, kernel sources %s = this "
+                                                 "build), not measured in this run" % (os.path.basename(tj), tr.get("commit", "?"), sha))
+            if "roofline_hbm" in out and tr.get("hbm_group_bytes_per_step") is not None:
+                out["roofline_hbm"]["traffic"] = tr["hbm_group_bytes_per_step"]
+                out["roofline_hbm"]["traffic_source"] = out["roofline"]["traffic_source"]
     top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]
     out["abi_calls_per_step"] = sum(v["calls"] for v in agg.values())
     out["kernel_launches_per_step"] = sum(v["kernels"] for v in agg.values())

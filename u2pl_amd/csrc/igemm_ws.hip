@@ -302,6 +302,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
         constexpr int j = decltype(j_c)::value;
         rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_kc < nk ? boff[j] : OOB_OFF, b_toff + b_kc * chunk_b, 0);
     };
+    // (Measured and dropped: the weight planes by LDS-DMA -- buffer_load_dwordx4 ... lds, a wave copying 1 KB units that are
+    // contiguous in the global image and in the stage, no registers, no ds_write.  Bit-identical; with the loads issued in
+    // the middle of the chunk -- behind the split, where the compiler's own waits do not cover them -- short-K shapes gained
+    // 3-4 % and long-K shapes lost 10 %; issued at the chunk's start through inline assembly with hand-written waits every
+    // shape of tools/bench_igemm_ws.py was slower: 5880 us against 5615 us for the set.  The builtin form cannot be placed
+    // early at all: the compiler orders every LDS access that may alias a pending LDS-DMA behind it with vmcnt(0).)
     auto advance_b = [&]() __attribute__((always_inline)) {
         if (b_kc + 1 < nk2) ++b_kc;
         else if (b_v + G < total_tiles) {

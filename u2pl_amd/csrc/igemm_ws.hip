@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     const float* __restrict__ x, long ldx, const unsigned short* __restrict__ ws, const float* __restrict__ bias,
     float* __restrict__ y, long ldy, ConvGeom g, unsigned xbytes, unsigned wsbytes, unsigned ybytes, unsigned resbytes, int Np,
     float* __restrict__ stats, const float* __restrict__ pivot, long zx, long zws, long zy, BnEpi epi, int mtiles, int ntiles,
-    int total_tiles) {
+    int total_tiles, int tile0) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
     constexpr int RPP = NT / 8, RA = BM / RPP;              // A: 8 threads x float4 per 32-deep row
     constexpr int UB = 3 * BN * 4, RBU = UB / NT;           // B: 16-byte units per chunk, per thread
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     auto tile_of = [&](int v, int& mt, int& nt, int& z) __attribute__((always_inline)) {
         const int xcd = v & 7, j = v >> 3;
         const int q = total_tiles >> 3, r = total_tiles & 7;
-        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        const int t = tile0 + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;     // (tile0: this launch's first tile)
         nt = t % ntiles;
         const int rest = t / ntiles;
         mt = rest % mtiles;
@@ -717,7 +717,7 @@ U2PL_API int u2pl_igemm_ws_set_persist(int on) { const int old = ws_persist(); g
 template <int TM, int TN, int WM, int WN, bool PW, int ABL = 0>
 static int launch_igemm_ws(const float* x, long ldx, const void* ws, const float* bias, float* y, long ldy,
                            const ConvGeom& g, hipStream_t stream, float* stats, const float* pivot, int batch, long zx,
-                           long zy, const BnEpi* epi) {
+                           long zy, const BnEpi* epi, long tile_first = 0, long tile_count = -1) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     const long M = (long)g.N * g.Hout * g.Wout;
     if (M <= 0) return 0;
@@ -740,15 +740,17 @@ static int launch_igemm_ws(const float* x, long ldx, const void* ws, const float
     const long resb = ep.res ? ((M - 1) * ep.ldr + g.Cout) * 4 : 0;
     if (resb >= (1L << 31)) return U2PL_EINVAL;
     const int mtiles = cdiv(M, BM), ntiles = cdiv(g.Cout, BN);
-    const long total = (long)mtiles * ntiles * batch;
-    if (total >= (1L << 30)) return U2PL_EINVAL;
+    const long all_tiles = (long)mtiles * ntiles * batch;
+    if (all_tiles >= (1L << 30)) return U2PL_EINVAL;
+    const long total = tile_count < 0 ? all_tiles : tile_count;      // this launch: tiles [tile_first, tile_first + total)
+    if (total <= 0) return 0;
     const unsigned grid = (unsigned)((total < WS_NUM_CUS || !ws_persist()) ? total : WS_NUM_CUS);
 #ifdef U2PL_WS_STAMPS
     (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(d_ws_stamps), &g_ws_stamps, sizeof(void*), 0, hipMemcpyHostToDevice, stream);
 #endif
     U2PL_LAUNCH((k_igemm_ws<TM, TN, WM, WN, PW, ABL>), dim3(grid), dim3(64 * WM * WN), lds, stream, x, ldx,
                 (const unsigned short*)ws, bias, y, ldy, g, (unsigned)xb, (unsigned)wsb1, (unsigned)yb, (unsigned)resb, Np, stats, pivot, zx,
-                wsb1 / 2, zy, ep, mtiles, ntiles, (int)total);
+                wsb1 / 2, zy, ep, mtiles, ntiles, (int)total, (int)tile_first);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -771,8 +773,12 @@ static int run_igemm_ws(const float* x, long ldx, const void* ws, const float* b
     // pointwise: 1x1, stride 1, no padding, forward or data-gradient geometry alike
     const bool pw = g.R == 1 && g.S == 1 && g.mul == 1 && g.off_h == 0 && g.off_w == 0 && g.log2div == 0 &&
                     g.Hin == g.Hout && g.Win == g.Wout;
-#define WS_GO(TM_, TN_, PW_) \
-    return launch_igemm_ws<TM_, TN_, 2, 4, PW_>(x, ldx, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi)
+    auto go = [&](bool narrow, long first, long count) {
+        if (!narrow) return pw ? launch_igemm_ws<2, 2, 2, 4, true>(x, ldx, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi, first, count)
+                               : launch_igemm_ws<2, 2, 2, 4, false>(x, ldx, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi, first, count);
+        return pw ? launch_igemm_ws<2, 1, 2, 4, true>(x, ldx, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi, first, count)
+                  : launch_igemm_ws<2, 1, 2, 4, false>(x, ldx, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi, first, count);
+    };
 #ifdef U2PL_WS_ABLATE
     if (g_ws_abl && g.Cout > 128 && pw) {
 #define WS_ABL(A_) case A_: return launch_igemm_ws<2, 2, 2, 4, true, A_>(x, ldx, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi)
@@ -783,26 +789,37 @@ static int run_igemm_ws(const float* x, long ldx, const void* ws, const float* b
     // 128 x 256 or 128 x 128 tiles?  One persistent block per CU: a launch costs (tiles of the busiest block) x (time per tile).
     // Narrow tiles halve the work per tile at ~15 % more time per product (the activation split is amortised over half the
     // matrix instructions) and fill the last round better: 295 row tiles x 256 columns take 2 rounds of wide tiles but only
-    // 3 rounds of half-size ones (measured 146 -> 125 us for the 1024 -> 256 1x1 convolution at 4 x 97^2; where the wide
-    // tiling divides well -- the 2048 -> 256 Winograd batch, 256 -> 1024 -- the wide tile stays).  Times in units of one
-    // 32-deep chunk of a wide tile; 4 / 2 = fixed cost per tile (prologue, epilogue), fitted to tools/bench_igemm_ws.py.
-    // U2PL_WS_NARROW = 0 (never) | 1 (always, where Cout <= 256) | unset (the model).
-    bool narrow_tiles = g.Cout <= 128;
-    if (g.Cout > 128) {
-        static int force = -2;
-        if (force == -2) { const char* e = getenv("U2PL_WS_NARROW"); force = (e && *e) ? atoi(e) : -1; }
-        const long M_ = (long)g.N * g.Hout * g.Wout;
-        const long mt = cdiv(M_, 128), nkc = (long)(g.R * g.S * g.Cin) / BK;
-        const long tw = mt * cdiv(g.Cout, 256) * batch, tn = mt * cdiv(g.Cout, 128) * batch;
-        const double cw = (double)cdiv(tw, WS_NUM_CUS) * (nkc + 4.0), cn = (double)cdiv(tn, WS_NUM_CUS) * (0.5 * 1.15 * nkc + 2.0);
-        narrow_tiles = force == 1 ? g.Cout <= 256 : force == 0 ? false : cn < 0.97 * cw;
+    // 3 rounds of half-size ones (measured 146 -> 125 us for the 1024 -> 256 1x1 convolution at 4 x 97^2).  Third plan,
+    // MIXED: the full rounds as wide tiles and the remainder R <= 128 wide tiles as 2 R narrow ones in a SECOND launch (a
+    // persistent block has one tile shape): 792 tiles of a Winograd batch = 3 rounds + 24 tiles cost 3.6 rounds instead of
+    // 4; a narrow tile (z, mt, 2 nt + h) is half h of the wide tile (z, mt, nt), so the remainder is a contiguous range of
+    // narrow tile numbers.  Times in units of one 32-deep chunk of a wide tile; 4 / 2 = fixed cost per tile (prologue,
+    // epilogue), 8 = the second launch (drain of the first, launch gap, a cold prologue: ~15 us measured); fitted to
+    // tools/bench_igemm_ws.py: the mixed plan wins on the long-K launches (2048 -> 256 3x3 at 4 x 97^2: 2194 -> 1953 us,
+    // 2048 -> 512: 410 -> 394 us) and is not chosen for K = 256 .. 1024, where it measured 0-7 % slower.
+    // U2PL_WS_NARROW = 0 (wide only) | 1 (narrow, where Cout <= 256) | 2 (wide / narrow by the model, never mixed) | unset.
+    if (g.Cout <= 128) return go(true, 0, -1);
+    static int force = -2;
+    if (force == -2) { const char* e = getenv("U2PL_WS_NARROW"); force = (e && *e) ? atoi(e) : -1; }
+    const long M_ = (long)g.N * g.Hout * g.Wout;
+    const long mt = cdiv(M_, 128), nkc = (long)(g.R * g.S * g.Cin) / BK;
+    const long ntw = cdiv(g.Cout, 256), ntn = cdiv(g.Cout, 128);
+    const long tw = mt * ntw * batch, tn = mt * ntn * batch;
+    const double cw1 = nkc + 4.0, cn1 = 0.5 * 1.15 * nkc + 2.0;
+    const double cw = (double)cdiv(tw, WS_NUM_CUS) * cw1, cn = (double)cdiv(tn, WS_NUM_CUS) * cn1;
+    if (force == 0) return go(false, 0, -1);
+    if (force == 1) return go(g.Cout <= 256, 0, -1);
+    const long full = tw / WS_NUM_CUS * WS_NUM_CUS, rem = tw - full;
+    const bool can_mix = force != 2 && ws_persist() && ntn == 2 * ntw && full > 0 && rem > 0 && 2 * rem <= WS_NUM_CUS;
+    const double cm = can_mix ? (double)(full / WS_NUM_CUS) * cw1 + cn1 + 8.0 : 1e30;
+    if (cm < 0.97 * cw && cm < cn) {
+        const int rc = go(false, 0, full);
+        return rc ? rc : go(true, 2 * full, 2 * rem);
     }
+    return go(cn < 0.97 * cw, 0, -1);
     // (Measured and dropped: the 128 x 256 tile on FOUR waves of 128 x 64 -- one wave per SIMD with 512 registers, 18 operand
     // reads per 48 matrix instructions instead of 12 per 24: bit-identical, 5-13 % slower on every wide-tile shape of
     // tools/bench_igemm_ws.py; the second wave of a SIMD does cover stalls of the first.)
-    if (!narrow_tiles) { if (pw) WS_GO(2, 2, true); else WS_GO(2, 2, false); }
-    if (pw) WS_GO(2, 1, true); else WS_GO(2, 1, false);
-#undef WS_GO
 }
 
 // ---- entry points: the conv.hip calls with the weight operand given as split planes (u2pl_weight_split3_f32 of the

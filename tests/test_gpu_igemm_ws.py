@@ -39,7 +39,9 @@ CASES = [
     (320, 320, 1, 1, 1, 19, 17, 1, True),       # Cout not a multiple of the tile, rows padded in the split planes
     (64, 256, 1, 1, 1, 40, 40, 1, False),       # K = 64: two chunks (prologue / clamped prefetch only)
     (32, 96, 1, 1, 1, 21, 21, 1, False),        # K = 32: a single chunk
-    (128, 130, 1, 1, 1, 23, 19, 1, True),       # Cout not a multiple of 4: dword result stores
+    (128, 130, 1, 1, 1, 23, 19, 1, True),       # Cout not a multiple of 4
+    (128, 256, 3, 1, 5, 40, 23, 3, False),      # filter-row skipping: tiles that straddle image boundaries, 5 of 40 rows per side
+    (256, 192, 3, 1, 24, 33, 29, 2, True),      # filter-row skipping: r = 0 / r = 2 outside for most tiles, both for none
 ]
 
 

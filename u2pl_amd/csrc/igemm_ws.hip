@@ -211,11 +211,41 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     // +0): stage and register-set parity then restart at every tile and the tile loop below has ONE epilogue instance
     const int nk2 = (nk + 1) & ~1;
     const int n_my = (total_tiles - (int)blockIdx.x + G - 1) / G;      // tiles of this block (>= 1: G <= total_tiles)
+    // Filter-row range of a tile.  A 128-pixel tile covers one or two image rows: where the dilation is a large part of the
+    // map (ASPP: d = 24 / 36 on 97 rows) the filter row r = 0 lies above the image for the top d output rows and r = R - 1
+    // below it for the bottom d -- 16 % / 25 % of those layers' chunks multiply zeros.  A tile runs only the filter rows
+    // [rb, re) that reach the image for at least one of its pixels (the hull, from the tile's first and last pixel: scalar
+    // arithmetic, the same in the three streams); skipped products would have added +-0.
+    const int cpt = g.S * (g.Cin / BK);                     // chunks per filter row
+    auto tile_taps = [&](int mt, int& rb_, int& re_) __attribute__((always_inline)) {
+        rb_ = 0;
+        re_ = g.R;
+        if constexpr (!PW) {
+            if (g.R > 1) {
+                const long mf = (long)mt * BM, ml_ = mf + BM - 1, ml = ml_ < M ? ml_ : M - 1;
+                const unsigned hw = (unsigned)(g.Hout * g.Wout);
+                const unsigned nf = (unsigned)mf / hw, nl = (unsigned)ml / hw;
+                const int hf = (int)(((unsigned)mf - nf * hw) / (unsigned)g.Wout), hl = (int)(((unsigned)ml - nl * hw) / (unsigned)g.Wout);
+                const int lim = g.Hin << g.log2div;
+                auto reach = [&](int r, int ha, int hb) { return hb * g.mul + g.off_h + r * g.step >= 0 && ha * g.mul + g.off_h + r * g.step < lim; };
+                int lo = g.R, hi = -1;
+                for (int r = 0; r < g.R; ++r) {
+                    const bool ok = nf == nl ? reach(r, hf, hl)
+                                             : (reach(r, hf, g.Hout - 1) || reach(r, 0, hl) || (nl > nf + 1 && reach(r, 0, g.Hout - 1)));
+                    if (ok) { lo = r < lo ? r : lo; hi = r; }
+                }
+                if (hi >= 0) { rb_ = lo; re_ = hi + 1; } else { rb_ = 0; re_ = 1; }
+                rb_ = __builtin_amdgcn_readfirstlane(rb_);
+                re_ = __builtin_amdgcn_readfirstlane(re_);
+            }
+        }
+    };
 
     // ---- A load stream (two chunks ahead of the products): its tile, its chunk / tap state, the rows' addresses
     const int kq = tid & 7, r0 = tid >> 3;
     const int ldxb = (int)ldx * 4;
     int a_v = blockIdx.x, a_kc = 0, a_c0 = 0, a_r = 0, a_s = 0;
+    int a_nk = nk, a_nk2 = nk2;                             // chunks of the A stream's tile (filter rows [rb, re) only)
     int bh[RA], bw[RA], nb[RA];
     bool mv[RA];
     int aoff[RA];         // PW: byte offset of the row's first chunk (OOB_OFF for rows past M)
@@ -223,6 +253,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
         int mt, nt, z;
         tile_of(a_v, mt, nt, z);
         rx = make_rsrc(x + (long)__builtin_amdgcn_readfirstlane(z) * zx, xbytes);
+        if constexpr (!PW) {
+            int rb_, re_;
+            tile_taps(mt, rb_, re_);
+            a_r = rb_;
+            a_nk = (re_ - rb_) * cpt;
+            a_nk2 = (a_nk + 1) & ~1;
+        }
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const long m = (long)mt * BM + r0 + RPP * i;
@@ -249,7 +286,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     u32x4 rb[RBU];
     auto load_a_row = [&](auto set_c, auto i_c) __attribute__((always_inline)) {
         constexpr int SET = decltype(set_c)::value, i = decltype(i_c)::value;
-        const bool live = a_kc < nk;
+        const bool live = a_kc < a_nk;
         if constexpr (PW) {
             ra[SET][i] = buf_load4s(rx, live ? aoff[i] : OOB_OFF, a_kc * (BK * 4));
         } else {
@@ -263,7 +300,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     // next chunk of the stream; after a tile's last chunk the next tile of this block; after the last tile: stay (the loads
     // are unconditional -- a load under `if` would be waited for with vmcnt(0) --, what they fetch then is never used)
     auto advance_a = [&]() __attribute__((always_inline)) {
-        if (a_kc + 1 < nk2) {
+        if (a_kc + 1 < a_nk2) {
             ++a_kc;
             a_c0 += BK;
             if (a_c0 == g.Cin) {
@@ -273,7 +310,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
         } else if (a_v + G < total_tiles) {
             a_v += G;
             a_kc = a_c0 = a_r = a_s = 0;
-            a_tile_setup();
+            a_tile_setup();         // (sets a_r to the tile's first filter row)
         }
     };
     auto load_a = [&](auto set_c) __attribute__((always_inline)) {
@@ -291,16 +328,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     }
     const int chunk_b = 3 * Np * WS_ROW_B;                  // bytes per chunk of the split planes
     int b_v = blockIdx.x, b_kc = 0, b_toff = 0;
+    int b_nk = nk, b_nk2 = nk2, b_base = 0;                 // chunks of the B stream's tile, its first chunk in the planes
     auto b_tile_setup = [&]() __attribute__((always_inline)) {
         int mt, nt, z;
         tile_of(b_v, mt, nt, z);
         rw = make_rsrc(ws + (long)__builtin_amdgcn_readfirstlane(z) * zws, wsbytes);
         b_toff = __builtin_amdgcn_readfirstlane(nt * BN * WS_ROW_B);
+        if constexpr (!PW) {
+            int rb_, re_;
+            tile_taps(mt, rb_, re_);
+            b_base = rb_ * cpt;
+            b_nk = (re_ - rb_) * cpt;
+            b_nk2 = (b_nk + 1) & ~1;
+        }
     };
     b_tile_setup();
     auto load_b_unit = [&](auto j_c) __attribute__((always_inline)) {
         constexpr int j = decltype(j_c)::value;
-        rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_kc < nk ? boff[j] : OOB_OFF, b_toff + b_kc * chunk_b, 0);
+        rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_kc < b_nk ? boff[j] : OOB_OFF, b_toff + (b_base + b_kc) * chunk_b, 0);
     };
     // (Measured and dropped: the weight planes by LDS-DMA -- buffer_load_dwordx4 ... lds, a wave copying 1 KB units that are
     // contiguous in the global image and in the stage, no registers, no ds_write.  Bit-identical; with the loads issued in
@@ -309,7 +354,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     // shape of tools/bench_igemm_ws.py was slower: 5880 us against 5615 us for the set.  The builtin form cannot be placed
     // early at all: the compiler orders every LDS access that may alias a pending LDS-DMA behind it with vmcnt(0).)
     auto advance_b = [&]() __attribute__((always_inline)) {
-        if (b_kc + 1 < nk2) ++b_kc;
+        if (b_kc + 1 < b_nk2) ++b_kc;
         else if (b_v + G < total_tiles) {
             b_v += G;
             b_kc = 0;
@@ -529,6 +574,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     //      Store offsets: element (row m, column c) at (m * ldy + c) * 4 in the matrix's descriptor; a row past M lies past the
     //      descriptor's extent (ldy >= Cout) and a column past Cout is given OOB_OFF: the hardware drops both, no compares.
     int c_v = blockIdx.x;
+    int c_nk2 = nk2;                  // chunks (even) of the products' tile
+    auto c_tile_setup = [&]() __attribute__((always_inline)) {
+        if constexpr (!PW) {
+            if (c_v < total_tiles) {
+                int mt, nt, z, rb_, re_;
+                tile_of(c_v, mt, nt, z);
+                tile_taps(mt, rb_, re_);
+                c_nk2 = ((re_ - rb_) * cpt + 1) & ~1;
+            }
+        }
+    };
+    c_tile_setup();
     float* red = (float*)(smem + 2 * ST);   // [4][2][BN] statistics scratch BEHIND the two stages (stage `nxt` already holds the next tile)
 #ifdef U2PL_WS_STAMPS
     int te_n = 0;
@@ -680,6 +737,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
         zero_tail_operands();
         c_v += G;
+        c_tile_setup();
 #ifdef U2PL_WS_STAMPS
         te[3] = __builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -692,7 +750,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     // (the inner loop's back edge comes from the odd chunk only and its entry states -- prologue, end of a tile -- leave the
     // loads in the same order: the compiler merges the wait-counter states at the loop header)
     for (int it = 0; it < n_my; ++it) {
-        for (kc = 0; kc < nk2; kc += 2) {
+        for (kc = 0; kc < c_nk2; kc += 2) {
             chunk(C0{});
             chunk(C1{});
         }

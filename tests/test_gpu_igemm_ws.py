@@ -219,7 +219,7 @@ def test_presplit_rebuilds_every_operand_in_batched_launches_with_the_lazy_paths
         for (i, k), b in lazy.items():
             e = convs[i].weight._u2pl_derived[k]
             assert torch.equal(e["buf"], b), (i, k)
-            assert e["stamp"] == (Kn.WEIGHT_EPOCH[0], convs[i].weight._version, convs[i].weight.data_ptr())
+            assert e["stamp"] == Kn._weight_stamp(convs[i].weight)
         k1 = query("u2pl_kernel_launches")
         y_pre, dx_pre = step()
         assert torch.equal(y_pre, y_lazy) and torch.equal(dx_pre, dx_lazy)
@@ -235,11 +235,26 @@ def test_presplit_rebuilds_every_operand_in_batched_launches_with_the_lazy_paths
         arena.sgd_step([0.05], 0.9, 1e-4)
         for c in convs:
             for e in c.weight._u2pl_derived.values():
-                assert e["stamp"] == (Kn.WEIGHT_EPOCH[0], c.weight._version, c.weight.data_ptr())
+                assert e["stamp"] == Kn._weight_stamp(c.weight)
         y_a, dx_a = step()
         Kn.CONV_WS["on"] = False
         y_b, dx_b = step()
         assert torch.equal(y_a, y_b) and torch.equal(dx_a, dx_b)
+        # another arena's update (the teacher's EMA beside the student's optimizer step) leaves these operands valid
+        Kn.CONV_WS["on"] = True
+        other = Kn.Conv2d(128, 256, 1, bias=False).to(DEV)
+        arena2 = Kn.ParamArena([[other.weight]])
+        with torch.no_grad():
+            other(x)
+        before = {(i, k): e["stamp"] for i, c in enumerate(convs) for k, e in c.weight._u2pl_derived.items()}
+        arena2.grad.normal_(0, 1.0)
+        arena2.sgd_step([0.05], 0.9, 1e-4)
+        assert other.weight._u2pl_derived["f"]["stamp"] == Kn._weight_stamp(other.weight)
+        for (i, k), st in before.items():
+            assert st == Kn._weight_stamp(convs[i].weight) == convs[i].weight._u2pl_derived[k]["stamp"]
+        k3 = query("u2pl_kernel_launches")
+        step()
+        assert query("u2pl_kernel_launches") - k3 == launches_pre
     finally:
         Kn.PRESPLIT["on"] = saved
 

@@ -193,8 +193,18 @@ WEIGHT_EPOCH = [0]
 CONV_WS = {"on": os.environ.get("U2PL_CONV_WS", "1") != "0"}
 
 
-def bump_weight_epoch():
-    WEIGHT_EPOCH[0] += 1
+def bump_weight_epoch(arena=None):
+    """the weights changed through raw pointers: every weight (arena None) or the parameters of one ParamArena (each arena
+    counts its own updates: the student's optimizer step must not invalidate the teacher's operands and vice versa)"""
+    if arena is None:
+        WEIGHT_EPOCH[0] += 1
+    else:
+        arena.epoch[0] += 1
+
+
+def _weight_stamp(weight):
+    ep = getattr(weight, "_u2pl_epoch", None)
+    return (WEIGHT_EPOCH[0], ep[0] if ep is not None else 0, weight._version, weight.data_ptr())
 
 
 def _derived(weight, kind, nbytes, build):
@@ -205,7 +215,7 @@ def _derived(weight, kind, nbytes, build):
     cache = weight.__dict__.get("_u2pl_derived")
     if cache is None:
         cache = weight.__dict__["_u2pl_derived"] = {}
-    stamp = (WEIGHT_EPOCH[0], weight._version, weight.data_ptr())
+    stamp = _weight_stamp(weight)
     ent = cache.get(kind)
     cur = torch.cuda.current_stream()
     if ent is None or ent["buf"].numel() != max(int(nbytes), 16) or ent["buf"].device != weight.device:
@@ -294,7 +304,7 @@ def presplit(params, owner=None):
         cache = w.__dict__.get("_u2pl_derived")
         if not cache:
             continue
-        stamp = (WEIGHT_EPOCH[0], w._version, w.data_ptr())
+        stamp = _weight_stamp(w)
         for kind, ent in cache.items():
             if "spec" in ent and ent["stamp"] is not None and ent["stamp"] != stamp:
                 todo.append((w, ent, stamp))
@@ -1181,7 +1191,9 @@ class ParamArena:
         self.flat = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.n, dtype=torch.float32, device=dev) if with_grad else None
         self._pidx = []
+        self.epoch = [0]            # raw-pointer updates of this arena (see bump_weight_epoch)
         for p, off in zip(self.params, offs):
+            p._u2pl_epoch = self.epoch
             n = p.numel()
             view = self.flat[off:off + n].as_strided(p.shape, p.stride())
             view.copy_(p.data)
@@ -1284,7 +1296,7 @@ class ParamArena:
             self.momentum_buf = torch.zeros_like(self.flat)
         b = self.bounds + [self.n] * 3
         lr = list(lrs) + [lrs[-1]] * 3
-        bump_weight_epoch()
+        bump_weight_epoch(self)
         call("u2pl_sgd_step_f32", self.flat, self.grad, self.momentum_buf, self.n, b[0], b[1], float(lr[0]),
              float(lr[1]), float(lr[2]), float(momentum), float(weight_decay), int(self.steps == 0),
              float(grad_scale))
@@ -1300,7 +1312,7 @@ class ParamArena:
         lr = list(lrs) + [lrs[-1]] * 3
         bc1 = 1.0 - betas[0] ** self.steps
         bc2s = math.sqrt(1.0 - betas[1] ** self.steps)
-        bump_weight_epoch()
+        bump_weight_epoch(self)
         call("u2pl_adam_step_f32", self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.n, b[0], b[1], float(lr[0]),
              float(lr[1]), float(lr[2]), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), float(bc1),
              float(bc2s), float(grad_scale))
@@ -1316,11 +1328,11 @@ class ParamArena:
 
     def ema_from(self, other, decay):
         """self = decay*self + (1-decay)*other  (train_semi.py:543-548)."""
-        bump_weight_epoch()
+        bump_weight_epoch(self)
         call("u2pl_ema_update_f32", self.flat, other.flat, self.n, float(decay), float(1 - decay))
         presplit(self.params, self)
 
     def copy_from(self, other):
-        bump_weight_epoch()
+        bump_weight_epoch(self)
         self.flat.copy_(other.flat)
         presplit(self.params, self)

@@ -284,9 +284,18 @@ def watch_split(rs):
     err = rs.get("err") if isinstance(rs, dict) else None
     if err is None:
         return
-    host = torch.empty(1, dtype=torch.int32).pin_memory()
+    # a small ring of pre-pinned slots and events (a fresh pin_memory() per step is a hipHostMalloc: tens of us and, on some
+    # ROCm versions, an implicit synchronisation -- the opposite of "no stall"); poll_split() keeps at most two copies
+    # outstanding, so a slot that comes round again has long been read
+    ring = _SPLIT_WATCH.get("ring")
+    if ring is None:
+        ring = _SPLIT_WATCH["ring"] = {"slots": [(torch.empty(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+                                                 for _ in range(4)], "next": 0}
+    host, ev = ring["slots"][ring["next"]]
+    ring["next"] = (ring["next"] + 1) % len(ring["slots"])
+    if any(h is host for h, _ in _SPLIT_WATCH["pending"]):      # (cannot happen with <= 2 outstanding; never overwrite an unread slot)
+        poll_split(block=True)
     host.copy_(err, non_blocking=True)
-    ev = torch.cuda.Event()
     ev.record()
     _SPLIT_WATCH["pending"].append((host, ev))
     poll_split()

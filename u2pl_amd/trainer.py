@@ -219,6 +219,16 @@ class SemiTrainer:
     def train_step(self, image_l, label_l, image_u, epoch, cutmix_boxes=None, randint=None, debug=None):
         cfg = self.cfg
         model, teacher = self.model, self.teacher
+        if K._lib.SIDE_WORK:
+            # an exception that escaped the previous step between a ledger entry and its removal (a caller may catch it and
+            # go on): join what the entries stand for and clear them, instead of leaving every later split on the
+            # multi-launch path
+            main_ = torch.cuda.current_stream()
+            side_ = self._side_stream()
+            if side_ is not main_:
+                main_.wait_stream(side_)
+            K.wgrad_stream_sync()
+            K._lib.SIDE_WORK.clear()
         B, h, w = label_l.shape
         lrs = self._lrs()
         i_iter = self.cur_iter - 1

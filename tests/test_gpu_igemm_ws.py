@@ -42,6 +42,8 @@ CASES = [
     (128, 130, 1, 1, 1, 23, 19, 1, True),       # Cout not a multiple of 4
     (128, 256, 3, 1, 5, 40, 23, 3, False),      # filter-row skipping: tiles that straddle image boundaries, 5 of 40 rows per side
     (256, 192, 3, 1, 24, 33, 29, 2, True),      # filter-row skipping: r = 0 / r = 2 outside for most tiles, both for none
+    (512, 256, 1, 1, 1, 140, 140, 2, True),     # 307 wide tiles: the MIXED plan (256 wide + 102 narrow tiles in one launch), pointwise
+    (64, 512, 3, 1, 2, 128, 80, 2, False),      # 320 wide tiles: the mixed plan on the gather kernel (dgrad: 512 -> 64 stays on conv.hip)
 ]
 
 

@@ -159,12 +159,14 @@ __device__ unsigned long long* d_ws_stamps;
 static unsigned long long* g_ws_stamps = nullptr;
 U2PL_API int u2pl_igemm_ws_set_stamp_buffer(void* p) { g_ws_stamps = (unsigned long long*)p; return 0; }
 #endif
+// the kernel body: block `bid` of a group of G persistent blocks that share the tiles [tile0, tile0 + total_tiles) of one
+// tile shape (k_igemm_ws: the whole grid is one group; k_igemm_ws_mix: a wide group and a narrow group in one launch)
 template <int TM, int TN, int WM, int WN, bool PW, int ABL = 0>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
+__device__ __forceinline__ void igemm_ws_body(
     const float* __restrict__ x, long ldx, const unsigned short* __restrict__ ws, const float* __restrict__ bias,
-    float* __restrict__ y, long ldy, ConvGeom g, unsigned xbytes, unsigned wsbytes, unsigned ybytes, unsigned resbytes, int Np,
-    float* __restrict__ stats, const float* __restrict__ pivot, long zx, long zws, long zy, BnEpi epi, int mtiles, int ntiles,
-    int total_tiles, int tile0) {
+    float* __restrict__ y, long ldy, const ConvGeom& g, unsigned xbytes, unsigned wsbytes, unsigned ybytes, unsigned resbytes, int Np,
+    float* __restrict__ stats, const float* __restrict__ pivot, long zx, long zws, long zy, const BnEpi& epi, int mtiles, int ntiles,
+    int total_tiles, int tile0, const int bid, const int G) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
     constexpr int RPP = NT / 8, RA = BM / RPP;              // A: 8 threads x float4 per 32-deep row
     constexpr int UB = 3 * BN * 4, RBU = UB / NT;           // B: 16-byte units per chunk, per thread
@@ -182,7 +184,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     // output of a whole round (33 MB) hit the memory at once.
     // Virtual tile id -> tile: XCD-aware (block b runs on XCD b % 8 and v = b mod 8; each XCD takes a contiguous range of
     // tiles, N tiles fastest so that neighbours in time on one L2 share their A rows).
-    const int G = gridDim.x;
     auto tile_of = [&](int v, int& mt, int& nt, int& z) __attribute__((always_inline)) {
         const int xcd = v & 7, j = v >> 3;
         const int q = total_tiles >> 3, r = total_tiles & 7;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     // chunks per tile, made EVEN (an odd K / 32 gets one all-zero chunk: out-of-range offsets load zeros, the products add
     // +0): stage and register-set parity then restart at every tile and the tile loop below has ONE epilogue instance
     const int nk2 = (nk + 1) & ~1;
-    const int n_my = (total_tiles - (int)blockIdx.x + G - 1) / G;      // tiles of this block (>= 1: G <= total_tiles)
+    const int n_my = (total_tiles - bid + G - 1) / G;      // tiles of this block (>= 1: G <= total_tiles)
     // Filter-row range of a tile.  A 128-pixel tile covers one or two image rows: where the dilation is a large part of the
     // map (ASPP: d = 24 / 36 on 97 rows) the filter row r = 0 lies above the image for the top d output rows and r = R - 1
     // below it for the bottom d -- 16 % / 25 % of those layers' chunks multiply zeros.  A tile runs only the filter rows
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     // ---- A load stream (two chunks ahead of the products): its tile, its chunk / tap state, the rows' addresses
     const int kq = tid & 7, r0 = tid >> 3;
     const int ldxb = (int)ldx * 4;
-    int a_v = blockIdx.x, a_kc = 0, a_c0 = 0, a_r = 0, a_s = 0;
+    int a_v = bid, a_kc = 0, a_c0 = 0, a_r = 0, a_s = 0;
     int a_nk = nk, a_nk2 = nk2;                             // chunks of the A stream's tile (filter rows [rb, re) only)
     int bh[RA], bw[RA], nb[RA];
     bool mv[RA];
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
         blds[j] = A_ST + p * BN * WS_ROW_B + wi * 16;
     }
     const int chunk_b = 3 * Np * WS_ROW_B;                  // bytes per chunk of the split planes
-    int b_v = blockIdx.x, b_kc = 0, b_toff = 0;
+    int b_v = bid, b_kc = 0, b_toff = 0;
     int b_nk = nk, b_nk2 = nk2, b_base = 0;                 // chunks of the B stream's tile, its first chunk in the planes
     auto b_tile_setup = [&]() __attribute__((always_inline)) {
         int mt, nt, z;
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
     //      128-byte row segment per half wave; the LDS-transposed 16-byte stores of conv.hip's epilogue cost ~9k with their drain.)
     //      Store offsets: element (row m, column c) at (m * ldy + c) * 4 in the matrix's descriptor; a row past M lies past the
     //      descriptor's extent (ldy >= Cout) and a column past Cout is given OOB_OFF: the hardware drops both, no compares.
-    int c_v = blockIdx.x;
+    int c_v = bid;
     int c_nk2 = nk2;                  // chunks (even) of the products' tile
     auto c_tile_setup = [&]() __attribute__((always_inline)) {
         if constexpr (!PW) {
@@ -763,6 +764,34 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
 #endif
 }
 
+template <int TM, int TN, int WM, int WN, bool PW, int ABL = 0>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
+    const float* __restrict__ x, long ldx, const unsigned short* __restrict__ ws, const float* __restrict__ bias,
+    float* __restrict__ y, long ldy, ConvGeom g, unsigned xbytes, unsigned wsbytes, unsigned ybytes, unsigned resbytes, int Np,
+    float* __restrict__ stats, const float* __restrict__ pivot, long zx, long zws, long zy, BnEpi epi, int mtiles, int ntiles,
+    int total_tiles, int tile0) {
+    igemm_ws_body<TM, TN, WM, WN, PW, ABL>(x, ldx, ws, bias, y, ldy, g, xbytes, wsbytes, ybytes, resbytes, Np, stats, pivot, zx, zws, zy,
+                                           epi, mtiles, ntiles, total_tiles, tile0, (int)blockIdx.x, (int)gridDim.x);
+}
+// MIXED tile plan in ONE launch: blocks [0, nwide) are the persistent 128 x 256 group over the wide tiles [0, wide_tiles)
+// (whole rounds: wide_tiles is a multiple of nwide), the blocks behind them take ONE 128 x 128 tile each of the remainder
+// (narrow tiles [2 wide_tiles, 2 wide_tiles + narrow_tiles): a narrow tile (z, mt, 2 nt + h) is half h of the wide tile
+// (z, mt, nt)).  A block needs a whole CU's LDS, so the hardware hands the narrow blocks to the CUs as the wide blocks
+// retire -- the remainder round starts without a second launch's drain, gap and cold start (~15 us measured).
+template <bool PW>
+__global__ __launch_bounds__(512, 2) void k_igemm_ws_mix(
+    const float* __restrict__ x, long ldx, const unsigned short* __restrict__ ws, const float* __restrict__ bias,
+    float* __restrict__ y, long ldy, ConvGeom g, unsigned xbytes, unsigned wsbytes, unsigned ybytes, unsigned resbytes, int Np,
+    float* __restrict__ stats, const float* __restrict__ pivot, long zx, long zws, long zy, BnEpi epi, int mtiles, int ntiles_w,
+    int nwide, int wide_tiles, int narrow_tiles) {
+    if ((int)blockIdx.x < nwide)
+        igemm_ws_body<2, 2, 2, 4, PW>(x, ldx, ws, bias, y, ldy, g, xbytes, wsbytes, ybytes, resbytes, Np, stats, pivot, zx, zws, zy, epi,
+                                      mtiles, ntiles_w, wide_tiles, 0, (int)blockIdx.x, nwide);
+    else
+        igemm_ws_body<2, 1, 2, 4, PW>(x, ldx, ws, bias, y, ldy, g, xbytes, wsbytes, ybytes, resbytes, Np, stats, pivot, zx, zws, zy, epi,
+                                      mtiles, 2 * ntiles_w, narrow_tiles, 2 * wide_tiles, (int)blockIdx.x - nwide, (int)gridDim.x - nwide);
+}
+
 #define WS_NUM_CUS 256
 // U2PL_WS_PERSIST = 1 (default): at most one block per CU, each working through its tiles; 0: one block per tile (A/B switch,
 // same results; u2pl_igemm_ws_set_persist returns the previous value)
@@ -813,6 +842,36 @@ static int launch_igemm_ws(const float* x, long ldx, const void* ws, const float
     return 0;
 }
 
+template <bool PW>
+static int launch_igemm_ws_mix(const float* x, long ldx, const void* ws, const float* bias, float* y, long ldy,
+                               const ConvGeom& g, hipStream_t stream, float* stats, const float* pivot, int batch, long zx,
+                               long zy, const BnEpi* epi, long wide_tiles, long narrow_tiles) {
+    const long M = (long)g.N * g.Hout * g.Wout;
+    const int K = g.R * g.S * g.Cin, Np = ws_pad_rows(g.Cout);
+    const BnEpi ep = epi ? *epi : BnEpi{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    const size_t lds = (size_t)2 * 3 * (128 + 256) * WS_ROW_B + (size_t)8 * 256 * sizeof(float);       // the wide body's
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_igemm_ws_mix<PW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const long xb = (((long)g.N * g.Hin * g.Win - 1) * ldx + g.Cin) * 4;
+    const long yb = ((M - 1) * ldy + g.Cout) * 4;
+    const long wsb1 = (long)(K / 32) * 3 * Np * WS_ROW_B;
+    if (xb >= (1L << 31) || wsb1 >= (1L << 31) || yb >= (1L << 31)) return U2PL_EINVAL;
+    if ((batch - 1) * zx * 4 + xb >= (1L << 31) || (batch - 1) * zy * 4 + yb >= (1L << 31) || (long)batch * wsb1 >= (1L << 31))
+        return U2PL_EINVAL;
+    const long resb = ep.res ? ((M - 1) * ep.ldr + g.Cout) * 4 : 0;
+    if (resb >= (1L << 31)) return U2PL_EINVAL;
+    const int mtiles = cdiv(M, 128), ntw = cdiv(g.Cout, 256);
+    if ((long)mtiles * 2 * ntw * batch >= (1L << 30)) return U2PL_EINVAL;
+    U2PL_LAUNCH((k_igemm_ws_mix<PW>), dim3((unsigned)(WS_NUM_CUS + narrow_tiles)), dim3(512), lds, stream, x, ldx,
+                (const unsigned short*)ws, bias, y, ldy, g, (unsigned)xb, (unsigned)wsb1, (unsigned)yb, (unsigned)resb, Np, stats, pivot, zx,
+                wsb1 / 2, zy, ep, mtiles, ntw, WS_NUM_CUS, (int)wide_tiles, (int)narrow_tiles);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
 #ifdef U2PL_WS_ABLATE
 // timing experiments only (a variant build: python -m u2pl_amd.build_ext --variant abl -DU2PL_WS_ABLATE): bit mask of main-loop
 // ingredients to DROP -- 1 split arithmetic, 2 weight-piece stores, 4 activation-piece stores, 8 global loads, 16 operand
@@ -851,8 +910,9 @@ static int run_igemm_ws(const float* x, long ldx, const void* ws, const float* b
     // MIXED: the full rounds as wide tiles and the remainder R <= 128 wide tiles as 2 R narrow ones in a SECOND launch (a
     // persistent block has one tile shape): 792 tiles of a Winograd batch = 3 rounds + 24 tiles cost 3.6 rounds instead of
     // 4; a narrow tile (z, mt, 2 nt + h) is half h of the wide tile (z, mt, nt), so the remainder is a contiguous range of
-    // narrow tile numbers.  Times in units of one 32-deep chunk of a wide tile; 4 / 2 = fixed cost per tile (prologue,
-    // epilogue), 8 = the second launch (drain of the first, launch gap, a cold prologue: ~15 us measured); fitted to
+    // narrow tile numbers.  Both groups run in ONE launch (k_igemm_ws_mix: the narrow blocks are handed to the CUs as the wide
+    // blocks retire); as two launches the plan cost ~15 us more (drain, launch gap, cold prologue: 8 units) and only paid on
+    // long-K layers.  Times in units of one 32-deep chunk of a wide tile; 4 / 2 = fixed cost per tile (prologue, epilogue); fitted to
     // tools/bench_igemm_ws.py: the mixed plan wins on the long-K launches (2048 -> 256 3x3 at 4 x 97^2: 2194 -> 1953 us,
     // 2048 -> 512: 410 -> 394 us) and is not chosen for K = 256 .. 1024, where it measured 0-7 % slower.
     // U2PL_WS_NARROW = 0 (wide only) | 1 (narrow, where Cout <= 256) | 2 (wide / narrow by the model, never mixed) | unset.
@@ -869,8 +929,13 @@ static int run_igemm_ws(const float* x, long ldx, const void* ws, const float* b
     if (force == 1) return go(g.Cout <= 256, 0, -1);
     const long full = tw / WS_NUM_CUS * WS_NUM_CUS, rem = tw - full;
     const bool can_mix = force != 2 && ws_persist() && ntn == 2 * ntw && full > 0 && rem > 0 && 2 * rem <= WS_NUM_CUS;
-    const double cm = can_mix ? (double)(full / WS_NUM_CUS) * cw1 + cn1 + 8.0 : 1e30;
+    static int two_launch = -1;      // U2PL_WS_MIX2=1: the mixed plan as two launches (A/B of the one-launch form)
+    if (two_launch < 0) { const char* e = getenv("U2PL_WS_MIX2"); two_launch = (e && *e) ? (atoi(e) != 0) : 0; }
+    const double cm = can_mix ? (double)(full / WS_NUM_CUS) * cw1 + cn1 + (two_launch ? 8.0 : 2.0) : 1e30;
     if (cm < 0.97 * cw && cm < cn) {
+        if (!two_launch)
+            return pw ? launch_igemm_ws_mix<true>(x, ldx, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi, full, 2 * rem)
+                      : launch_igemm_ws_mix<false>(x, ldx, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi, full, 2 * rem);
         const int rc = go(false, 0, full);
         return rc ? rc : go(true, 2 * full, 2 * rem);
     }

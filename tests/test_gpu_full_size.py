@@ -166,7 +166,7 @@ def _assert_step(r, first):
         return
     assert r["entropy_max_err_vs_port"] <= (3e-4 if first else 1e-3), r       # measured 4e-5 / 9e-5 (step 0), 3.7e-4 / 4.3e-4 (VOC step 1)
     assert r["label_u_diff_vs_reference"] <= (0 if first else 4), r            # measured 0 / 0
-    assert r["target_u_diff_vs_reference"] <= (16 if first else 64), r         # measured 2 / 4 (step 0), 32 / 36 (VOC step 1)
+    assert r["target_u_diff_vs_reference"] <= (8 if first else 64), r          # measured 2 / 4 (step 0; 5 / 4 in round 3), 32 / 36 (VOC step 1): measured + margin
     mask_max = 4 if first else 6                                               # measured 0 (step 0), 1-3 (VOC step 1)
     assert r["low_mask_diff_vs_reference"] <= mask_max and r["high_mask_diff_vs_reference"] <= mask_max, r
     assert r["lbits_diff_vs_reference"] <= 2, r                                # measured 0 everywhere

@@ -145,12 +145,19 @@ def test_train_step_matches_cpu_port(arch, S, conv_mode):
             r.setdefault("err_vs_f64", []).append((float(f"{e_hip:.3g}"), float(f"{e_port:.3g}")))
             kk = 2.0 if conv_mode == 0 else 8.0
             assert e_hip <= kk * e_port + 1e-6 + (2e-4 * max(1.0, abs(c64)) if r["step"] else 0.0), (k_, e_hip, e_port, r)
-            assert abs(a - b) <= 1e-2 * max(1.0, abs(b)), r           # (sanity cap on the raw difference)
+            # ... and an ABSOLUTE bound next to the arbiter-relative one (the relative bound alone scales with how far
+            # the port happens to land from float64).  Direct kernels: round 3's fixed tolerances (2e-3; unsupervised loss 4e-3).
+            # Winograd F(4x4): measured raw differences at step 2: 2.1e-4 / 4.7e-3 / 3.2e-4 absolute = 5e-5 / 2.3e-3 / 3.2e-4
+            # relative to max(1, |loss|) (sup / unsup / contra) -> the same 2e-3 / 2e-3, and 6e-3 for the unsupervised loss.
+            cap = (2e-3, 4e-3 if conv_mode == 0 else 6e-3, 2e-3)[k_]
+            assert abs(a - b) <= cap * max(1.0, abs(b)), (k_, cap, r)
         # the unsupervised loss of OUR logits over the PORT's pixel set: separates "which pixels survive the percentile
-        # threshold" from "what the logits are" (step 0: the north_star tolerance; later steps: reported)
+        # threshold" from "what the logits are" (step 0: the north_star tolerance; later steps: the fixed unsupervised-loss bound)
         b = r["ref"][1]
         if r["step"] == 0:
             assert abs(r["unsup_same_px"] - b) <= 1e-4 * max(1.0, abs(b)), r
+        else:   # same fixed bound as the unsupervised loss itself (re-instated)
+            assert abs(r["unsup_same_px"] - b) <= (4e-3 if conv_mode == 0 else 6e-3) * max(1.0, abs(b)), r
         print("vs f64 (hip, port) per loss:", r["step"], r["err_vs_f64"])
         if r["step"] == 0 and conv_mode == 0:
             # identical weights, all-direct fp32 kernel: every label / target / reliability mask is bit-exact

@@ -11,9 +11,14 @@ def bf16_rne(x):
     return (r & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
 
 
+BF16_MAX = np.float32(3.3895313892515355e38)      # 0x7F7F0000
+
+
 def split3(x):
     x = np.asarray(x, dtype=np.float32)
-    x0 = bf16_rne(x)
+    # first piece: the conversion's overflow is taken out (conv_geom.h: clamp_bf16 / pack2_bf16_first) -- a finite |x| above
+    # the largest bf16 would round to Inf and make the residual NaN
+    x0 = bf16_rne(np.clip(x, -BF16_MAX, BF16_MAX))
     r1 = (x - x0).astype(np.float32)          # exact in fp32
     x1 = bf16_rne(r1)
     r2 = (r1 - x1).astype(np.float32)         # exact in fp32
@@ -66,3 +71,16 @@ def test_six_piece_products_give_an_fp32_class_dot_product():
     for pa, pb in ((a2, b0), (a0, b2), (a1, b0), (a0, b1), (a0, b0)):
         acc5 += np.einsum("mk,mk->m", pa.astype(np.float64), pb.astype(np.float64))
     assert np.abs(acc5 - ref).max() / scale > 4 * e_split
+
+
+def test_split_is_exact_for_finite_values_above_the_largest_bfloat16():
+    """3.3895e38 < |x| <= 3.4028e38: plain bf16(x) is +-Inf for the upper half of that range; with the clamp the first piece
+    is +-bf16max and the other two carry the rest exactly"""
+    fmax = np.finfo(np.float32).max
+    x = np.float32([fmax, -fmax, np.nextafter(BF16_MAX, np.float32(np.inf)), 3.395e38, -3.399e38, 3.40e38, BF16_MAX, -BF16_MAX])
+    assert np.isinf(bf16_rne(x[:2])).all()                                    # what the unguarded conversion does
+    x0, x1, x2, r1, r2 = split3(x)
+    assert np.isfinite(x0).all() and np.isfinite(x1).all() and np.isfinite(x2).all()
+    assert np.array_equal(np.abs(x0), np.full(len(x), BF16_MAX))
+    total = x0.astype(np.float64) + x1.astype(np.float64) + x2.astype(np.float64)
+    assert np.array_equal(total, x.astype(np.float64))

@@ -781,7 +781,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_bf16(const float* __restr
         }
     };
     auto put1 = [&](unsigned short* d, long pl, float a, float b) {     // one channel row, pixels 2pp and 2pp+1
-        const unsigned w0 = pack2_bf16(a, b);
+        const unsigned w0 = SP == 3 ? pack2_bf16_first(a, b) : pack2_bf16(a, b);
         *(unsigned*)d = w0;
         if (SP == 3) {
             const float a1 = a - bf16_lo_f(w0), b1 = b - bf16_hi_f(w0);

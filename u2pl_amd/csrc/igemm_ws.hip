@@ -519,7 +519,8 @@ __device__ __forceinline__ void igemm_ws_body(
                 unsigned w;
                 if constexpr (ABL & 1) w = (__float_as_uint(sp_h) & 0xffff0000u) | (__float_as_uint(sp_l) >> 16);
                 else {
-                    w = pack2_bf16(sp_l, sp_h);
+                    if constexpr (step == 0) w = pack2_bf16_first(sp_l, sp_h);      // (first piece: overflow guard, conv_geom.h)
+                    else w = pack2_bf16(sp_l, sp_h);
                     if constexpr (step < 2) {
                         sp_l = sp_l - bf16_lo_f(w);
                         sp_h = sp_h - bf16_hi_f(w);
@@ -819,11 +820,9 @@ static int launch_igemm_ws(const float* x, long ldx, const void* ws, const float
     const long xb = (((long)g.N * g.Hin * g.Win - 1) * ldx + g.Cin) * 4;
     const long yb = ((M - 1) * ldy + g.Cout) * 4;
     const long wsb1 = (long)(K / 32) * 3 * Np * WS_ROW_B;           // one matrix
-    // every tensor of the batch within 2 GiB: 32-bit byte offsets (per-matrix extents in the descriptors, the batch stride in
-    // the scalar offset)
+    // every MATRIX of the batch within 2 GiB (32-bit byte offsets inside a matrix); the batch itself may be larger: the kernel
+    // rebuilds the buffer descriptors per matrix from a 64-bit base (x + z * zx, ws + z * zws, y + z * zy)
     if (xb >= (1L << 31) || wsb1 >= (1L << 31) || yb >= (1L << 31)) return U2PL_EINVAL;
-    if ((batch - 1) * zx * 4 + xb >= (1L << 31) || (batch - 1) * zy * 4 + yb >= (1L << 31) || (long)batch * wsb1 >= (1L << 31))
-        return U2PL_EINVAL;
     const long resb = ep.res ? ((M - 1) * ep.ldr + g.Cout) * 4 : 0;
     if (resb >= (1L << 31)) return U2PL_EINVAL;
     const int mtiles = cdiv(M, BM), ntiles = cdiv(g.Cout, BN);
@@ -859,8 +858,6 @@ static int launch_igemm_ws_mix(const float* x, long ldx, const void* ws, const f
     const long yb = ((M - 1) * ldy + g.Cout) * 4;
     const long wsb1 = (long)(K / 32) * 3 * Np * WS_ROW_B;
     if (xb >= (1L << 31) || wsb1 >= (1L << 31) || yb >= (1L << 31)) return U2PL_EINVAL;
-    if ((batch - 1) * zx * 4 + xb >= (1L << 31) || (batch - 1) * zy * 4 + yb >= (1L << 31) || (long)batch * wsb1 >= (1L << 31))
-        return U2PL_EINVAL;
     const long resb = ep.res ? ((M - 1) * ep.ldr + g.Cout) * 4 : 0;
     if (resb >= (1L << 31)) return U2PL_EINVAL;
     const int mtiles = cdiv(M, 128), ntw = cdiv(g.Cout, 256);

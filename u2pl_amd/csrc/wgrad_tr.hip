@@ -215,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_tr(const float* __restrict__ d
                         sp_l = (k & 1) ? v.z : v.x;
                         sp_h = (k & 1) ? v.w : v.y;
                     }
-                    const unsigned w = pack2_bf16(sp_l, sp_h);
+                    const unsigned w = step == 0 ? pack2_bf16_first(sp_l, sp_h) : pack2_bf16(sp_l, sp_h);
                     if constexpr (step < 2) {
                         sp_l = sp_l - bf16_lo_f(w);
                         sp_h = sp_h - bf16_hi_f(w);

@@ -44,6 +44,8 @@ def parse():
                     help="BASELINE configs[4] (config 5): student convolutions on the bf16 matrix cores (fp32 accumulate, fp32 "
                          "master weights, fp32 EMA teacher); a SEPARATE line, never the headline (use with --crop 801)")
     ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--no-direct-leg", action="store_true", help="skip ms_per_step_direct / conv_error_vs_f64 (N = 1 only)")
+    ap.add_argument("--no-config5-leg", action="store_true", help="skip the short BASELINE configs[4] leg (801x801, bf16 student)")
     return ap.parse_args()
 
 
@@ -98,33 +100,77 @@ def calibrate(model, teacher, calib, batches, sharpen):
     return out
 
 
-_WD = {"timer": None, "phase": "setup", "step": -1}
+_WD = {"thread": None, "phase": "setup", "step": -1, "last": time.time(), "done": False, "t_timed": None, "steps_done": 0}
+
+
+def _progress(phase=None, step=None):
+    """every phase change and every step is progress: the watchdog measures the time since the LAST one"""
+    if phase is not None:
+        _WD["phase"] = phase
+    if step is not None:
+        _WD["step"] = step
+    _WD["last"] = time.time()
 
 
 def _watchdog_arm(args, rank, world):
-    """If the run has not finished after U2PL_BENCH_WATCHDOG_S seconds (default 900; multi-GPU runs only), print ONE JSON line
-    that says where it stopped -- phase, step, collectives issued by this rank, the communicator configuration -- and exit:
-    a hang (e.g. a collective order mismatch on RCCL) then costs minutes, not the whole lease, and leaves a record."""
+    """If the run makes no progress (no phase change, no completed step) for U2PL_BENCH_WATCHDOG_S seconds (default 600;
+    multi-GPU runs only), EVERY stuck rank prints ONE JSON line that says where it stopped -- phase, step, its own ms per step
+    over the timed steps it did complete, collectives issued, the communicator configuration -- and exits: a hang (e.g. a
+    collective order mismatch on RCCL) then costs minutes, not the whole lease, and leaves a record.  A healthy but long
+    run (first-time build, long diagnostics) is not killed: the limit applies to the time since the last progress mark."""
     import threading
     if world <= 1:
         return
+    limit = float(os.environ.get("U2PL_BENCH_WATCHDOG_S", "600"))
 
-    def fire():
-        from u2pl_amd import nn as KN
-        line = {"metric": "train images/sec at 769x769 (R101-DeepLabv3+)", "value": None, "unit": "images/s", "n_gpus": world,
-                "error": "watchdog: no progress", "rank": rank, "phase": _WD["phase"], "step": _WD["step"],
-                "collectives_issued_by_this_rank": KN.COMM_DEBUG["issued"], "comm_stats": dict(KN.COMM_STATS),
-                "teacher_communicator": os.environ.get("U2PL_TEACHER_COMM", "0"),
-                "bucket_overlap": os.environ.get("U2PL_NO_BUCKET_OVERLAP") is None,
-                "hint": "rerun with U2PL_COMM_DEBUG=1 (per-step comparison of the ranks' collective sequences) and "
-                        "U2PL_NO_BUCKET_OVERLAP=1 (all gradient buckets after backward)"}
-        print(json.dumps(line), flush=True)
-        os._exit(3)
+    def watch():
+        while not _WD["done"]:
+            time.sleep(2.0)
+            if _WD["done"] or time.time() - _WD["last"] <= limit:
+                continue
+            from u2pl_amd import nn as KN
+            so_far = None
+            if _WD["t_timed"] is not None and _WD["steps_done"] > 0:
+                so_far = round((_WD["t_steps_end"] - _WD["t_timed"]) / _WD["steps_done"] * 1e3, 3)
+            line = {"metric": "train images/sec at 769x769 (R101-DeepLabv3+)", "value": None, "unit": "images/s", "n_gpus": world,
+                    "error": "watchdog: no progress for %.0f s" % (time.time() - _WD["last"]), "rank": rank, "phase": _WD["phase"],
+                    "step": _WD["step"], "timed_steps_completed_by_this_rank": _WD["steps_done"],
+                    "per_rank_ms": {str(rank): so_far}, "comm_exposed_ms": None,
+                    "collectives_issued_by_this_rank": KN.COMM_DEBUG["issued"], "comm_stats": dict(KN.COMM_STATS),
+                    "teacher_communicator": os.environ.get("U2PL_TEACHER_COMM", "0"),
+                    "bucket_overlap": os.environ.get("U2PL_NO_BUCKET_OVERLAP") is None,
+                    "hint": "rerun with U2PL_COMM_DEBUG=1 (per-step comparison of the ranks' collective sequences) and "
+                            "U2PL_NO_BUCKET_OVERLAP=1 (all gradient buckets after backward)"}
+            # ONE line on stdout (rank 0's, the one the driver parses); the other ranks report on stderr
+            print(json.dumps(line), flush=True, file=sys.stdout if rank == 0 else sys.stderr)
+            os._exit(3)
 
-    t = threading.Timer(float(os.environ.get("U2PL_BENCH_WATCHDOG_S", "900")), fire)
-    t.daemon = True
+    t = threading.Thread(target=watch, daemon=True)
     t.start()
-    _WD["timer"] = t
+    _WD["thread"] = t
+
+
+def wino_vs_direct_error(dev):
+    """measured accuracy side of the Winograd / direct trade: the step's most frequent 3x3 layer
+    (layer3: 256 -> 256, dilation 2, 97 x 97 maps) through both algorithms against a float64 convolution on the host"""
+    import torch.nn.functional as F
+    from u2pl_amd import nn as KN
+    saved = dict(KN.CONV_ALGO)
+    g = torch.Generator(device=dev).manual_seed(11)
+    conv = KN.Conv2d(256, 256, 3, padding=2, dilation=2, bias=False).to(dev)
+    x = torch.randn(1, 256, 97, 97, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+    ref = F.conv2d(x.double().cpu(), conv.weight.detach().double().cpu(), padding=2, dilation=2)
+    out = {}
+    try:
+        for name, w in (("winograd_f4", 4), ("direct", 0)):
+            KN.CONV_ALGO.update(wino=w)
+            with torch.no_grad():
+                y = conv(x)
+            out[name] = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
+    finally:
+        KN.CONV_ALGO.update(saved)
+    return {"layer": "3x3 256->256 d=2 @97x97 (layer3 conv2)", "max_err_over_max_vs_f64": {k: float("%.3g" % v) for k, v in out.items()},
+            "winograd_over_direct": round(out["winograd_f4"] / max(out["direct"], 1e-30), 2)}
 
 
 def main():
@@ -196,10 +242,10 @@ def main():
 
     def step(i):
         il, ll, iu = batches[i % len(batches)]
-        _WD["step"] = i
+        _progress(step=i)
         return trainer.train_step(il, ll, iu, epoch=0)
 
-    _WD["phase"] = "warmup"
+    _progress("warmup")
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -214,25 +260,34 @@ def main():
     torch.cuda.synchronize()
     comm0 = dict(KN.COMM_STATS)
     route0 = HO.split_route_stats()
-    _WD["phase"] = "timed"
+    _progress("timed")
     t0 = time.perf_counter()
+    _WD["t_timed"] = _WD["t_steps_end"] = time.time()
     host_s = 0.0       # time the Python thread spends inside train_step (enqueue + the step's one blocking read)
     for i in range(args.steps):
         th = time.perf_counter()
         meters = step(args.warmup + i)
         host_s += time.perf_counter() - th
+        _WD["steps_done"], _WD["t_steps_end"] = i + 1, time.time()
     host_tail = time.perf_counter()
     torch.cuda.synchronize()
     host_tail = time.perf_counter() - host_tail      # GPU work still queued when the host left the last step
+    own_dt = time.perf_counter() - t0                # this rank alone: its K steps + its own queue drained, before the barrier
+    _progress("timed-barrier")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    per_rank_ms = [round(own_dt / args.steps * 1e3, 3)]
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        own = torch.tensor([own_dt / args.steps * 1e3], device=dev, dtype=torch.float64)
+        allv = [torch.empty_like(own) for _ in range(world)]
+        dist.all_gather(allv, own)
+        per_rank_ms = [round(float(v), 3) for v in allv]
     dt = float(tt)
-    _WD["phase"] = "diagnostics"
+    _progress("diagnostics")
     ms = dt / args.steps * 1e3
     imgs = world * 2 * args.batch
     value = imgs / (ms / 1e3)
@@ -253,6 +308,7 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        _progress()
         tb = torch.tensor([time.perf_counter() - ta], device=dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(tb, op=dist.ReduceOp.MAX)
@@ -266,9 +322,40 @@ def main():
         del os.environ["U2PL_NO_BUCKET_OVERLAP"]
         diag["comm_exposed_ms"] = round(diag["ms_per_step_no_bucket_overlap"] - ms, 3)
 
+    diag["per_rank_ms"] = per_rank_ms       # each rank's own K steps + queue drain, before the closing barrier (max = the headline's clock)
+    if world == 1:
+        diag["comm_exposed_ms"] = 0.0
+    # per-phase time (the reference's meters: train_semi.py:563-587): ONE extra step with the side streams folded
+    # into the main stream (teacher passes, weight gradients) and an event at every phase boundary.  Serialised, the phases
+    # add up to more than the overlapped step (`phase_sum_ms` vs `ms_per_step`): what the side streams hide is the difference.
+    KNp = KN
+    trainer.train_step(*batches[0], epoch=0)     # (warm: same allocator / operand state as the timed steps)
+    torch.cuda.synchronize()
+    saved_side, saved_wg = getattr(trainer, "_side", None), KNp._WGRAD["enabled"]
+    trainer._side, KNp._WGRAD["enabled"] = torch.cuda.current_stream(), False
+    try:
+        trainer.phase_log = []
+        trainer.train_step(*batches[1 % len(batches)], epoch=0)
+        torch.cuda.synchronize()
+        log = trainer.phase_log
+    finally:
+        trainer.phase_log = None
+        trainer._side, KNp._WGRAD["enabled"] = saved_side, saved_wg
+    phase_ms = {b[0]: round(a[1].elapsed_time(b[1]), 3) for a, b in zip(log[:-1], log[1:])}
+    diag["phase_ms"] = dict(phase_ms, comm_exposed=diag.get("comm_exposed_ms"))
+    diag["phase_sum_ms"] = round(sum(phase_ms.values()), 3)
+    diag["phase_ms_note"] = ("one extra step serialised on ONE stream (teacher passes and weight gradients folded into the main stream), "
+                             "HIP events at the phase boundaries; teacher_eval = pseudo-label pass + CutMix, student_fwd includes the "
+                             "supervised loss heads, contrastive = unsupervised CE + bank + InfoNCE forward, bwd = whole backward incl. "
+                             "weight gradients [+ bucket all-reduce launches], opt_ema = all-reduce join + SGD + EMA + operand re-split")
+    _progress()
+    if world > 1:
+        dist.barrier()
+
     # the roofline leg runs ONE extra (un-timed) step with per-call HIP events; it contains the step's
     # collectives, so every rank executes it
     roof = RL.measure(trainer, batches[0], args, ms)
+    _progress()
     if world > 1:
         dist.barrier()
     if not args.no_calibrate:
@@ -278,6 +365,19 @@ def main():
         diag["ms_step_lr0.01"] = round(timed_steps(1, 0), 3)
         trainer.base_lr = 1e-6
     wt = KN.CONV_ALGO["wino"]
+    if wt in (2, 4) and not args.bf16 and world == 1 and not args.no_direct_leg:
+        # the accuracy / speed trade of the default algorithm, in the line itself: the SAME workload with
+        # every 3x3 layer on the direct implicit-GEMM kernel (U2PL_CONV_WINO=0), and both algorithms' error against float64
+        KN.CONV_ALGO["wino"] = 0
+        try:
+            step(0)                              # builds the direct kernels' operands (3x3 split planes), un-timed
+            diag["ms_per_step_direct"] = round(timed_steps(3, 1), 3)
+        finally:
+            KN.CONV_ALGO["wino"] = wt
+        step(0)
+        torch.cuda.synchronize()
+        diag["conv_error_vs_f64"] = wino_vs_direct_error(dev)
+        _progress()
     conv_algo = ("student: bf16-operand implicit GEMM on v_mfma_f32_32x32x16_bf16 (fwd, dgrad, wgrad; direct, no Winograd); "
                  "teacher: fp32 as in the headline" if args.bf16 else
                  "fp32 implicit GEMM for every layer (U2PL_CONV_WINO=0)" if wt not in (2, 4) else
@@ -333,7 +433,25 @@ def main():
                     "images_per_s": round(rt["reference_images_per_s"], 5), "cores": rt["cores"], "file": "profiles/" + os.path.basename(ref_t),
                     "note": "the reference's own train_semi.train() through oracle/ref_shim.py, 1 warm-up + 2 timed steps, "
                             "same configuration; /root/reference does not exist on the GPU box"}
+        if world == 1 and not args.bf16 and not args.no_config5_leg and args.crop == 769:
+            # BASELINE configs[4] ("config 5": 801x801, reduced-precision student, fp32 EMA teacher) as a short leg of the default
+            # run, so that the driver's line carries it; own process, after the headline measurement
+            import subprocess
+            try:
+                r5 = subprocess.run([sys.executable, os.path.abspath(__file__), "--bf16", "--crop", "801", "--steps", "4", "--warmup", "2",
+                                     "--no-cpu-baseline", "--no-config5-leg"], capture_output=True, text=True, timeout=600)
+                l5 = [ln for ln in r5.stdout.splitlines() if ln.startswith("{")]
+                j5 = json.loads(l5[-1])
+                out["config5"] = {"images_per_s": j5["value"], "ms_per_step": j5["ms_per_step"], "crop": 801, "steps": j5["steps"],
+                                  "warmup": j5["warmup"], "dtype": j5["dtype"], "conv_algo": j5["config"]["conv_algo"],
+                                  "roofline_bf16": j5.get("roofline_bf16"),
+                                  "note": "python bench.py --bf16 --crop 801: student conv operands rounded to bf16 while staged into LDS "
+                                          "(bf16 matrix cores, fp32 accumulate), activations still fp32 in HBM; teacher as in the headline"}
+            except Exception as e:      # the leg must never cost the headline line
+                out["config5"] = {"error": repr(e)[:300]}
+        _WD["done"] = True
         print(json.dumps(out))
+    _WD["done"] = True
     if world > 1:
         dist.destroy_process_group()
 

@@ -517,7 +517,7 @@ def _pack_classbits(onehot):
 
 
 def _run_reference_train(ns, cfg, data, steps, epochs_run, voc, init_seed=0, np_seed=31, torch_seed=41, p_drop=0.0,
-                         dropout_seed=None, sharpen=None, capture=None, threads=None, ddp=False):
+                         dropout_seed=None, sharpen=None, capture=None, threads=None, ddp=False, perturb=None):
     """Drive the reference's OWN train() (train_semi.py:234-594) over `data` (list of (il, ll, iu), `steps` per epoch
     in `epochs_run`) with fake loaders, plain BN and a gloo world of 1.  Dropout: p_drop = 0, or p = 0.1 with the
     keep-masks of oracle/parity_dropout.KeyedMasks(dropout_seed) (nn.Dropout2d.forward patched at run time; no
@@ -538,6 +538,11 @@ def _run_reference_train(ns, cfg, data, steps, epochs_run, voc, init_seed=0, np_
     if sharpen:
         with torch.no_grad():
             model.decoder.classifier[8].weight.mul_(sharpen)
+    if perturb:     # (noise-floor runs of the mIoU gate: the initial weights moved by a relative N(0, perturb) each)
+        gp = torch.Generator().manual_seed(99)
+        with torch.no_grad():
+            for p_ in model.parameters():
+                p_.mul_(1 + perturb * torch.randn(p_.shape, generator=gp))
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     teacher = ns.model_helper.ModelBuilder(copy.deepcopy(cfg["net"]))
     teacher.load_state_dict(sd)
@@ -793,6 +798,77 @@ def gen_train_full(ns, tag):
     save("train_full_" + tag, **fx)
 
 
+def _reference_validate(ns, cfg, model, val_batches):
+    """the reference's own validate() (train_semi.py:595-654) over in-memory batches -> (mIoU, per-class IoU)"""
+    import logging
+
+    ts = _load_ref_train_semi()
+    ts.cfg = cfg
+    got = {}
+
+    class _Meter(ts.AverageMeter):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            got.setdefault("meters", []).append(self)
+
+    ts.AverageMeter = _Meter
+
+    class _Loader:
+        class sampler:
+            @staticmethod
+            def set_epoch(e):
+                pass
+
+        def __iter__(self):
+            return iter(val_batches)
+
+    miou = ts.validate(model, _Loader(), 0, logging.getLogger("gen_golden"))
+    inter, union = got["meters"][0], got["meters"][1]
+    return float(miou), inter.sum / (union.sum + 1e-10)
+
+
+def gen_miou_gate(ns, steps=None, tag="miou_gate", noise_floor=True):
+    """north_star gate: "mIoU on a fixed 50-image val subset within +-0.3 of the CPU reference after 1 epoch".  The
+    REFERENCE's own train() (train_semi.py:234-592) runs one epoch (40 steps, R101, 193x193, 2 + 2 images, OHEM + aux,
+    CutMix, contrastive bank, dropout ON with keyed masks) on the learnable synthetic task of tests/miou_gate.py from its
+    own seeded initialisation, then its own validate() (train_semi.py:595-654) scores the EMA teacher on the 50
+    validation images.  Also stored: the mIoU of the initial weights (the gate asserts that training moved it), the
+    per-step losses, and a NOISE-FLOOR run -- the same epoch from initial weights perturbed by 1e-7 relative (one fp32
+    rounding): what two fp32 implementations of the same step may legitimately differ by after 40 chaotic steps."""
+    import copy
+    import time
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    import miou_gate as MG
+
+    G = dict(MG.GATE)
+    if steps:
+        G["steps"] = steps
+    cfg = _train_cfg(False, G["arch"], G["C"], min_kept=G["min_kept"], class_thr=G["class_thr"], epochs=G["epochs"])
+    data = MG.gate_data(G["data_seed"], G["steps"], G["B"], G["S"])
+    val = MG.gate_val(G["data_seed"] + 1, G["n_val"], G["S"])
+    fx = dict(digest=MG.data_digest(data, val), steps=np.int64(G["steps"]),
+              seeds=np.array([G["init_seed"], G["data_seed"], G["np_seed"], G["torch_seed"], G["dropout_seed"]]))
+    runs = [("", None)] + ([("noise_", 1e-7)] if noise_floor else [])
+    for pre, perturb in runs:
+        t0 = time.time()
+        r = _run_reference_train(ns, copy.deepcopy(cfg), data, G["steps"], [0], False, init_seed=G["init_seed"],
+                                 np_seed=G["np_seed"], torch_seed=G["torch_seed"], p_drop=0.1, dropout_seed=G["dropout_seed"],
+                                 perturb=perturb)
+        t1 = time.time()
+        if not pre:
+            init = ns.model_helper.ModelBuilder(copy.deepcopy(cfg["net"]))
+            init.load_state_dict(r["sd"])
+            fx["miou_init"], fx["iou_init"] = _reference_validate(ns, cfg, init, val)
+        miou_t, iou_t = _reference_validate(ns, cfg, r["teacher"], val)
+        miou_s, iou_s = _reference_validate(ns, cfg, r["model"], val)
+        fx.update({pre + "miou_teacher": miou_t, pre + "iou_teacher": iou_t, pre + "miou_student": miou_s,
+                   pre + "iou_student": iou_s, pre + "meters": r["meters"],
+                   pre + "bank_len": np.array([m[0].shape[0] for m in r["memobank"]])})
+        print(tag, pre or "reference", "train %.0f s" % (t1 - t0), "mIoU init %.2f teacher %.2f student %.2f" %
+              (100 * float(fx["miou_init"]), 100 * miou_t, 100 * miou_s), "last losses", r["meters"][-1, 1:5], flush=True)
+    save(tag, **fx)
+
+
 def gen_resample(ns):
     """reference city_dset.__init__ (cityscapes.py:18-33): the seeded random.sample of the (tiled) list, both
     regimes (list longer / shorter than n_sup)."""
@@ -993,6 +1069,10 @@ def main():
     for tag in FULL_SIZE:
         if ("full_" + tag) in which or "full" in which:     # minutes of CPU each: only on request
             gen_train_full(ns, tag)
+    if "miou_gate" in which:      # ~10 minutes of CPU (two 40-step R101 epochs at 193^2): only on request
+        gen_miou_gate(ns)
+    if "miou_gate_try" in which:  # quick look at the task (8 steps, no noise-floor run, scratch fixture name)
+        gen_miou_gate(ns, steps=int(os.environ.get("GATE_STEPS", "8")), tag="_miou_gate_try", noise_floor=False)
     if want("resample"):
         gen_resample(ns)
     if want("augment"):

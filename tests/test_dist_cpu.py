@@ -206,3 +206,85 @@ def test_comm_sequence_check_accepts_equal_and_reports_differing_orders():
     assert r0[0] and r1[0]
     for r in (r0, r1):
         assert r[1] is not None and "rank 1 differs from rank 0 at #0" in r[1] and "bucket_allreduce" in r[1]
+
+
+# ---- world 8: order bugs that need more than two ranks to show ----------------------------------------
+W8_LENGTHS = ([3, 0, 5, 0, 0, 7, 1, 2], [0, 0, 0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0, 0, 9], [4, 4, 4, 4, 4, 4, 4, 4], [0, 11, 0, 2, 6, 0, 0, 1])
+
+
+def _gather8_case(rank, world):
+    from u2pl_amd import nn as K
+    from u2pl_amd.utils.utils import dequeue_and_enqueue, gather_keys
+
+    K.COMM_DEBUG["on"] = True
+    K.COMM_DEBUG["log"].clear()
+    g = torch.Generator().manual_seed(100 + rank)
+    outs = []
+    queue, ptr = [torch.zeros(0, 4)], torch.zeros(1, dtype=torch.long)
+    for n in W8_LENGTHS:
+        keys = torch.rand(n[rank], 4, generator=g) + 10 * rank          # rows of rank r lie in [10 r, 10 r + 1)
+        outs.append(gather_keys(keys).numpy())
+        dequeue_and_enqueue(keys, queue, ptr, 25)
+    ok = K.check_comm_sequence()        # a rank with zero keys must still take part in both all-gathers of every call
+    K.COMM_DEBUG["on"] = False
+    return outs, queue[0].numpy(), int(ptr[0]), ok
+
+
+def test_world8_gather_keys_is_rank_major_with_empty_ranks_and_banks_stay_replicated():
+    res = _run(_gather8_case, world=8)
+    o0, q0, p0, _ = res[0]
+    for o, q, p, ok in res:
+        assert ok and p == p0 and np.array_equal(q, q0)
+        for a, b in zip(o, o0):
+            assert np.array_equal(a, b)
+    for lens, got in zip(W8_LENGTHS, o0):
+        if sum(lens) == 0:
+            continue          # (all ranks empty: gather_keys hands the local empty block back)
+        assert got.shape[0] == sum(lens)
+        owner = np.floor(got[:, 0] / 10).astype(int)
+        assert owner.tolist() == [r for r, n in enumerate(lens) for _ in range(n)]      # rank-major, each rank's rows in order
+    assert q0.shape[0] == 25
+
+
+def _bucket8_case(rank, world):
+    """the bucketed gradient all-reduce under 8 ranks whose gradients become ready in a DIFFERENT order on every rank (and one
+    rank-dependent parameter never reports): every rank must issue the same collective sequence and end with the flat sum"""
+    os.environ["U2PL_BUCKET_MB"] = "0.002"
+    from u2pl_amd import nn as K
+    K.COMM_DEBUG["on"] = True
+    K.COMM_DEBUG["log"].clear()
+    g = torch.Generator().manual_seed(7)
+    shapes = [(64, 3, 3, 3), (64,), (64,), (128, 64, 1, 1), (128,), (300,), (19, 128, 1, 1), (19,), (700,), (33,)]
+    params = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    arena = K.ParamArena([params[:5], params[5:]])
+    out = []
+    for step in range(2):
+        arena.zero_grad()
+        gs = torch.Generator().manual_seed(100 * step + rank)
+        for p in params:
+            p._u2pl_grad.add_(torch.randn(p.shape, generator=gs))
+        local = arena.grad.clone()
+        order = torch.randperm(len(params), generator=gs).tolist()
+        silent = rank % len(params)
+        for i in order:
+            if i != silent:
+                K._mark_ready(params[i]._u2pl_grad)
+        arena.finish_allreduce()
+        ref = local.clone()
+        dist.all_reduce(ref)
+        same_seq = K.check_comm_sequence()
+        # (a ring all-reduce over 8 ranks adds an element's 8 terms in an order that depends on the element's position in the
+        # buffer: bucketed and flat sums agree to fp32 rounding, not bit for bit as with 2 ranks; what must hold bit for bit is
+        # that every rank ends with the SAME gradient)
+        out.append((bool(torch.allclose(arena.grad, ref, rtol=1e-5, atol=1e-5)), same_seq, arena.grad.double().sum().item(),
+                    arena.grad.double().abs().sum().item()))
+    K.COMM_DEBUG["on"] = False
+    return out
+
+
+def test_world8_bucket_sequence_is_rank_independent():
+    res = _run(_bucket8_case, world=8)
+    for r in res:
+        for (same, same_seq, s1, s2), (_, _, t1, t2) in zip(r, res[0]):
+            assert same and same_seq
+            assert s1 == t1 and s2 == t2          # replicas stay bit-identical

@@ -74,15 +74,15 @@ def test_syncbn_two_ranks_equals_full_batch_bn():
     assert np.abs(r0["dgamma_local"] + r1["dgamma_local"] - r0["dgamma_ref"]).max() < 2e-3
 
 
-def _train_case(rank, world):
+def _train_case(rank, world, S=97, steps=3):
     from u2pl_amd import configs
     from u2pl_amd.models.model_helper import ModelBuilder
     from u2pl_amd.trainer import SemiTrainer
     from u2pl_amd.utils.loss_helper import get_criterion
     torch.manual_seed(2)
     np.random.seed(2)
-    cfg = configs.cityscapes_semi(arch="resnet50", crop=97, batch_size=2, sync_bn=True, epochs=10)
-    cfg["criterion"]["kwargs"]["min_kept"] = 3000
+    cfg = configs.cityscapes_semi(arch="resnet50", crop=S, batch_size=2, sync_bn=True, epochs=10)
+    cfg["criterion"]["kwargs"]["min_kept"] = 3000 if S >= 97 else 1500
     cfg["trainer"]["contrastive"]["current_class_threshold"] = 0.055
     dev = torch.device("cuda", 0)
     model, teacher = ModelBuilder(cfg["net"]).to(dev), ModelBuilder(cfg["net"]).to(dev)
@@ -92,14 +92,14 @@ def _train_case(rank, world):
     from u2pl_amd import nn as K
     K.COMM_DEBUG["on"] = True       # every step ends with the cross-rank comparison of the collective sequences (raises on a mismatch)
     issued0 = K.COMM_DEBUG["issued"]
-    for step in range(3):
-        il, iu = torch.randn(2, 3, 97, 97, generator=g), torch.randn(2, 3, 97, 97, generator=g)
-        ll = torch.randint(0, 19, (2, 97, 97), generator=g)
+    for step in range(steps):
+        il, iu = torch.randn(2, 3, S, S, generator=g), torch.randn(2, 3, S, S, generator=g)
+        ll = torch.randint(0, 19, (2, S, S), generator=g)
         ll[:, :6] = 255
         meters.append(tr.train_step(il.to(dev), ll.to(dev), iu.to(dev), epoch=0).cpu().numpy())
     torch.cuda.synchronize()
     K.COMM_DEBUG["on"] = False
-    return dict(collectives=K.COMM_DEBUG["issued"] - issued0,
+    return dict(collectives=K.COMM_DEBUG["issued"] - issued0, syncbn=K.COMM_STATS["syncbn_allreduce"],
                 meters=np.stack(meters), w=tr.arena.flat.double().sum().item(), w2=(tr.arena.flat.double() ** 2).sum().item(),
                 t=tr.t_arena.flat.double().sum().item(), bank_len=list(tr.memobank.length),
                 bank_sum=[float(tr.memobank.logical(c).double().sum()) for c in range(19)],
@@ -115,6 +115,24 @@ def test_two_rank_training_keeps_replicas_and_banks_identical():
     assert r0["rm"] == r1["rm"]                                  # SyncBN running stats identical
     # one communicator by default: both ranks issued the same number of collectives (their ORDER was compared inside every step)
     assert r0["collectives"] == r1["collectives"] > 0
+
+
+def _train_case_small(rank, world):
+    return _train_case(rank, world, S=65, steps=2)
+
+
+def test_eight_rank_training_keeps_replicas_and_banks_identical():
+    """the whole step under EIGHT ranks (gloo, sharing the one GPU; the driver's RCCL run is the first time
+    this many ranks meet): per-step comparison of the ranks' collective sequences (U2PL_COMM_DEBUG), replicated weights /
+    teacher / SyncBN statistics / banks bit for bit, the bank filled rank-major from all eight ranks."""
+    res = _run(_train_case_small, world=8)
+    r0 = res[0]
+    assert np.isfinite(r0["meters"]).all() and sum(r0["bank_len"]) > 0
+    for r in res[1:]:
+        assert np.array_equal(r0["meters"], r["meters"])
+        assert r0["w"] == r["w"] and r0["w2"] == r["w2"] and r0["t"] == r["t"] and r0["rm"] == r["rm"]
+        assert r0["bank_len"] == r["bank_len"] and r0["bank_sum"] == r["bank_sum"]
+        assert r0["collectives"] == r["collectives"] > 0
 
 
 def _pack_case(rank, world):

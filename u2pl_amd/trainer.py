@@ -203,6 +203,17 @@ class SemiTrainer:
         else:
             self.arena.sgd_step(lrs, self.momentum, self.weight_decay, grad_scale=grad_scale)
 
+    # per-phase timing (bench.py `phase_ms`): when `phase_log` is a list, train_step appends (name, event) at every
+    # phase boundary, recorded on the CURRENT stream.  Meaningful when the step is serialised on one stream (bench.py's extra
+    # diagnostic step sets _side to the main stream and turns the weight-gradient side stream off); a no-op otherwise.
+    phase_log = None
+
+    def _mark(self, name):
+        if self.phase_log is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.phase_log.append((name, ev))
+
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream() if os.environ.get("U2PL_NO_SIDE_STREAM") is None else torch.cuda.current_stream()
@@ -235,6 +246,7 @@ class SemiTrainer:
         model.train()
         self.arena.zero_grad()
         label_l = label_l.long().contiguous()
+        self._mark("start")
         if epoch < self.sup_only_epoch:  # train_semi.py:288-307
             outs = model(image_l)
             pred = H.bilinear_up(outs["pred"], (h, w))
@@ -295,6 +307,7 @@ class SemiTrainer:
             else:
                 with torch.cuda.stream(side):
                     image_all = torch.cat((image_l, image_u_aug))
+            self._mark("teacher_eval")       # pseudo-label pass + strong augmentation
             # (2) teacher train-mode forward (train_semi.py:360-374)
             teacher.train()
             with torch.cuda.stream(side), torch.no_grad():
@@ -304,6 +317,7 @@ class SemiTrainer:
                 pt, ldp = K.as_rows(pred_all_t)
                 Cn = pred_all_t.shape[1]
                 K.call("u2pl_softmax_rows_f32", pt, ldp, prob_all_t, Cn, pt.shape[0] * pt.shape[2] * pt.shape[3], Cn)
+            self._mark("teacher_train")
             image_all_s = torch.cat((image_l, mixed_on_main if mixed_on_main is not None else image_u))
             # student forward (train_semi.py:339-358)
             outs = model(image_all_s)
@@ -315,6 +329,7 @@ class SemiTrainer:
                 sup_loss = self.sup_loss_fn([pred_l_large, aux], label_l.clone())
             else:
                 sup_loss = self.sup_loss_fn(pred_l_large, label_l.clone())
+            self._mark("student_fwd")        # incl. the supervised loss heads (bilinear up + OHEM / CE)
             main.wait_stream(side)
             K._lib.SIDE_WORK.discard("teacher")
             if side is not main:
@@ -342,6 +357,7 @@ class SemiTrainer:
                                          negative_high_entropy=neg_high)
                 ent, thr, target_u = rs["entropy"], rs["thr"], rs["target_u"]
                 low_mask, high_mask, lbits = rs["low_mask"], rs["high_mask"], rs["lbits"]
+            self._mark("reliability")
             unsup_loss = H.cross_entropy(pred_u_large, target_u, 255, unsup_weight=True,
                                          scale=float(unsup_cfg.get("loss_weight", 1)))
             if ccfg:
@@ -358,8 +374,12 @@ class SemiTrainer:
             debug.update(label_u=label_u_aug, target_u=target_u, entropy=ent, thr=thr, pred_u_large=pred_u_large.detach())
             if ccfg:
                 debug.update(low_mask=low_mask, high_mask=high_mask, lbits=lbits)
+        self._mark("contrastive")            # unsupervised CE + memory-bank contrastive loss (forward)
         loss = sup_loss + unsup_loss + contra_loss
         loss.backward()
+        if self.phase_log is not None:
+            K.wgrad_stream_sync()            # (the weight-gradient side stream, if on, belongs to the backward phase)
+        self._mark("bwd")
         self._reduce_grads_and_step(lrs)
         # teacher EMA (train_semi.py:531-548)
         if epoch >= self.sup_only_epoch:
@@ -367,6 +387,7 @@ class SemiTrainer:
             if epoch == self.sup_only_epoch:
                 self.t_arena.copy_from(self.arena)  # aliasing: t == s_new before the EMA line
             self.t_arena.ema_from(self.arena, d)
+        self._mark("opt_ema")
         meters = torch.stack((sup_loss.detach(), unsup_loss.detach(), contra_loss.detach()))
         if _world() > 1:
             cv = contra_loss.detach().clone()

@@ -260,6 +260,9 @@ def main():
     torch.cuda.synchronize()
     comm0 = dict(KN.COMM_STATS)
     route0 = HO.split_route_stats()
+    from u2pl_amd import _lib as LIBc, graphs as GR
+    from u2pl_amd.utils import utils as UU
+    calls0, launches0, gstats0, blocked0 = LIBc.CALLS[0], LIBc.lib().cdll.u2pl_kernel_launches(), dict(GR.STATS), UU.BLOCKED_S[0]
     _progress("timed")
     t0 = time.perf_counter()
     _WD["t_timed"] = _WD["t_steps_end"] = time.time()
@@ -269,6 +272,10 @@ def main():
         meters = step(args.warmup + i)
         host_s += time.perf_counter() - th
         _WD["steps_done"], _WD["t_steps_end"] = i + 1, time.time()
+    calls_timed = (LIBc.CALLS[0] - calls0) / args.steps
+    launches_timed = (LIBc.lib().cdll.u2pl_kernel_launches() - launches0) / args.steps
+    replays_timed = (GR.STATS["replays"] - gstats0["replays"]) / args.steps
+    blocked_s = UU.BLOCKED_S[0] - blocked0
     host_tail = time.perf_counter()
     torch.cuda.synchronize()
     host_tail = time.perf_counter() - host_tail      # GPU work still queued when the host left the last step
@@ -414,10 +421,24 @@ def main():
             # the step's one blocking device-to-host read -- and the GPU work still queued when the host left the last step
             # (tools/host_overhead.py has the cProfile breakdown).  host_enqueue_ms close to ms_per_step with a small tail =
             # the host is the bound; well below it = the GPU is
-            "host_enqueue_ms": round(host_s / args.steps * 1e3, 2), "gpu_tail_after_last_enqueue_ms": round(host_tail * 1e3, 2),
+            # host_in_step_ms = wall time inside train_step; host_blocked_ms = the part of it spent inside the step's one blocking
+            # device-to-host read (the host waiting for the GPU); host_enqueue_ms = the difference = what the host needs to issue a step
+            "host_in_step_ms": round(host_s / args.steps * 1e3, 2), "host_blocked_ms": round(blocked_s / args.steps * 1e3, 2),
+            "host_enqueue_ms": round((host_s - blocked_s) / args.steps * 1e3, 2),
+            "gpu_tail_after_last_enqueue_ms": round(host_tail * 1e3, 2),
         }
         out.update(diag)
         out.update(roof)
+        # calls / launches of the TIMED steps (a HIP-graph replay of a static segment is one hipGraphLaunch, not a C-ABI call); the
+        # roofline leg's counts come from its eager per-call profile step and are kept under *_eager_profile
+        for k in ("abi_calls_per_step", "kernel_launches_per_step"):
+            if k in out:
+                out[k + "_eager_profile"] = out.pop(k)
+        out["abi_calls_per_step"] = round(calls_timed, 1)
+        out["kernel_launches_issued_by_host_per_step"] = round(launches_timed, 1)
+        out["graph_replays_per_step"] = round(replays_timed, 2)
+        out["graphs"] = dict(GR.STATS, enabled=GR.enabled(), warm=GR.WARM,
+                             segments="teacher eval pass, teacher train pass, student forward, student backward")
         if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N=1 only (the checker's port, never the product)
             from oracle import step_ref
             out["cpu_baseline"] = step_ref.timed_cpu_baseline(crop=args.crop, arch=args.arch, batch=args.batch)

@@ -107,6 +107,12 @@ def stream_ptr():
 # empty when it launches, i.e. that by stream order no other kernel of this process can be resident.
 SIDE_WORK = set()
 
+# True while u2pl_amd.graphs records a HIP graph on the current stream: code that synchronises with work OUTSIDE the capture
+# (events of other streams, operand rebuilds) must not do so then -- see nn._derived
+CAPTURING = [False]
+# C-ABI calls issued by this process (bench.py reports the per-step count of the TIMED steps; a graph replay is not a call)
+CALLS = [0]
+
 PROFILE = None  # when a list: (name, args, start_event, end_event) per call (bench.py roofline leg)
 _FN = {}
 
@@ -118,6 +124,7 @@ def call(name, *args):
     if fn is None:
         fn = _FN[name] = getattr(lib().cdll, name)
     conv = [a.data_ptr() if hasattr(a, "data_ptr") and a.is_cuda else _ptr(a) for a in args]
+    CALLS[0] += 1
     if PROFILE is not None:
         import torch
 

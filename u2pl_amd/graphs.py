@@ -1,0 +1,188 @@
+"""HIP graphs over the ctypes launches of the step's STATIC segments.
+
+A training step issues ~2400 C-ABI calls from Python; four segments of it are shape-static and free of host decisions:
+the teacher's pseudo-label pass (eval mode), the teacher's train-mode pass, the student's forward and the student's backward
+(train_semi.py:317-324, 360-374, 339-358, 526).  After ``WARM`` eager executions of a segment with the same input
+shapes it is captured ONCE -- torch.cuda.graph() puts the current HIP stream into capture mode, the entry points of
+libu2pl_hip.so launch into whatever stream they are handed, so the same Python code that runs the segment eagerly records
+it -- and replayed from then on: one hipGraphLaunch instead of 400-800 calls, same kernels, same order, same bits.
+
+What stays eager: everything with a host decision in it (CutMix coin and boxes, the contrastive path's counts / sampling,
+the optimizer's scalars), the losses, the persistent reliability split.  Graphs are NOT used under a process group (the
+SyncBatchNorm all-reduces sit between the kernels; capturing RCCL collectives is untested here), when a dropout hook
+feeds host-made masks (parity tests), while bench.py's per-call profile records, or with U2PL_GRAPHS=0.
+
+Host-side effects of a captured segment are re-applied at replay: BatchNorm's ``num_batches_tracked`` host counters.
+Buffers a graph reads by address and that are rebuilt in place between replays (the pre-split weight planes,
+nn.presplit) need no handling; nn._derived refuses to (re)build or to wait on foreign events while capturing, which makes
+a stale operand abort the capture (the segment then runs eagerly and is captured at a later step)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from . import nn as K
+
+WARM = int(os.environ.get("U2PL_GRAPH_WARM", "2"))
+STATS = {"captures": 0, "replays": 0, "eager": 0, "aborted": 0}
+
+
+def enabled():
+    if os.environ.get("U2PL_GRAPHS", "1") == "0" or _lib.PROFILE is not None or K.DROPOUT_HOOK is not None:
+        return False
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return False
+    return True
+
+
+def _bns(modules):
+    return [m for mod in modules for m in mod.modules() if isinstance(m, K.BatchNorm2d)]
+
+
+class _Capture:
+    """context: torch.cuda.graph + the package's capture flag + BatchNorm host-counter bookkeeping"""
+
+    def __init__(self, graph, bns, pool=None):
+        self.graph, self.bns, self.pool = graph, bns, pool
+
+    def __enter__(self):
+        self.nbt0 = [m._nbt for m in self.bns]
+        self.ctx = torch.cuda.graph(self.graph, pool=self.pool)
+        self.ctx.__enter__()
+        _lib.CAPTURING[0] = True
+        return self
+
+    def __exit__(self, et, ev, tb):
+        _lib.CAPTURING[0] = False
+        try:
+            self.ctx.__exit__(et, ev, tb)
+        finally:
+            # nothing executed during capture: undo the host counters, remember what a replay has to add
+            self.bumps = [(m, m._nbt - n0) for m, n0 in zip(self.bns, self.nbt0) if m._nbt != n0]
+            for m, n0 in zip(self.bns, self.nbt0):
+                m._nbt = n0
+        return False
+
+
+def _key(xs, modules):
+    return tuple((tuple(x.shape), x.dtype, x.device.index) for x in xs) + tuple(m.training for m in modules)
+
+
+class GraphedNoGrad:
+    """fn(*tensors) -> tuple of tensors, executed under no_grad on the CURRENT stream (the teacher passes).  Inputs are copied
+    into static buffers; the returned tensors are the graph's static outputs (valid until the next replay)."""
+
+    def __init__(self, fn, modules, name):
+        self.fn, self.modules, self.name, self.cache = fn, list(modules), name, {}
+
+    def __call__(self, *xs):
+        if not enabled():
+            STATS["eager"] += 1
+            return self.fn(*xs)
+        key = _key(xs, self.modules)
+        ent = self.cache.setdefault(key, {"count": 0, "graph": None})
+        if ent["graph"] is None:
+            if ent["count"] < WARM or ent.get("failed", 0) >= 2:
+                ent["count"] += 1
+                STATS["eager"] += 1
+                return self.fn(*xs)
+            static_in = [x.clone() for x in xs]
+            g = torch.cuda.CUDAGraph()
+            cap = _Capture(g, _bns(self.modules))
+            try:
+                with cap:
+                    outs = self.fn(*static_in)
+            except Exception:
+                ent["failed"] = ent.get("failed", 0) + 1
+                STATS["aborted"] += 1
+                if os.environ.get("U2PL_GRAPH_DEBUG"):
+                    raise
+                STATS["eager"] += 1
+                return self.fn(*xs)
+            ent.update(graph=g, static_in=static_in, outs=outs, bumps=cap.bumps)
+            STATS["captures"] += 1
+        for s, x in zip(ent["static_in"], xs):
+            if s.data_ptr() != x.data_ptr():
+                s.copy_(x)
+        ent["graph"].replay()
+        for m, d in ent["bumps"]:
+            m._nbt += d
+        STATS["replays"] += 1
+        return ent["outs"]
+
+
+class _Bridge(torch.autograd.Function):
+    """hands the forward graph's static outputs to autograd; its backward fills the static gradient buffers and replays the
+    backward graph (weight / BatchNorm gradients go straight into the arena's sinks, like in the eager step)"""
+
+    @staticmethod
+    def forward(ctx, owner, ent, dummy, *outs):
+        ctx.owner, ctx.ent = owner, ent
+        return tuple(o.detach() for o in outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ent = ctx.ent
+        for buf, g in zip(ent["gouts"], gs):
+            if g is None:
+                buf.zero_()
+            else:
+                buf.copy_(g)
+        ent["bwd"].replay()
+        STATS["replays"] += 1
+        return (None, None, None) + (None,) * len(gs)
+
+
+class GraphedTrain:
+    """model(x) -> dict of tensors WITH a backward: forward and backward of the student as two graphs sharing one memory pool
+    (the tensors saved for backward live in it).  Call pattern per step: outs = graphed(x); ...; loss.backward()."""
+
+    def __init__(self, model, name="student"):
+        self.model, self.name, self.cache = model, name, {}
+        self._dummy = None
+
+    def __call__(self, x):
+        if not (enabled() and torch.is_grad_enabled()):
+            STATS["eager"] += 1
+            return self.model(x)
+        key = _key((x,), (self.model,))
+        ent = self.cache.setdefault(key, {"count": 0, "fwd": None})
+        if ent["fwd"] is None:
+            if ent["count"] < WARM or ent.get("failed", 0) >= 2:
+                ent["count"] += 1
+                STATS["eager"] += 1
+                return self.model(x)
+            static_x = x.clone()
+            bns = _bns([self.model])
+            fwd, bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            pool = torch.cuda.graph_pool_handle()
+            try:
+                cap = _Capture(fwd, bns, pool)
+                with cap:
+                    outs = self.model(static_x)
+                keys = sorted(outs)
+                souts = [outs[k] for k in keys]
+                gouts = [torch.zeros_like(o) for o in souts]
+                cap_b = _Capture(bwd, bns, pool)
+                with cap_b:
+                    torch.autograd.backward(souts, gouts)
+            except Exception:
+                ent["failed"] = ent.get("failed", 0) + 1
+                STATS["aborted"] += 1
+                K.wgrad_stream_sync()
+                if os.environ.get("U2PL_GRAPH_DEBUG"):
+                    raise
+                STATS["eager"] += 1
+                return self.model(x)
+            ent.update(fwd=fwd, bwd=bwd, static_x=static_x, keys=keys, outs=souts, gouts=gouts, bumps=cap.bumps)
+            STATS["captures"] += 2
+        if self._dummy is None:
+            self._dummy = torch.zeros((), device=x.device, requires_grad=True)
+        ent["static_x"].copy_(x)
+        ent["fwd"].replay()
+        for m, d in ent["bumps"]:
+            m._nbt += d
+        STATS["replays"] += 1
+        outs = _Bridge.apply(self, ent, self._dummy, *ent["outs"])
+        return dict(zip(ent["keys"], outs))

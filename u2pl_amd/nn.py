@@ -218,6 +218,14 @@ def _derived(weight, kind, nbytes, build):
     stamp = _weight_stamp(weight)
     ent = cache.get(kind)
     cur = torch.cuda.current_stream()
+    if _lib.CAPTURING[0]:
+        # inside a HIP-graph capture (u2pl_amd.graphs): the operand must already be current -- it is rebuilt IN PLACE by presplit()
+        # right after every optimizer / EMA update, on the stream the replay is launched on, so the graph reads the fresh planes
+        # by address; an event of another stream cannot be waited for inside a capture and a rebuild recorded into the graph
+        # would leave the host-side stamps behind
+        if ent is None or ent["stamp"] != stamp:
+            raise HipError("derived weight operand '%s' is stale during graph capture (the segment runs eagerly once more)" % kind)
+        return ent["buf"]
     if ent is None or ent["buf"].numel() != max(int(nbytes), 16) or ent["buf"].device != weight.device:
         ent = cache[kind] = {"buf": torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=weight.device), "stamp": None,
                              "event": torch.cuda.Event(), "stream": cur, "readers": set()}

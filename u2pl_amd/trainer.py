@@ -21,6 +21,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import graphs as G
 from . import hipops as H
 from . import nn as K
 from .utils import loss_helper as LH
@@ -214,6 +215,35 @@ class SemiTrainer:
             ev.record()
             self.phase_log.append((name, ev))
 
+    # ---- the step's static segments, eager for the first calls and as HIP graphs from then on (u2pl_amd.graphs) ----
+    def _teacher_eval_pass(self, image_u, hw):
+        """pseudo labels (train_semi.py:317-324): eval-mode teacher, bilinear up, softmax max / arg-max"""
+        pred_u_t = self.teacher(image_u, need_aux=False, need_rep=False)["pred"]
+        return H.pseudo_label(H.bilinear_up(pred_u_t, hw))
+
+    def _teacher_train_pass(self, image_all):
+        """train-mode teacher forward (train_semi.py:360-374) + the class probabilities of its logits"""
+        out_t = self.teacher(image_all, need_aux=False)
+        pred_all_t, rep_all_t = out_t["pred"], out_t["rep"]
+        prob_all_t = K.new_act(*pred_all_t.shape, pred_all_t.device)
+        pt, ldp = K.as_rows(pred_all_t)
+        Cn = pred_all_t.shape[1]
+        K.call("u2pl_softmax_rows_f32", pt, ldp, prob_all_t, Cn, pt.shape[0] * pt.shape[2] * pt.shape[3], Cn)
+        return pred_all_t, rep_all_t, prob_all_t
+
+    def _graphed(self, which, arg):
+        cache = self.__dict__.setdefault("_graph_cache", {})
+        fn = cache.get((which, arg))
+        if fn is None:
+            if which == "teacher_eval":
+                fn = G.GraphedNoGrad(lambda x, hw=arg: self._teacher_eval_pass(x, hw), [self.teacher], which)
+            elif which == "teacher_train":
+                fn = G.GraphedNoGrad(self._teacher_train_pass, [self.teacher], which)
+            else:
+                fn = G.GraphedTrain(self.model, which)
+            cache[(which, arg)] = fn
+        return fn
+
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream() if os.environ.get("U2PL_NO_SIDE_STREAM") is None else torch.cuda.current_stream()
@@ -275,8 +305,7 @@ class SemiTrainer:
             # (1) pseudo labels (train_semi.py:317-324), eval mode
             teacher.eval()
             with torch.cuda.stream(side), torch.no_grad():
-                pred_u_t = teacher(image_u, need_aux=False, need_rep=False)["pred"]
-                conf_u, label_u_aug = H.pseudo_label(H.bilinear_up(pred_u_t, (h, w)))
+                conf_u, label_u_aug = self._graphed("teacher_eval", (h, w))(image_u)
             # strong augmentation (train_semi.py:326-337): host coin flip + host rectangle draws.  The IMAGE mix
             # needs only the boxes, so it is issued on the main stream right away; labels are mixed on the side.
             image_u_aug = image_u
@@ -311,16 +340,11 @@ class SemiTrainer:
             # (2) teacher train-mode forward (train_semi.py:360-374)
             teacher.train()
             with torch.cuda.stream(side), torch.no_grad():
-                out_t = teacher(image_all, need_aux=False)
-                pred_all_t, rep_all_t = out_t["pred"], out_t["rep"]
-                prob_all_t = K.new_act(*pred_all_t.shape, pred_all_t.device)
-                pt, ldp = K.as_rows(pred_all_t)
-                Cn = pred_all_t.shape[1]
-                K.call("u2pl_softmax_rows_f32", pt, ldp, prob_all_t, Cn, pt.shape[0] * pt.shape[2] * pt.shape[3], Cn)
+                pred_all_t, rep_all_t, prob_all_t = self._graphed("teacher_train", None)(image_all)
             self._mark("teacher_train")
             image_all_s = torch.cat((image_l, mixed_on_main if mixed_on_main is not None else image_u))
             # student forward (train_semi.py:339-358)
-            outs = model(image_all_s)
+            outs = self._graphed("student", None)(image_all_s)
             pred_all, rep_all = outs["pred"], outs["rep"]
             pred_l_large = H.bilinear_up(pred_all[:B], (h, w))
             pred_u_large = H.bilinear_up(pred_all[B:], (h, w))

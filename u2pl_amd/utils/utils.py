@@ -3,6 +3,7 @@ pieces on the hot path: memory-bank enqueue with cross-rank key gather."""
 import logging
 import os
 import random
+import time
 
 import numpy as np
 import torch
@@ -43,17 +44,26 @@ def gather_keys(keys):
     return torch.cat([o[:k] for o, k in zip(outs, ns)])
 
 
+# wall time this process spent inside the step's one blocking device-to-host read (bench.py: host_blocked_ms -- the host waiting
+# for the GPU to catch up, as opposed to the time it spends enqueueing)
+BLOCKED_S = [0.0]
+
+
 def exchange_counts(counts_dev, C):
     """phase-1 list lengths (u32 [3][32] on the device) -> host (this rank's [3][32]) and, under a process group, every
     rank's negative-key counts [W][C]: the all-gather runs on the device BEFORE the single device-to-host copy."""
     W = _world()
-    if W == 1:
-        return counts_dev.cpu().numpy(), None
-    outs = [torch.empty_like(counts_dev) for _ in range(W)]
-    _note("key_allgather", counts_dev.numel())
-    dist.all_gather(outs, counts_dev)
-    host = torch.stack(outs).cpu().numpy()                   # [W][3][32]: the one sync
-    return host[dist.get_rank()], host[:, 2, :C].astype(np.int64)
+    t0 = time.perf_counter()
+    try:
+        if W == 1:
+            return counts_dev.cpu().numpy(), None
+        outs = [torch.empty_like(counts_dev) for _ in range(W)]
+        _note("key_allgather", counts_dev.numel())
+        dist.all_gather(outs, counts_dev)
+        host = torch.stack(outs).cpu().numpy()                   # [W][3][32]: the one sync
+        return host[dist.get_rank()], host[:, 2, :C].astype(np.int64)
+    finally:
+        BLOCKED_S[0] += time.perf_counter() - t0
 
 
 def enqueue_all_classes(bank, rows, ld, idx, counts_c, C, all_counts=None):

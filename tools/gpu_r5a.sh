@@ -9,4 +9,4 @@ timeout 700 python -m pytest tests/test_gpu_miou_gate.py -x -q -s > $O/miou.log 
 timeout 700 python -m pytest tests/test_gpu_dist.py -x -q -k "eight" > $O/dist8.log 2>&1; echo "dist8 rc $?"
 timeout 600 python bench.py --steps 10 --warmup 4 --no-cpu-baseline > $O/bench_graphs.json 2> $O/bench_graphs.err; echo "bench rc $?"
 U2PL_GRAPHS=0 timeout 500 python bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-config5-leg --no-direct-leg > $O/bench_eager.json 2> $O/bench_eager.err; echo "bench eager rc $?"
-tail -3 $O/graphs.log $O/ws.log $O/miou.log $O/dist8.log
+for f in graphs ws miou dist8; do tail -n 3 $O/$f.log; done

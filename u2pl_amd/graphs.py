@@ -184,5 +184,7 @@ class GraphedTrain:
         for m, d in ent["bumps"]:
             m._nbt += d
         STATS["replays"] += 1
-        outs = _Bridge.apply(self, ent, self._dummy, *ent["outs"])
+        # (detached: the capture-time autograd graph behind the static outputs has been consumed by the backward capture and must
+        # not be reachable from the step's graph -- _Bridge is the only link)
+        outs = _Bridge.apply(self, ent, self._dummy, *[o.detach() for o in ent["outs"]])
         return dict(zip(ent["keys"], outs))

@@ -376,11 +376,17 @@ def main():
         # the accuracy / speed trade of the default algorithm, in the line itself: the SAME workload with
         # every 3x3 layer on the direct implicit-GEMM kernel (U2PL_CONV_WINO=0), and both algorithms' error against float64
         KN.CONV_ALGO["wino"] = 0
+        g_env = os.environ.get("U2PL_GRAPHS")
+        os.environ["U2PL_GRAPHS"] = "0"          # eager steps for this leg (graphs are keyed on the algorithm; no capture inside the timing)
         try:
             step(0)                              # builds the direct kernels' operands (3x3 split planes), un-timed
             diag["ms_per_step_direct"] = round(timed_steps(3, 1), 3)
         finally:
             KN.CONV_ALGO["wino"] = wt
+            if g_env is None:
+                del os.environ["U2PL_GRAPHS"]
+            else:
+                os.environ["U2PL_GRAPHS"] = g_env
         step(0)
         torch.cuda.synchronize()
         diag["conv_error_vs_f64"] = wino_vs_direct_error(dev)
@@ -462,6 +468,8 @@ def main():
                 r5 = subprocess.run([sys.executable, os.path.abspath(__file__), "--bf16", "--crop", "801", "--steps", "4", "--warmup", "2",
                                      "--no-cpu-baseline", "--no-config5-leg"], capture_output=True, text=True, timeout=600)
                 l5 = [ln for ln in r5.stdout.splitlines() if ln.startswith("{")]
+                if not l5:
+                    raise RuntimeError("no JSON line; rc %s; stderr tail: %s" % (r5.returncode, r5.stderr[-600:]))
                 j5 = json.loads(l5[-1])
                 out["config5"] = {"images_per_s": j5["value"], "ms_per_step": j5["ms_per_step"], "crop": 801, "steps": j5["steps"],
                                   "warmup": j5["warmup"], "dtype": j5["dtype"], "conv_algo": j5["config"]["conv_algo"],
@@ -469,7 +477,7 @@ def main():
                                   "note": "python bench.py --bf16 --crop 801: student conv operands rounded to bf16 while staged into LDS "
                                           "(bf16 matrix cores, fp32 accumulate), activations still fp32 in HBM; teacher as in the headline"}
             except Exception as e:      # the leg must never cost the headline line
-                out["config5"] = {"error": repr(e)[:300]}
+                out["config5"] = {"error": repr(e)[:900]}
         _WD["done"] = True
         print(json.dumps(out))
     _WD["done"] = True

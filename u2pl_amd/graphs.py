@@ -13,6 +13,9 @@ SyncBatchNorm all-reduces sit between the kernels; capturing RCCL collectives is
 feeds host-made masks (parity tests), while bench.py's per-call profile records, or with U2PL_GRAPHS=0.
 
 Host-side effects of a captured segment are re-applied at replay: BatchNorm's ``num_batches_tracked`` host counters.
+Random numbers: no generator-driven kernel runs inside a graph -- the Dropout2d uniforms of a pass are drawn into a buffer
+BEFORE the pass by ONE generator call, eager or replayed alike (nn.dropout_pool; graphs that share the default generator and
+replay on different streams race on its seed / offset tensors otherwise -- measured).
 Buffers a graph reads by address and that are rebuilt in place between replays (the pre-split weight planes,
 nn.presplit) need no handling; nn._derived refuses to (re)build or to wait on foreign events while capturing, which makes
 a stale operand abort the capture (the segment then runs eagerly and is captured at a later step)."""
@@ -66,45 +69,56 @@ class _Capture:
 
 
 def _key(xs, modules):
-    return tuple((tuple(x.shape), x.dtype, x.device.index) for x in xs) + tuple(m.training for m in modules)
+    """what a captured segment is valid for: input shapes, train / eval mode, and the convolution algorithm switches (a graph
+    recorded with Winograd kernels must not be replayed after U2PL_CONV_WINO / _BF16 / _SPLIT / _WS changed)"""
+    algo = tuple(sorted(K.CONV_ALGO.items())) + (K.CONV_WS["on"], _lib.query("u2pl_conv_get_split"), K.FUSE_EVAL_BN)
+    return tuple((tuple(x.shape), x.dtype, x.device.index) for x in xs) + tuple(m.training for m in modules) + algo
 
 
 class GraphedNoGrad:
     """fn(*tensors) -> tuple of tensors, executed under no_grad on the CURRENT stream (the teacher passes).  Inputs are copied
     into static buffers; the returned tensors are the graph's static outputs (valid until the next replay)."""
 
-    def __init__(self, fn, modules, name):
-        self.fn, self.modules, self.name, self.cache = fn, list(modules), name, {}
+    def __init__(self, fn, modules, name, uniforms=None):
+        """uniforms(xs) -> number of dropout uniforms one pass consumes (nn.dropout_pool); None / 0: the pass draws nothing"""
+        self.fn, self.modules, self.name, self.cache, self.uniforms = fn, list(modules), name, {}, uniforms
+
+    def _eager(self, xs):
+        STATS["eager"] += 1
+        n = self.uniforms(xs) if self.uniforms else 0
+        with K.dropout_pool(torch.empty(n, device=xs[0].device).uniform_() if n else None):
+            return self.fn(*xs)
 
     def __call__(self, *xs):
         if not enabled():
-            STATS["eager"] += 1
-            return self.fn(*xs)
+            return self._eager(xs)
         key = _key(xs, self.modules)
         ent = self.cache.setdefault(key, {"count": 0, "graph": None})
         if ent["graph"] is None:
             if ent["count"] < WARM or ent.get("failed", 0) >= 2:
                 ent["count"] += 1
-                STATS["eager"] += 1
-                return self.fn(*xs)
+                return self._eager(xs)
             static_in = [x.clone() for x in xs]
+            n = self.uniforms(xs) if self.uniforms else 0
+            u = torch.empty(n, device=xs[0].device) if n else None
             g = torch.cuda.CUDAGraph()
             cap = _Capture(g, _bns(self.modules))
             try:
-                with cap:
+                with cap, K.dropout_pool(u):
                     outs = self.fn(*static_in)
             except Exception:
                 ent["failed"] = ent.get("failed", 0) + 1
                 STATS["aborted"] += 1
                 if os.environ.get("U2PL_GRAPH_DEBUG"):
                     raise
-                STATS["eager"] += 1
-                return self.fn(*xs)
-            ent.update(graph=g, static_in=static_in, outs=outs, bumps=cap.bumps)
+                return self._eager(xs)
+            ent.update(graph=g, static_in=static_in, outs=outs, bumps=cap.bumps, u=u)
             STATS["captures"] += 1
         for s, x in zip(ent["static_in"], xs):
             if s.data_ptr() != x.data_ptr():
                 s.copy_(x)
+        if ent["u"] is not None:
+            ent["u"].uniform_()           # this pass's dropout uniforms: the same generator call the eager pass makes
         ent["graph"].replay()
         for m, d in ent["bumps"]:
             m._nbt += d
@@ -142,24 +156,30 @@ class GraphedTrain:
         self.model, self.name, self.cache = model, name, {}
         self._dummy = None
 
+    def _eager(self, x):
+        STATS["eager"] += 1
+        n = K.dropout_uniforms_needed(self.model, x.shape[0]) if self.model.training else 0
+        with K.dropout_pool(torch.empty(n, device=x.device).uniform_() if n else None):
+            return self.model(x)
+
     def __call__(self, x):
         if not (enabled() and torch.is_grad_enabled()):
-            STATS["eager"] += 1
-            return self.model(x)
+            return self._eager(x)
         key = _key((x,), (self.model,))
         ent = self.cache.setdefault(key, {"count": 0, "fwd": None})
         if ent["fwd"] is None:
             if ent["count"] < WARM or ent.get("failed", 0) >= 2:
                 ent["count"] += 1
-                STATS["eager"] += 1
-                return self.model(x)
+                return self._eager(x)
             static_x = x.clone()
             bns = _bns([self.model])
             fwd, bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             pool = torch.cuda.graph_pool_handle()
+            n = K.dropout_uniforms_needed(self.model, x.shape[0]) if self.model.training else 0
+            u = torch.empty(n, device=x.device) if n else None
             try:
                 cap = _Capture(fwd, bns, pool)
-                with cap:
+                with cap, K.dropout_pool(u):
                     outs = self.model(static_x)
                 keys = sorted(outs)
                 souts = [outs[k] for k in keys]
@@ -173,13 +193,14 @@ class GraphedTrain:
                 K.wgrad_stream_sync()
                 if os.environ.get("U2PL_GRAPH_DEBUG"):
                     raise
-                STATS["eager"] += 1
-                return self.model(x)
-            ent.update(fwd=fwd, bwd=bwd, static_x=static_x, keys=keys, outs=souts, gouts=gouts, bumps=cap.bumps)
+                return self._eager(x)
+            ent.update(fwd=fwd, bwd=bwd, static_x=static_x, keys=keys, outs=souts, gouts=gouts, bumps=cap.bumps, u=u)
             STATS["captures"] += 2
         if self._dummy is None:
             self._dummy = torch.zeros((), device=x.device, requires_grad=True)
         ent["static_x"].copy_(x)
+        if ent["u"] is not None:
+            ent["u"].uniform_()
         ent["fwd"].replay()
         for m, d in ent["bumps"]:
             m._nbt += d

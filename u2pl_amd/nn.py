@@ -992,8 +992,59 @@ def dropout2d_scale(mod, N, C, device):
         s = DROPOUT_HOOK(mod, N, C)
         if s is not None:
             return s.to(torch.float32).contiguous().pin_memory().to(device, non_blocking=True)
-    keep = (torch.rand((N, C), device=device) >= p).to(torch.float32)
+    u = None
+    if DROPOUT_POOL is not None:      # uniforms of this PASS drawn ahead in one call (see dropout_pool)
+        off, n = DROPOUT_POOL["off"], N * C
+        if off + n <= DROPOUT_POOL["u"].numel():
+            u = DROPOUT_POOL["u"][off:off + n].view(N, C)
+            DROPOUT_POOL["off"] = off + n
+        elif _lib.CAPTURING[0]:
+            raise HipError("dropout pool exhausted inside a graph capture")
+    if u is None:
+        u = torch.rand((N, C), device=device)
+    keep = (u >= p).to(torch.float32)
     return keep.mul_(1.0 / (1.0 - p))
+
+
+# The keep-masks of ONE forward pass come from one block of uniforms drawn BEFORE the pass (one generator call per pass instead
+# of one per Dropout2d layer).  Reason: a HIP graph that contains generator-driven kernels reads seed / offset from tensors that
+# belong to the GENERATOR, refreshed at every replay on the replaying stream; the teacher's graph (side stream) and the student's
+# (main stream) share the default generator, so one replay's refresh raced the other graph's kernels (measured: masks of the
+# late layers differed from the eager step's).  With the uniforms in a buffer filled outside the graphs the passes draw
+# identically eager or replayed, and no generator state is read inside a graph.
+DROPOUT_POOL = None
+
+
+class dropout_pool:
+    """with dropout_pool(u): every Dropout2d of the enclosed pass takes its (N, C) uniforms from u, in call order"""
+
+    def __init__(self, u):
+        self.u = u
+
+    def __enter__(self):
+        global DROPOUT_POOL
+        self.prev = DROPOUT_POOL
+        DROPOUT_POOL = None if self.u is None else {"u": self.u, "off": 0}
+        return self
+
+    def __exit__(self, *a):
+        global DROPOUT_POOL
+        DROPOUT_POOL = self.prev
+        return False
+
+
+def dropout_uniforms_needed(model, N):
+    """N x (channels in front of every Dropout2d of the model): the size of a pass's uniform block (an upper bound when the
+    pass skips heads)"""
+    total = 0
+    for seq in model.modules():
+        if isinstance(seq, nn.Sequential):
+            mods = list(seq)
+            for j, m in enumerate(mods):
+                if isinstance(m, nn.Dropout2d) and m.p > 0:
+                    bn = next((q for q in reversed(mods[:j]) if isinstance(q, BatchNorm2d)), None)
+                    total += N * (bn.num_features if bn is not None else 0)
+    return total
 
 
 def run_seq(seq, x):

@@ -238,7 +238,8 @@ class SemiTrainer:
             if which == "teacher_eval":
                 fn = G.GraphedNoGrad(lambda x, hw=arg: self._teacher_eval_pass(x, hw), [self.teacher], which)
             elif which == "teacher_train":
-                fn = G.GraphedNoGrad(self._teacher_train_pass, [self.teacher], which)
+                fn = G.GraphedNoGrad(self._teacher_train_pass, [self.teacher], which,
+                                     uniforms=lambda xs: K.dropout_uniforms_needed(self.teacher, xs[0].shape[0]))
             else:
                 fn = G.GraphedTrain(self.model, which)
             cache[(which, arg)] = fn

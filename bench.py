@@ -423,6 +423,7 @@ def main():
             "syncbn_collectives_per_step": comm["syncbn_allreduce"], "bucket_allreduces_per_step": comm["bucket_allreduce"],
             "rccl_ranks": rccl_ranks,
             "split_launches_timed": route1[0] - route0[0], "split_second_barrier_launches_timed": route1[1] - route0[1],
+            "split_ledger_fallbacks": HO.SPLIT_FALLBACKS["ledger"],
             # host side of the timed steps (rank 0): wall time inside train_step per step -- the enqueue of ~3000 C-ABI calls plus
             # the step's one blocking device-to-host read -- and the GPU work still queued when the host left the last step
             # (tools/host_overhead.py has the cProfile breakdown).  host_enqueue_ms close to ms_per_step with a small tail =
@@ -463,8 +464,13 @@ def main():
         if world == 1 and not args.bf16 and not args.no_config5_leg and args.crop == 769:
             # BASELINE configs[4] ("config 5": 801x801, reduced-precision student, fp32 EMA teacher) as a short leg of the default
             # run, so that the driver's line carries it; own process, after the headline measurement
+            import gc
             import subprocess
             try:
+                # the child needs ~100 GB of its own: hand this process's cached blocks and graph pools back first
+                trainer.__dict__.pop("_graph_cache", None)
+                gc.collect()
+                torch.cuda.empty_cache()
                 r5 = subprocess.run([sys.executable, os.path.abspath(__file__), "--bf16", "--crop", "801", "--steps", "4", "--warmup", "2",
                                      "--no-cpu-baseline", "--no-config5-leg"], capture_output=True, text=True, timeout=600)
                 l5 = [ln for ln in r5.stdout.splitlines() if ln.startswith("{")]

@@ -276,3 +276,28 @@ def test_bank_ring_bookkeeping_follows_dequeue_and_enqueue():
             assert bank.length[c] == len(fifo[c]) and bank.ptr[c] == ptr_ref[c], (it, c)
             window = [int(ring[c][(bank.head[c] + j) % caps[c]]) for j in range(bank.length[c])]
             assert window == fifo[c], (it, c, window, fifo[c])
+
+
+def test_modules_pickle_with_a_populated_operand_cache_and_arena():
+    """ADVICE r4 (low): the derived-operand cache (device buffers, HIP events, streams) and the arena hang off the Parameters;
+    torch.save(model) / multiprocessing pickle Parameter.__dict__ -- the cache must travel as empty, the arena without its
+    streams / in-flight collectives"""
+    import io
+    import pickle
+
+    import torch
+    from u2pl_amd import nn as K
+
+    net = torch.nn.Sequential(K.Conv2d(32, 32, 3, padding=1, bias=False), K.BatchNorm2d(32))
+    arena = K.ParamArena([list(net.parameters())])
+    w = net[0].weight
+    cache = w.__dict__["_u2pl_derived"] = K._DerivedCache()
+    cache["f"] = {"buf": torch.zeros(4), "event": object(), "stream": lambda: None, "readers": {1}, "stamp": (0, 0, 0, 0)}
+    arena._works, arena._streams = [object()], (object(),)
+    buf = io.BytesIO()
+    torch.save(net, buf)
+    buf.seek(0)
+    net2 = torch.load(buf, weights_only=False)
+    assert torch.equal(net2[0].weight, w) and len(net2[0].weight.__dict__.get("_u2pl_derived", {})) == 0
+    a2 = pickle.loads(pickle.dumps(arena))
+    assert a2._works == [None] and a2._streams == () and torch.equal(a2.flat, arena.flat)

@@ -180,6 +180,9 @@ def _rf_workspace(device, n_px):
 RF_FLAGS = int(os.environ.get("U2PL_RF_FENCES", "0")) & 1     # bit 0: fence pair around the split's barrier (csrc/relfused.hip)
 
 
+SPLIT_FALLBACKS = {"ledger": 0}     # persistent split skipped because the side-work ledger was not empty at launch
+
+
 def split_route_stats():
     """(launches, launches that needed the second device-wide barrier) of the persistent split on every workspace of this
     process (device-to-host read: call it outside the timed region)"""
@@ -233,7 +236,14 @@ def reliability_split(logits_low, size, label_l, label_u_aug, out_hw, percents, 
         # the device-wide barrier needs all G blocks resident: every side stream of this process must have been joined
         # (stream order then guarantees that none of its kernels can still occupy a CU when this one starts).  A ledger entry
         # that is still here (e.g. left behind by an exception the caller caught between add and discard) is not fatal: the
-        # five-launch path has no such requirement and gives the same thresholds / masks
+        # five-launch path has no such requirement and gives the same thresholds / masks.  NOT silent: counted
+        # (bench.py reports split_ledger_fallbacks) and warned about once -- a missing side-stream join would otherwise be an
+        # invisible slowdown of every later step
+        SPLIT_FALLBACKS["ledger"] += 1
+        if SPLIT_FALLBACKS["ledger"] == 1:
+            import warnings
+            warnings.warn("u2pl_amd: reliability_split found un-joined side-stream work %s and took the multi-launch path"
+                          % sorted(_lib.SIDE_WORK), RuntimeWarning)
         return reliability_split(logits_low, size, label_l, label_u_aug, out_hw, percents,
                                  negative_high_entropy=negative_high_entropy, ignore=ignore, fused=False)
     q32 = np.array([percentile_q32(p) for p in percents], dtype=np.float32)

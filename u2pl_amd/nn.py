@@ -32,7 +32,7 @@ COMM_DEBUG = {"on": os.environ.get("U2PL_COMM_DEBUG", "0") not in ("", "0"), "lo
 
 
 def _all_reduce(t, kind, group=None, async_op=False, op=None):
-    """the ONE place this package issues a collective from"""
+    """every all-reduce of this package (the memory bank's all-gathers in utils/utils.py are logged through note_collective)"""
     COMM_STATS[kind] = COMM_STATS.get(kind, 0) + 1
     COMM_DEBUG["issued"] += 1
     if COMM_DEBUG["on"]:
@@ -207,6 +207,23 @@ def _weight_stamp(weight):
     return (WEIGHT_EPOCH[0], ep[0] if ep is not None else 0, weight._version, weight.data_ptr())
 
 
+class _DerivedCache(dict):
+    """per-weight cache of derived operands (device buffers, HIP events, streams).  It hangs in the Parameter's __dict__, which
+    Parameter.__reduce_ex__ pickles: it pickles as EMPTY (torch.save(model) / multiprocessing keep working; the operands are
+    rebuilt on first use) -- ADVICE r4, low"""
+
+    def __reduce__(self):
+        return (_DerivedCache, ())
+
+
+def invalidate_weights(arena=None):
+    """Call after writing weights through a path the stamps cannot see -- ``p.data.<op>_()``, raw writes into ``arena.flat`` --
+    i.e. anything other than the arena's own sgd_step / adam_step / ema_from / copy_from (they do this themselves) and
+    ordinary torch in-place ops on the Parameter (they bump ``_version``): every cached bf16 plane of the arena's parameters
+    (all parameters when arena is None) is rebuilt on next use."""
+    bump_weight_epoch(arena)
+
+
 def _derived(weight, kind, nbytes, build):
     """-> device buffer (uint8) of `nbytes`, filled by build(buf) when the weight changed since it was last built.  The
     buffer hangs on the weight tensor OBJECT (it dies with it: a freed weight's address can be handed to another tensor),
@@ -214,7 +231,7 @@ def _derived(weight, kind, nbytes, build):
     rebuild waits for the streams that read the previous contents."""
     cache = weight.__dict__.get("_u2pl_derived")
     if cache is None:
-        cache = weight.__dict__["_u2pl_derived"] = {}
+        cache = weight.__dict__["_u2pl_derived"] = _DerivedCache()
     stamp = _weight_stamp(weight)
     ent = cache.get(kind)
     cur = torch.cuda.current_stream()
@@ -246,8 +263,9 @@ def _derived(weight, kind, nbytes, build):
 
 def _ws_ok(n_cols, k_depth):
     """can this GEMM (n_cols output channels, reduction depth k_depth) take the pre-split-weight kernel?"""
-    return (CONV_WS["on"] and not CONV_ALGO.get("bf16", 0) and n_cols > 64 and k_depth % 32 == 0
-            and query("u2pl_conv_get_split") == 1)
+    # (config 5: the STUDENT's bf16-operand calls never ask -- their call sites test ctx.bf / use_bf first -- so the fp32 teacher
+    # keeps the pre-split kernels there too)
+    return CONV_WS["on"] and n_cols > 64 and k_depth % 32 == 0 and query("u2pl_conv_get_split") == 1
 
 
 def _split_of(weight, kind, rows, K, batch, src, spec):
@@ -880,6 +898,14 @@ def conv_bn_res_pair(conv_a, bn_a, xa, conv_b, bn_b, xb):
     return _BNResPairFn.apply(ya, bn_a.weight, bn_a.bias, sa, yb, bn_b.weight, bn_b.bias, sb, meta)
 
 
+def _bn_write_nbt(m, prefix, keep_vars):
+    m.num_batches_tracked.fill_(m._nbt)
+
+
+def _bn_read_nbt(m, incompatible):
+    m._nbt = int(m.num_batches_tracked)
+
+
 class BatchNorm2d(nn.Module):
     """nn.BatchNorm2d / nn.SyncBatchNorm (base.py:6-8) with torch defaults (eps 1e-5,
     momentum 0.1, affine, running stats).  `sync=True` exchanges the per-channel
@@ -897,8 +923,8 @@ class BatchNorm2d(nn.Module):
         # torch bumps num_batches_tracked with one tiny kernel per BN per forward (236 launches / step);
         # the count is kept on the host and written into the buffer only when a state_dict is taken.
         self._nbt = 0
-        self.register_state_dict_pre_hook(lambda m, prefix, keep_vars: m.num_batches_tracked.fill_(m._nbt))
-        self.register_load_state_dict_post_hook(lambda m, incompatible: setattr(m, "_nbt", int(m.num_batches_tracked)))
+        self.register_state_dict_pre_hook(_bn_write_nbt)       # (module-level functions: lambdas would make the module unpicklable)
+        self.register_load_state_dict_post_hook(_bn_read_nbt)
 
     def forward(self, x, res=None, relu=False, drop=None, pre_sums=None):
         return _BNFn.apply(x, self.weight, self.bias, res, drop, self, relu, _grad_sink(self.weight),
@@ -1267,6 +1293,12 @@ class ParamArena:
         self.momentum_buf = None
         self.steps = 0
         self._offs = {id(p): off for p, off in zip(self.params, offs)}
+
+    def __getstate__(self):
+        # (reachable from a pickled Parameter through its gradient view: streams / in-flight collectives do not travel)
+        d = dict(self.__dict__)
+        d["_works"], d["_streams"] = [None] * len(d.get("_works", [])), ()
+        return d
 
     def momentum_view(self, p):
         """view of the momentum arena shaped / strided like parameter p (allocated on first use)"""

@@ -270,6 +270,10 @@ class SemiTrainer:
             if side_ is not main_:
                 main_.wait_stream(side_)
             K.wgrad_stream_sync()
+            if "buckets" in K._lib.SIDE_WORK:      # in-flight gradient all-reduces: wait for them before forgetting them
+                for w_ in getattr(self.arena, "_works", ()):
+                    if w_ is not None:
+                        w_.wait()
             K._lib.SIDE_WORK.clear()
         B, h, w = label_l.shape
         lrs = self._lrs()

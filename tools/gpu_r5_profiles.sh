@@ -1,40 +1,53 @@
-# Round-4 measurement artefacts, ONE script run under gpurun at the final kernel commit (tools/run_r4_profiles.sh wraps it:
-# writes the commit into gpurun_head.txt, calls gpurun, copies the results into profiles/r04_*).  Outputs: gpurun_out/r4final/.
+# Round-5 measurement artefacts, ONE script run under gpurun at the final kernel commit (tools/run_r5_profiles.sh wraps it:
+# writes the commit into gpurun_head.txt, calls gpurun, copies the results into profiles/r05_*).  Outputs: gpurun_out/r5final/.
 #   1 full GPU suite (+ full_size_parity.json)   2 smoke()   3 plain bench line with the CPU-baseline leg
 #   4 rocprofv3 kernel stats of the bench, side streams on / serialised   5 dense replay of the MFMA group: kernel trace
 #   6 MFMA-busy PMC pass (own pass, counters only)   7 loss-path group kernel stats   8 FETCH_SIZE / WRITE_SIZE PMC passes
 #   9 host overhead (cProfile of the enqueue)   10 the config-5 line (bf16 operands, 801^2)
+# Round 5: HIP graphs are on by default (the `overlap` profile and the plain line replay the four static segments; the
+# `serial` profile is eager: U2PL_GRAPHS=0, one stream); the profiled bench runs skip the direct-convolution and config-5 legs.
+# Sets of MFMA-group launches in a profiled bench run: warm-up + timed + 2 (phase leg) + 1 (roofline step) + 1 (lr 0.01) steps
+# + ONE dense replay = 16 for --steps 8 --warmup 3, 9 for --steps 3 --warmup 1.
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r4final
+O=$GRAFT_REPO_ROOT/gpurun_out/r5final
 rm -rf $O; mkdir -p $O
 HEAD=$(cat gpurun_head.txt 2>/dev/null || echo unknown)
 SHA=$(python -c "from u2pl_amd.roofline import kernel_source_hash as h; print(h())")
 echo "{\"commit\": \"$HEAD\", \"kernel_sources_sha\": \"$SHA\"}" > $O/STAMP.json
 cat $O/STAMP.json
+# 8
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c
+  timeout 420 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-direct-leg --no-config5-leg < /dev/null > $O/bench_$c.json 2> $O/bench_$c.err
+  echo "pmc $c rc=$?"
+done
+python tools/parse_pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $O/traffic.json 8 10 $HEAD
+cp $O/traffic.json profiles/r05_traffic.json    # (so that the plain bench line below carries this build's traffic record)
 # 1-3
-timeout 900 python -m pytest tests -q -m gpu < /dev/null > $O/tests.log 2>&1; echo "tests rc=$?"
+timeout 1100 python -m pytest tests -q -m gpu < /dev/null > $O/tests.log 2>&1; echo "tests rc=$?"
 tail -4 $O/tests.log | cut -c1-300
-cp gpurun_out/full_size_parity.json $O/ 2>/dev/null
+cp gpurun_out/full_size_parity.json gpurun_out/miou_gate.json $O/ 2>/dev/null
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" < /dev/null > $O/smoke.log 2>&1; tail -1 $O/smoke.log
-timeout 400 python bench.py --steps 10 --warmup 3 < /dev/null > $O/bench_plain.json 2> $O/bench_plain.err; echo "plain rc=$?"
+timeout 700 python bench.py --steps 10 --warmup 4 < /dev/null > $O/bench_plain.json 2> $O/bench_plain.err; echo "plain rc=$?"
 python - <<'P'
 import json,os
-d=json.loads(open(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/r4final/bench_plain.json").read().strip().splitlines()[-1])
+d=json.loads(open(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/r5final/bench_plain.json").read().strip().splitlines()[-1])
 print(d["ms_per_step"], d["value"], "igemm", d["roofline"]["frac"], d["roofline"]["ms_per_step"], "wgrad", d["roofline_wgrad"]["frac"], d["roofline_wgrad"]["ms_per_step"],
-      "hbm", d["roofline_hbm"]["frac"], d["roofline_hbm"]["stages_us"], "host", d.get("host_enqueue_ms"), "cpu", d.get("cpu_baseline",{}).get("value"))
+      "hbm", d["roofline_hbm"]["frac"], d["roofline_hbm"]["stages_us"], "host", d.get("host_enqueue_ms"), "cpu", d.get("cpu_baseline",{}).get("value"),
+      "calls", d.get("abi_calls_per_step"), "direct", d.get("ms_per_step_direct"), "phases", d.get("phase_ms"), "cfg5", d.get("config5",{}).get("images_per_s"))
 P
 # 4
 prof() {   # name, extra env...
   n=$1; shift
   rm -rf /tmp/prof_$n
-  env "$@" timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$n -- python bench.py --steps 8 --warmup 3 --no-cpu-baseline < /dev/null > $O/bench_${n}_under_rocprof.json 2> $O/bench_${n}.err
+  env "$@" timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$n -- python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-direct-leg --no-config5-leg < /dev/null > $O/bench_${n}_under_rocprof.json 2> $O/bench_${n}.err
   echo "prof $n rc=$?"
   f=$(find /tmp/prof_$n -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" $O/bench_${n}_kernel_stats.csv
 }
 prof overlap U2PL_DUMMY=1
-prof serial U2PL_NO_SIDE_STREAM=1 U2PL_NO_WGRAD_STREAM=1
+prof serial U2PL_GRAPHS=0 U2PL_NO_SIDE_STREAM=1 U2PL_NO_WGRAD_STREAM=1
 # 5
 rm -rf /tmp/prof_dense
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_dense -- python tools/dense_replay.py < /dev/null > $O/dense_replay.json 2> $O/dense.err; echo "dense rc=$?"
@@ -56,7 +69,7 @@ timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-tr
 python - <<'P'
 import csv,glob,collections,json,os
 f=glob.glob("/tmp/pmc_mfma/*/*counter_collection.csv")
-O=os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/r4final"
+O=os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/r5final"
 if f:
     per=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter(); dur=collections.Counter()
     for r in csv.DictReader(open(f[0])):
@@ -82,7 +95,7 @@ f=$(find /tmp/prof_lp -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$
 python - <<'P'
 import csv,os
 try:
-    rows=list(csv.DictReader(open(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/r4final/loss_path_kernel_stats.csv")))
+    rows=list(csv.DictReader(open(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/r5final/loss_path_kernel_stats.csv")))
     tot=0
     for r in rows:
         n=r['Name']
@@ -91,15 +104,8 @@ try:
     print("loss-path group: sum of average kernel durations", round(tot,1), "us")
 except Exception as e: print("lp parse failed", e)
 P
-# 8
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_$c
-  timeout 420 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline < /dev/null > $O/bench_$c.json 2> $O/bench_$c.err
-  echo "pmc $c rc=$?"
-done
-python tools/parse_pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $O/traffic.json 6 10 $HEAD
 # 9
 timeout 200 python tools/host_overhead.py < /dev/null 2>&1 | grep -v amdgpu.ids > $O/host_overhead.txt; head -4 $O/host_overhead.txt
 # 10
-timeout 300 python bench.py --bf16 --crop 801 --steps 6 --warmup 3 --no-cpu-baseline < /dev/null > $O/bench_bf16_801.json 2> $O/bench_bf16_801.err; echo "bf16 rc=$?"
+timeout 300 python bench.py --bf16 --crop 801 --steps 6 --warmup 3 --no-cpu-baseline --no-config5-leg < /dev/null > $O/bench_bf16_801.json 2> $O/bench_bf16_801.err; echo "bf16 rc=$?"
 ls -la $O | head -40

@@ -246,8 +246,14 @@ def main():
         return trainer.train_step(il, ll, iu, epoch=0)
 
     _progress("warmup")
-    for i in range(args.warmup):
+    # HIP graphs capture a static segment at its (WARM + 1)-th execution (u2pl_amd/graphs.py): with fewer warm-up steps than
+    # that, the capture would land inside the timed region -- run the missing ones here, un-timed, before the W warm-up steps
+    from u2pl_amd import graphs as GRw
+    priming = max(0, GRw.WARM + 1 - args.warmup) if GRw.enabled() else 0
+    for i in range(priming):
         step(i)
+    for i in range(args.warmup):
+        step(priming + i)
     torch.cuda.synchronize()
     from u2pl_amd import nn as KN
     from u2pl_amd import hipops as HO
@@ -444,7 +450,7 @@ def main():
         out["abi_calls_per_step"] = round(calls_timed, 1)
         out["kernel_launches_issued_by_host_per_step"] = round(launches_timed, 1)
         out["graph_replays_per_step"] = round(replays_timed, 2)
-        out["graphs"] = dict(GR.STATS, enabled=GR.enabled(), warm=GR.WARM,
+        out["graphs"] = dict(GR.STATS, enabled=GR.enabled(), warm=GR.WARM, priming_steps_before_warmup=priming,
                              segments="teacher eval pass, teacher train pass, student forward, student backward")
         if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N=1 only (the checker's port, never the product)
             from oracle import step_ref
@@ -471,7 +477,7 @@ def main():
                 trainer.__dict__.pop("_graph_cache", None)
                 gc.collect()
                 torch.cuda.empty_cache()
-                r5 = subprocess.run([sys.executable, os.path.abspath(__file__), "--bf16", "--crop", "801", "--steps", "4", "--warmup", "2",
+                r5 = subprocess.run([sys.executable, os.path.abspath(__file__), "--bf16", "--crop", "801", "--steps", "4", "--warmup", "3",
                                      "--no-cpu-baseline", "--no-config5-leg"], capture_output=True, text=True, timeout=600)
                 l5 = [ln for ln in r5.stdout.splitlines() if ln.startswith("{")]
                 if not l5:

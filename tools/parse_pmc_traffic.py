@@ -48,7 +48,9 @@ def main(fetch_dir, write_dir, out, steps_profiled, hbm_reps=0, commit="?"):
                     "WRITE_SIZE) KiB (gfx950 FETCH_SIZE x2 correction, WRITE_SIZE uncalibrated); Infinity-Cache hits are counted",
                commit=commit, kernel_sources_sha=_sha(),
                igemm_bytes_per_launch=round(ig_b), igemm_launches=ig_l,
-               # the MFMA-group launches of ONE step (the profiled run holds steps_profiled steps + one dense replay of the group)
+               # by SET COUNT: total / (steps_profiled + one dense replay).  Over-estimates: bench.py's calibration passes (~800 more
+               # launches of the group) are in the total but not in the divisor; bench.py therefore reports bytes_per_launch x its own
+               # launches per step (473) as traffic_per_step and keeps this figure as traffic_per_step_by_set_count
                igemm_bytes_per_step=round(ig_b * ig_l / (steps_profiled + 1)),
                k_conv_igemm_bytes_per_launch=round(ig_b), k_conv_igemm_launches=ig_l,
                hbm_group_bytes_per_step=round(hb), kernels={k: v for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["bytes_per_launch"] * kv[1]["launches"])[:25]})

@@ -371,13 +371,23 @@ def measure(trainer, batch, args, ms_per_step):
         if tr.get("kernel_sources_sha") != sha:
             # a PMC record of OTHER kernel sources is not this build's traffic: refuse it rather than quote a stale number
             out["roofline"]["traffic_source"] = ("none: profiles/%s was taken with kernel sources %s (commit %s), this build is %s; "
-                                                 "re-run tools/gpu_r4_profiles.sh" % (os.path.basename(tj), tr.get("kernel_sources_sha", "?"),
+                                                 "re-run tools/run_r5_profiles.sh" % (os.path.basename(tj), tr.get("kernel_sources_sha", "?"),
                                                                                       tr.get("commit", "?"), sha))
             if "roofline_hbm" in out:
                 out["roofline_hbm"]["traffic_source"] = out["roofline"]["traffic_source"]
         else:
             out["roofline"]["traffic"] = tr.get("igemm_bytes_per_launch", tr.get("k_conv_igemm_bytes_per_launch"))
-            out["roofline"]["traffic_per_step"] = tr.get("igemm_bytes_per_step")
+            # per step = the record's average bytes per launch x THIS run's launches of the group per step.  (Rounds 2-4 divided
+            # the profiled run's total by its number of timed + diagnostic steps, which counted the calibration passes' ~800
+            # launches as step traffic: 187.6 GB = "1.61x algorithmic" in round 4 was 150 GB = 1.29x by this accounting; the
+            # record's own figure is kept beside it)
+            nl = out["roofline"].get("kernel_launches_per_step")
+            if out["roofline"]["traffic"] and nl:
+                out["roofline"]["traffic_per_step"] = int(out["roofline"]["traffic"] * nl)
+                ab = out["roofline"].get("algorithmic_bytes_per_step")
+                if ab:
+                    out["roofline"]["traffic_over_algorithmic"] = round(out["roofline"]["traffic_per_step"] / ab, 3)
+            out["roofline"]["traffic_per_step_by_set_count"] = tr.get("igemm_bytes_per_step")
             out["roofline"]["traffic_source"] = ("static: profiles/%s (rocprofv3 PMC passes at commit %s, kernel sources %s = this "
                                                  "build), not measured in this run" % (os.path.basename(tj), tr.get("commit", "?"), sha))
             if "roofline_hbm" in out and tr.get("hbm_group_bytes_per_step") is not None:

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _run(monkeypatch, graphs_on, steps, S=97, arch="resnet50"):
+def _run(monkeypatch, graphs_on, steps, S=97, arch="resnet50", poke_at=None):
     from u2pl_amd import configs, graphs as G
     from u2pl_amd import _lib
     from u2pl_amd.models.model_helper import ModelBuilder
@@ -36,6 +36,14 @@ def _run(monkeypatch, graphs_on, steps, S=97, arch="resnet50"):
         il, iu = torch.randn(2, 3, S, S, generator=g), torch.randn(2, 3, S, S, generator=g)
         ll = torch.randint(0, 19, (2, S, S), generator=g)
         ll[:, :6] = 255
+        if poke_at is not None and step == poke_at:
+            # weights written OUTSIDE the arena updates (what load_state_dict / a user's p.mul_() does): the replayed segments
+            # must pick the new values up exactly like the eager ones (whose layer calls notice the stale operand stamps)
+            with torch.no_grad():
+                for m in (model, teacher):
+                    for p in m.parameters():
+                        if p.dim() == 4:
+                            p.mul_(1.03125)
         np.random.seed(30 + step)
         torch.manual_seed(40 + step)
         torch.cuda.manual_seed(50 + step)
@@ -67,6 +75,17 @@ def test_graph_replay_steps_are_bit_identical_to_eager_steps(monkeypatch):
         assert torch.equal(x, y)
     # the point of the exercise: the replayed steps issue a fraction of the eager steps' C-ABI calls (<= 900)
     assert a["calls"][-1] <= 900 and a["calls"][-1] < 0.4 * b["calls"][-1], (a["calls"], b["calls"])
+
+
+def test_replayed_segments_follow_weights_written_outside_the_arena_updates(monkeypatch):
+    a = _run(monkeypatch, True, 6, poke_at=4)
+    b = _run(monkeypatch, False, 6, poke_at=4)
+    assert a["stats"]["replays"] == 16
+    assert np.array_equal(a["meters"], b["meters"]), (a["meters"], b["meters"])
+    for k in ("w", "t", "rm", "rv"):
+        assert torch.equal(a[k], b[k]), k
+    c = _run(monkeypatch, True, 6)
+    assert not np.array_equal(a["meters"][4:], c["meters"][4:])       # (the poke does change the step)
 
 
 def test_graphs_fall_back_to_eager_under_a_dropout_hook_or_profile(monkeypatch):

@@ -68,6 +68,25 @@ class _Capture:
         return False
 
 
+def _conv_weights(modules):
+    return [p for mod in modules for p in mod.parameters() if p.dim() == 4]
+
+
+def _refresh_operands(ent, modules, owner):
+    """A replayed segment never passes through nn._derived, which is where the eager path notices a weight that was written
+    OUTSIDE the arena updates (load_state_dict, p.mul_(), nn.invalidate_weights()) and rebuilds its bf16 planes.  Before every
+    replay: a cheap signature of the segment's conv weights (global epoch + sum of tensor versions); when it moved, rebuild the
+    stale planes in place (nn.presplit) -- the graph then reads the fresh ones by address."""
+    ws = ent.get("weights")
+    if ws is None:
+        ws = ent["weights"] = _conv_weights(modules)
+    sig = (K.WEIGHT_EPOCH[0], sum(p._version for p in ws))
+    if sig != ent.get("sig"):
+        if ent.get("sig") is not None:
+            K.presplit(ws, owner)
+        ent["sig"] = sig
+
+
 def _key(xs, modules):
     """what a captured segment is valid for: input shapes, train / eval mode, and the convolution algorithm switches (a graph
     recorded with Winograd kernels must not be replayed after U2PL_CONV_WINO / _BF16 / _SPLIT / _WS changed)"""
@@ -114,6 +133,7 @@ class GraphedNoGrad:
                 return self._eager(xs)
             ent.update(graph=g, static_in=static_in, outs=outs, bumps=cap.bumps, u=u)
             STATS["captures"] += 1
+        _refresh_operands(ent, self.modules, self)
         for s, x in zip(ent["static_in"], xs):
             if s.data_ptr() != x.data_ptr():
                 s.copy_(x)
@@ -198,6 +218,7 @@ class GraphedTrain:
             STATS["captures"] += 2
         if self._dummy is None:
             self._dummy = torch.zeros((), device=x.device, requires_grad=True)
+        _refresh_operands(ent, [self.model], self)
         ent["static_x"].copy_(x)
         if ent["u"] is not None:
             ent["u"].uniform_()

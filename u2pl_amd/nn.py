@@ -433,6 +433,9 @@ class _ConvFn(torch.autograd.Function):
         Wo = (W + 2 * pad - dil * (S - 1) - 1) // stride + 1
         if not weight.is_contiguous(memory_format=_CL) and not (R == 1 and S == 1 and weight.is_contiguous()):
             raise HipError("conv weight must be stored channels_last ([Cout][R][S][Cin])")
+        # the second output (the fused BatchNorm sums) is not differentiable: without this autograd materialises a zero fp64
+        # gradient for it in front of every backward call (116 fill launches per step, profiles/r05_bench_serial_kernel_stats.csv)
+        ctx.set_materialize_grads(False)
         y = new_act(N, Cout, Ho, Wo, x.device)
         col = None
         # `recording`: grad mode at the call site (inside forward() it is always off); the teacher's calls run under no_grad
@@ -489,6 +492,8 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, gsums=None):
+        if gy is None:      # (only the non-differentiable sums were used downstream)
+            return (None,) * 10
         x, weight, col = ctx.saved_tensors
         N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ldx = ctx.geom
         gy, ldg = as_rows(gy)

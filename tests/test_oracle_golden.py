@@ -383,6 +383,44 @@ def test_step_port_with_dropout_on_pinned_to_the_reference_train_loop():
     assert any(x.startswith("teacher:decoder.classifier.7|1|") for x in mine)   # teacher dropout is live in train mode
 
 
+def test_step_port_pinned_to_the_reference_on_the_miou_gate_task():
+    """The first two steps of the mIoU-gate epoch (tests/golden/miou_gate.npz: the reference's own train() on the learnable
+    synthetic task, R101 at 193 x 193, default configuration values, un-sharpened classifier, epochs = 1 so the poly lr decays
+    inside the epoch) through the CPU port: another data distribution and schedule the port is pinned on (the GPU gate itself
+    compares the HIP path with the reference's fixture directly, not with the port)."""
+    import torch
+    import miou_gate as MG
+    from oracle.parity_dropout import KeyedMasks
+    from oracle.step_ref import CpuStepRef
+    from u2pl_amd import configs
+    from u2pl_amd.models.model_helper import ModelBuilder
+
+    g = golden("miou_gate")
+    G = MG.GATE
+    init_seed, data_seed, np_seed, torch_seed, dropout_seed = (int(x) for x in g["seeds"])
+    steps = int(g["steps"])
+    data = MG.gate_data(data_seed, 2, G["B"], G["S"])          # (a prefix of the epoch's stream: same generator, same order)
+    full_first = MG.gate_data(data_seed, steps, G["B"], G["S"])[0]
+    assert torch.equal(data[0][0], full_first[0]) and torch.equal(data[0][2], full_first[2])
+    cfg = configs.cityscapes_semi(arch=G["arch"], crop=G["S"], batch_size=G["B"], sync_bn=False, epochs=G["epochs"])
+    cfg["criterion"]["kwargs"]["min_kept"] = G["min_kept"]
+    torch.manual_seed(init_seed)
+    sd = {k: v.detach().clone() for k, v in ModelBuilder(cfg["net"]).state_dict().items()}
+    ok = cfg["trainer"]["optimizer"]["kwargs"]
+    ref = CpuStepRef(arch=G["arch"], num_classes=G["C"], aux=True, epochs=G["epochs"], steps_per_epoch=steps, lr=ok["lr"],
+                     weight_decay=ok["weight_decay"], lr_times=1, sup_only_epoch=0, ohem=(0.7, G["min_kept"]), p_drop=0.1,
+                     contra=dict(cfg["trainer"]["contrastive"]), state_dict=sd, dropout_masks=KeyedMasks(dropout_seed))
+    np.random.seed(np_seed)
+    torch.manual_seed(torch_seed)
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    for i in range(2):
+        o = ref.step(*data[i], epoch=0)
+        tol = 1e-5 if i == 0 else 2e-3
+        for name, a, b in (("sup", o["sup"], g["meters"][i][2]), ("unsup", o["unsup"], g["meters"][i][3]),
+                           ("contra", o["contra"], g["meters"][i][4])):
+            assert abs(a - float(b)) <= tol * max(1.0, abs(float(b))), (i, name, a, float(b))
+
+
 def test_cutout_and_classmix():
     """the two other strong augmentations (augmentation.py:486-541) against the reference's generate_unsup_data"""
     import torch

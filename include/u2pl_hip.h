@@ -321,6 +321,21 @@ int u2pl_bn_bwd_sums_f32(const float* dy, long lddy, const float* x, long ldx, c
 int u2pl_bn_finalize_f32(const double* sums, double count, const float* pivot, int C, float eps, float momentum,
                          float* mean, float* invstd, float* running_mean, float* running_var, hipStream_t stream);
 int u2pl_bn_eval_invstd_f32(const float* running_var, int C, float eps, float* invstd, hipStream_t stream);
+/* round 5 (fewer launches on the dependency chain conv -> statistics -> normalise; same arithmetic, same bits):
+ *  u2pl_bn_finish_finalize_f32    u2pl_colreduce_finish_f32 + u2pl_bn_finalize_f32 in one launch (single-rank train mode:
+ *                                 no all-reduce between them); partial = the conv epilogue's [nblk][2][C] float partial sums;
+ *                                 sums_out (double [2C], may be NULL) receives what u2pl_colreduce_finish_f32 would write
+ *  u2pl_bn_eval_invstd_multi_f32  u2pl_bn_eval_invstd_f32 for every BatchNorm of a model at once; jobs_dev: device array of
+ *                                 u2pl_bn_eval_invstd_job_bytes() = 32-byte records {const float* running_var; float* invstd;
+ *                                 int64 first_element; int32 C; float eps}, first_element = running sum of the previous C's,
+ *                                 total = sum of C
+ *  u2pl_bn_bwd_apply_pg_f32       u2pl_bn_bwd_apply_f32 + the two u2pl_sums_to_f32 calls of the layer's parameter gradients
+ *                                 (dgamma = psums[C..2C), dbeta = psums[0..C), psums = the LOCAL backward sums) */
+int u2pl_bn_finish_finalize_f32(const float* partial, int nblk, int C, double count, const float* pivot, float eps,
+                                float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                                double* sums_out, hipStream_t stream);
+size_t u2pl_bn_eval_invstd_job_bytes(void);
+int u2pl_bn_eval_invstd_multi_f32(const void* jobs_dev, int njobs, long total, hipStream_t stream);
 int u2pl_bn_apply_f32(const float* x, long ldx, const float* mean, const float* invstd, const float* gamma,
                       const float* beta, const float* res, long ldr, int relu, const float* drop,
                       long rows_per_image, float* y, long ldy, long M, int C, hipStream_t stream);
@@ -328,6 +343,11 @@ int u2pl_bn_bwd_apply_f32(const float* dy, long lddy, const float* x, long ldx, 
                           const float* mean, const float* invstd, const float* gamma, const float* drop,
                           long rows_per_image, const double* sums, double count, float* dx, long lddx, float* dres,
                           long lddr, long M, int C, hipStream_t stream);
+int u2pl_bn_bwd_apply_pg_f32(const float* dy, long lddy, const float* x, long ldx, const float* y, long ldy,
+                             const float* mean, const float* invstd, const float* gamma, const float* drop,
+                             long rows_per_image, const double* sums, double count, float* dx, long lddx, float* dres,
+                             long lddr, long M, int C, const double* psums, float* gsink, float* bsink, int accumulate,
+                             hipStream_t stream);
 int u2pl_sums_to_f32(const double* sums, int n, float scale, int accumulate, float* out, hipStream_t stream);
 /* nn.MaxPool2d(3,2,1,ceil_mode=True): resnet.py:189-191 */
 int u2pl_maxpool3s2_fwd_f32(const float* x, long ldx, int N, int H, int W, int C, int Ho, int Wo, float* y, long ldy,

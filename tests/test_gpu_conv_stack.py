@@ -641,3 +641,46 @@ def test_adam_step_matches_torch_adam():
     for i in range(len(shapes)):
         assert (sd["state"][i]["exp_avg"] - rs[i]["exp_avg"]).abs().max().item() <= 1e-6
         assert (sd["state"][i]["exp_avg_sq"] - rs[i]["exp_avg_sq"]).abs().max().item() <= 1e-6
+
+
+def test_fused_batchnorm_launches_give_the_separate_launches_bits():
+    """round 5: (1) ordered finish of the conv epilogue's partial statistics + finalisation in ONE launch, (2) the parameter
+    gradients inside the backward-apply launch, (3) eval-mode 1 / sqrt(var + eps) of a whole model in one launch -- each
+    against the separate launches it replaces (U2PL_NO_BN_FINISH_FUSION=1): outputs, input / parameter gradients and
+    running statistics BIT-identical, train mode with residual + ReLU + dropout scale, and an eval-mode stack."""
+    from u2pl_amd import nn as Kn
+    saved = Kn.FUSE_BN_FINISH
+    outs = []
+    try:
+        for fused in (True, False):
+            Kn.FUSE_BN_FINISH = fused
+            torch.manual_seed(3)
+            conv = Kn.Conv2d(256, 384, 1, bias=False).to(DEV)
+            bn = Kn.BatchNorm2d(384).to(DEV)
+            conv2 = Kn.Conv2d(384, 128, 3, padding=1, bias=False).to(DEV)
+            bn2 = Kn.BatchNorm2d(128).to(DEV)
+            arena = Kn.ParamArena([list(conv.parameters()) + list(bn.parameters()) + list(conv2.parameters()) + list(bn2.parameters())])
+            with torch.no_grad():
+                bn.weight.normal_(1.0, 0.2), bn.bias.normal_(0, 0.2), bn.running_mean.normal_(0, 0.1)
+            g = torch.Generator(device=DEV).manual_seed(9)
+            x = torch.randn(2, 256, 23, 19, device=DEV, generator=g).contiguous(memory_format=CL).requires_grad_(True)
+            r = torch.randn(2, 384, 23, 19, device=DEV, generator=g).contiguous(memory_format=CL).requires_grad_(True)
+            drop = (torch.rand(2, 384, device=DEV, generator=g) > 0.1).float() / 0.9
+            arena.zero_grad()
+            y = Kn.conv_bn(conv, bn, x, res=r, relu=True, drop=drop)
+            z = Kn.conv_bn(conv2, bn2, y, relu=True)
+            gz = torch.randn(z.shape, device=DEV, generator=g).contiguous(memory_format=CL)
+            z.backward(gz)
+            Kn.wgrad_stream_sync()
+            bn.eval(), bn2.eval()
+            with torch.no_grad(), Kn.eval_invstd(torch.nn.ModuleList([bn, bn2])):
+                e = Kn.conv_bn(conv2, bn2, Kn.conv_bn(conv, bn, x.detach(), res=r.detach(), relu=True), relu=True)
+            torch.cuda.synchronize()
+            outs.append([t.detach().clone() for t in (y, z, x.grad, r.grad, arena.grad, bn.running_mean, bn.running_var,
+                                                      bn2.running_mean, bn2.running_var, e)])
+    finally:
+        Kn.FUSE_BN_FINISH = saved
+    names = "y z dx dres arena_grad rm1 rv1 rm2 rv2 eval".split()
+    for n, a, b in zip(names, outs[0], outs[1]):
+        assert torch.equal(a, b), n
+    assert float(outs[0][4].abs().sum()) > 0

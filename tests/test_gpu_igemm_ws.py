@@ -56,6 +56,7 @@ def _run(Kn, ws_on, conv, x, gy, pivot=None):
         sums = None
     else:
         y, sums = conv(x, stat_pivot=pivot)
+        sums = Kn.finished_sums(sums, conv.out_channels)        # (the conv hands out its epilogue's raw partials since round 5)
     y.backward(gy)
     torch.cuda.synchronize()
     return y.detach(), x.grad.detach(), sums

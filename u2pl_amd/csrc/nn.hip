@@ -220,6 +220,67 @@ U2PL_API int u2pl_bn_finalize_f32(const double* sums, double count, const float*
     U2PL_LAUNCH_CHECK();
     return 0;
 }
+// ---- round 5: the ordered finish of the conv epilogue's partial statistics AND the BatchNorm finalisation in ONE launch
+// (single-rank train mode: nothing sits between the two; under a process group the all-reduce does and the two kernels
+// above stay).  Same arithmetic in the same order as k_colreduce_final followed by k_bn_finalize: a block owns 32 channels,
+// lanes 0..31 of a wave column reduce S1, lanes 32..63 S2, 16 row groups with 8 loads in flight each, ordered LDS combine.
+__global__ __launch_bounds__(1024) void k_bn_finish_finalize(const float* __restrict__ partial, int nblk, int C, double count,
+                                                             const float* __restrict__ pivot, float eps, float momentum,
+                                                             float* __restrict__ mean, float* __restrict__ invstd,
+                                                             float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                             double* __restrict__ sums_out) {
+    __shared__ double sh[16][64];
+    __shared__ double tot[64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 32 + (cl & 31);
+    const int i = (cl >> 5) * C + c;                 // column of the [2][C] partial rows: S1 of channel c, or S2
+    double acc = 0.0;
+    if (c < C) {
+        const float* p = partial + i;
+        int b = rg;
+        for (; b + 7 * 16 < nblk; b += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(long)(b + u * 16) * 2 * C];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (double)v[u];
+        }
+        for (; b < nblk; b += 16) acc += (double)p[(long)b * 2 * C];
+    }
+    sh[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][cl];
+        tot[cl] = t;
+        if (sums_out && c < C) sums_out[i] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && c < C) {
+        const double m1 = tot[cl] / count, m2 = tot[32 + cl] / count;
+        const double pv = pivot ? (double)pivot[c] : 0.0;
+        double var = m2 - m1 * m1;
+        if (var < 0.0) var = 0.0;
+        const double mu = pv + m1;
+        mean[c] = (float)mu;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+        }
+    }
+}
+U2PL_API int u2pl_bn_finish_finalize_f32(const float* partial, int nblk, int C, double count, const float* pivot, float eps,
+                                         float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                                         double* sums_out, hipStream_t stream) {
+    if (!partial || nblk <= 0 || C <= 0 || !mean || !invstd) return U2PL_EINVAL;
+    U2PL_LAUNCH(k_bn_finish_finalize, dim3(cdiv(C, 32)), dim3(1024), 0, stream, partial, nblk, C, count, pivot, eps, momentum, mean,
+                invstd, running_mean, running_var, sums_out);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
 // eval mode: invstd from running_var
 __global__ void k_bn_eval_prep(const float* __restrict__ rv, int C, float eps, float* __restrict__ invstd) {
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x)
@@ -227,6 +288,30 @@ __global__ void k_bn_eval_prep(const float* __restrict__ rv, int C, float eps, f
 }
 U2PL_API int u2pl_bn_eval_invstd_f32(const float* running_var, int C, float eps, float* invstd, hipStream_t stream) {
     U2PL_LAUNCH(k_bn_eval_prep, dim3(cdiv(C, 256)), dim3(256), 0, stream, running_var, C, eps, invstd);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+// every BatchNorm of a model in ONE launch (an eval-mode pass used to issue one k_bn_eval_prep per layer: 115 launches of a
+// few hundred threads per R101 pass).  jobs: device array of {running_var ptr, invstd ptr, first element, C, eps} (32 bytes).
+struct EvalPrepJob { const float* rv; float* out; long long begin; int C; float eps; };
+__global__ void k_bn_eval_prep_multi(const EvalPrepJob* __restrict__ jobs, int njobs, long total) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = njobs - 1;
+        while (lo < hi) {                     // last job whose first element is <= e
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].begin <= e) lo = mid; else hi = mid - 1;
+        }
+        const EvalPrepJob j = jobs[lo];
+        const int c = (int)(e - j.begin);
+        if (c < j.C) j.out[c] = (float)(1.0 / sqrt((double)j.rv[c] + (double)j.eps));
+    }
+}
+U2PL_API size_t u2pl_bn_eval_invstd_job_bytes(void) { return sizeof(EvalPrepJob); }
+U2PL_API int u2pl_bn_eval_invstd_multi_f32(const void* jobs_dev, int njobs, long total, hipStream_t stream) {
+    if (njobs <= 0 || total <= 0) return 0;
+    if (!jobs_dev) return U2PL_EINVAL;
+    U2PL_LAUNCH(k_bn_eval_prep_multi, dim3(grid_for(total, 256)), dim3(256), 0, stream, (const EvalPrepJob*)jobs_dev, njobs, total);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -270,7 +355,14 @@ __global__ U2PL_HBM_KERNEL void k_bn_bwd_apply(const float* __restrict__ dy, lon
                                const float* __restrict__ invstd, const float* __restrict__ gamma,
                                const float* __restrict__ drop, long rows_per_image,
                                const double* __restrict__ sums, double count, float* __restrict__ dx, long lddx,
-                               float* __restrict__ dres, long lddr, long M, int C) {
+                               float* __restrict__ dres, long lddr, long M, int C, const double* __restrict__ psums,
+                               float* __restrict__ gsink, float* __restrict__ bsink, int accumulate) {
+    if (psums) {   // (u2pl_bn_bwd_apply_pg_f32) the parameter gradients ride along: k_sums_to_f32's arithmetic, dgamma = S1, dbeta = S0
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < C; i += (long)gridDim.x * blockDim.x) {
+            gsink[i] = (accumulate ? gsink[i] : 0.f) + (float)(psums[C + i] * (double)1.0f);
+            bsink[i] = (accumulate ? bsink[i] : 0.f) + (float)(psums[i] * (double)1.0f);
+        }
+    }
     const int C4 = C >> 2;
     const long total = M * C4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -308,7 +400,22 @@ U2PL_API int u2pl_bn_bwd_apply_f32(const float* dy, long lddy, const float* x, l
                                    float* dres, long lddr, long M, int C, hipStream_t stream) {
     if (C % 4) return U2PL_EINVAL;
     U2PL_LAUNCH(k_bn_bwd_apply, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, dy, lddy, x, ldx, y, ldy,
-                       mean, invstd, gamma, drop, rows_per_image, sums, count, dx, lddx, dres, lddr, M, C);
+                       mean, invstd, gamma, drop, rows_per_image, sums, count, dx, lddx, dres, lddr, M, C, (const double*)nullptr,
+                       (float*)nullptr, (float*)nullptr, 0);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+// the same + the layer's parameter gradients written by the same launch (dgamma = psums[C..2C), dbeta = psums[0..C): the LOCAL
+// backward sums -- single-rank training passes sums == psums; `accumulate` != 0 adds into gsink / bsink like u2pl_sums_to_f32)
+U2PL_API int u2pl_bn_bwd_apply_pg_f32(const float* dy, long lddy, const float* x, long ldx, const float* y, long ldy,
+                                      const float* mean, const float* invstd, const float* gamma, const float* drop,
+                                      long rows_per_image, const double* sums, double count, float* dx, long lddx,
+                                      float* dres, long lddr, long M, int C, const double* psums, float* gsink, float* bsink,
+                                      int accumulate, hipStream_t stream) {
+    if (C % 4 || !psums || !gsink || !bsink) return U2PL_EINVAL;
+    U2PL_LAUNCH(k_bn_bwd_apply, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, dy, lddy, x, ldx, y, ldy,
+                       mean, invstd, gamma, drop, rows_per_image, sums, count, dx, lddx, dres, lddr, M, C, psums, gsink, bsink,
+                       accumulate);
     U2PL_LAUNCH_CHECK();
     return 0;
 }

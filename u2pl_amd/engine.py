@@ -55,9 +55,11 @@ def validate(model, loader, cfg, device):
     model.eval()
     C, ign = cfg["net"]["num_classes"], cfg["dataset"]["ignore_label"]
     hist = torch.zeros(3 * C, dtype=torch.int64, device=device)
+    from . import nn as K
     for images, labels in loader:
         images, labels = images.to(device, non_blocking=True), labels.to(device, non_blocking=True).long().contiguous()
-        out = model(images, need_aux=False, need_rep=False)["pred"]
+        with K.eval_invstd(model):
+            out = model(images, need_aux=False, need_rep=False)["pred"]
         large = H.bilinear_up(out, labels.shape[1:])
         N, _, Hh, Ww = large.shape
         call("u2pl_confusion_hist_f32", large, labels, ign, N, C, Hh, Ww, hist)

@@ -425,7 +425,8 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil, wsink, bsink, pivot=None, recording=True):
         """pivot (a BatchNorm running_mean) requests the fused train-mode BN statistics of the output:
-        returns (y, sums) with sums = double [2C+1] (S1, S2 pivot-shifted; last slot spare for the count)."""
+        returns (y, partials) with partials = float32 [nblk][2][C] (S1, S2 pivot-shifted, per row block of the epilogue);
+        finished_sums() / the BatchNorm's fused finish turn them into the double [2C] sums."""
         x, ldx = as_rows(x)
         N, Cin, H, W = x.shape
         Cout, _, R, S = weight.shape
@@ -460,8 +461,7 @@ class _ConvFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 col = V     # the transformed input is the weight gradient's operand: keep it instead of redoing it
             if pivot is not None:
-                sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=x.device)
-                call("u2pl_colreduce_finish_f32", part, part.shape[0], Cout, sums)
+                sums = part      # raw [nblk][2][Cout] partials: the BatchNorm finishes them (fused with its finalisation, round 5)
         elif pivot is not None and pivot is not False:
             ws = not use_bf and _ws_ok(Cout, R * S * Cin)
             nblk = query("u2pl_igemm_ws_stat_blocks", N, Ho, Wo) if ws else query("u2pl_conv2d_fwd_stat_blocks", N, Ho, Wo, Cout)
@@ -472,8 +472,7 @@ class _ConvFn(torch.autograd.Function):
             else:
                 call("u2pl_conv2d_fwd_bnstats" + sfx, x, ldx, weight, bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S, stride,
                      pad, dil, pivot, part)
-            sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=x.device)
-            call("u2pl_colreduce_finish_f32", part, nblk, Cout, sums)
+            sums = part          # raw partials, see above
         elif not use_bf and _ws_ok(Cout, R * S * Cin):
             call("u2pl_conv2d_fwd_ws_f32", x, ldx, ws_forward(weight), bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S,
                  stride, pad, dil)
@@ -628,6 +627,20 @@ class Conv2d(nn.Module):
 
 
 # ------------------------------------------------------------------ batch norm (+res +relu +dropout)
+def finished_sums(pre, C, out=None):
+    """conv-epilogue statistics -> double [2C(+1)] pivot-shifted sums: `pre` is either the raw float32 [nblk][2][C] partials
+    (ordered finish here) or already-finished double sums"""
+    if pre.dtype == torch.float32:
+        if out is None:
+            out = torch.empty(2 * C + 1, dtype=torch.float64, device=pre.device)
+        call("u2pl_colreduce_finish_f32", pre, pre.shape[0], C, out)
+        return out
+    if out is not None:
+        out.copy_(pre)
+        return out
+    return pre
+
+
 class _BNFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, res, drop, mod, relu, gsink, bsink, pre_sums=None):
@@ -643,26 +656,30 @@ class _BNFn(torch.autograd.Function):
         sync = mod.sync and _world() > 1
         if training:
             pivot = mod.running_mean
-            if pre_sums is not None:     # statistics came out of the producing conv's epilogue
-                sums = pre_sums
-            else:
-                sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
-                wsb = _ws(query("u2pl_colreduce_workspace_bytes", M, 1, C), dev)
-                call("u2pl_bn_stats_f32", x, ldx, M, C, pivot, wsb, sums)
-            count = float(M)
-            if sync:
-                sums[2 * C] = float(M)
-                _all_reduce(sums, "syncbn_allreduce", group=mod.group)
-                count = float(M * _world())  # equal per-rank shapes (drop_last loaders)
             mean = torch.empty(C, dtype=torch.float32, device=dev)
             invstd = torch.empty(C, dtype=torch.float32, device=dev)
-            call("u2pl_bn_finalize_f32", sums, count, pivot, C, mod.eps, mod.momentum, mean, invstd, mod.running_mean,
-                 mod.running_var)
+            count = float(M)
+            if pre_sums is not None and pre_sums.dtype == torch.float32 and not sync and FUSE_BN_FINISH:
+                # single rank: ordered finish of the conv epilogue's partials + finalisation in ONE launch (same bits)
+                call("u2pl_bn_finish_finalize_f32", pre_sums, pre_sums.shape[0], C, count, pivot, mod.eps, mod.momentum, mean,
+                     invstd, mod.running_mean, mod.running_var, None)
+            else:
+                if pre_sums is not None:     # statistics came out of the producing conv's epilogue
+                    sums = finished_sums(pre_sums, C)
+                else:
+                    sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+                    wsb = _ws(query("u2pl_colreduce_workspace_bytes", M, 1, C), dev)
+                    call("u2pl_bn_stats_f32", x, ldx, M, C, pivot, wsb, sums)
+                if sync:
+                    sums[2 * C] = float(M)
+                    _all_reduce(sums, "syncbn_allreduce", group=mod.group)
+                    count = float(M * _world())  # equal per-rank shapes (drop_last loaders)
+                call("u2pl_bn_finalize_f32", sums, count, pivot, C, mod.eps, mod.momentum, mean, invstd, mod.running_mean,
+                     mod.running_var)
             mod._nbt += 1   # host counter; the buffer is materialised lazily (see BatchNorm2d)
         else:
             mean = mod.running_mean
-            invstd = torch.empty(C, dtype=torch.float32, device=dev)
-            call("u2pl_bn_eval_invstd_f32", mod.running_var, C, mod.eps, invstd)
+            invstd = _eval_invstd(mod, C, dev)
             count = float(M)
         call("u2pl_bn_apply_f32", x, ldx, mean, invstd, gamma, beta, rr, ldr or 0, int(relu), drop, H * W, y, C, M, C)
         ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma, drop)
@@ -681,8 +698,11 @@ class _BNFn(torch.autograd.Function):
         wsb = _ws(query("u2pl_colreduce_workspace_bytes", M, 1, C), dev)
         call("u2pl_bn_bwd_sums_f32", gy, ldg, x, ldx, y, C, mean, invstd, drop, H * W, M, C, wsb, sums)
         dgamma = dbeta = None
+        # single rank, gradients into the arena: the two parameter-gradient writes ride in the apply launch (same arithmetic)
+        pg_fused = (FUSE_BN_FINISH and ctx.needs_input_grad[1] and ctx.gsink is not None and ctx.needs_input_grad[0]
+                    and not (sync and training))
         # parameter gradients are LOCAL sums (DDP averages them later), like torch SyncBN
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not pg_fused:
             if ctx.gsink is not None:
                 call("u2pl_sums_to_f32", sums[C:], C, 1.0, 1, ctx.gsink)
                 call("u2pl_sums_to_f32", sums, C, 1.0, 1, ctx.bsink)
@@ -697,7 +717,12 @@ class _BNFn(torch.autograd.Function):
             _all_reduce(sums, "syncbn_allreduce", group=ctx.group)
         dx = new_act(N, C, H, W, dev) if ctx.needs_input_grad[0] else None
         dres = new_act(N, C, H, W, dev) if has_res and ctx.needs_input_grad[3] else None
-        if dx is not None:
+        if pg_fused:
+            call("u2pl_bn_bwd_apply_pg_f32", gy, ldg, x, ldx, y, C, mean, invstd, gamma, drop, H * W,
+                 sums if training else None, count, dx, C, dres, C, M, C, sums, ctx.gsink, ctx.bsink, 1)
+            _mark_ready(ctx.gsink)
+            _mark_ready(ctx.bsink)
+        elif dx is not None:
             call("u2pl_bn_bwd_apply_f32", gy, ldg, x, ldx, y, C, mean, invstd, gamma, drop, H * W,
                  sums if training else None, count, dx, C, dres, C, M, C)
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None
@@ -712,7 +737,7 @@ class _BNFn(torch.autograd.Function):
 def _bn_local_sums(x, ldx, M, C, mod, pre_sums, out):
     """pivot-shifted sums of one BatchNorm into out (double [2C+1], slot 2C = the local row count)"""
     if pre_sums is not None:
-        out.copy_(pre_sums)
+        finished_sums(pre_sums, C, out)
     else:
         wsb = _ws(query("u2pl_colreduce_workspace_bytes", M, 1, C), x.device)
         call("u2pl_bn_stats_f32", x, ldx, M, C, mod.running_mean, wsb, out)
@@ -937,6 +962,66 @@ class BatchNorm2d(nn.Module):
 
 
 FUSE_EVAL_BN = os.environ.get("U2PL_NO_EVAL_BN_FUSION") is None
+# round 5: fewer tiny launches on the conv -> statistics -> normalise chain (same arithmetic, same bits; U2PL_NO_BN_FINISH_FUSION=1:
+# the separate launches): finish + finalize in one, parameter gradients inside the backward apply, eval-mode invstd of a whole
+# model in one launch (eval_invstd)
+FUSE_BN_FINISH = os.environ.get("U2PL_NO_BN_FINISH_FUSION") is None
+_EVAL_INVSTD = {}
+
+
+def _eval_invstd(bn, C, dev):
+    v = _EVAL_INVSTD.get(id(bn))
+    if v is not None:
+        return v
+    invstd = torch.empty(C, dtype=torch.float32, device=dev)
+    call("u2pl_bn_eval_invstd_f32", bn.running_var, C, bn.eps, invstd)
+    return invstd
+
+
+class eval_invstd:
+    """with eval_invstd(model): <eval-mode pass(es)> -- 1 / sqrt(running_var + eps) of EVERY BatchNorm of the model by ONE launch
+    up front (u2pl_bn_eval_invstd_multi_f32) instead of one launch per layer and pass.  Valid while no train-mode pass of the
+    model runs inside the block (eval-mode passes do not touch the running statistics)."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def __enter__(self):
+        import numpy as np
+        if not FUSE_BN_FINISH:
+            self.ids = []
+            return self
+        m = self.model
+        bns = [b for b in m.modules() if isinstance(b, BatchNorm2d)]
+        key = tuple(b.running_var.data_ptr() for b in bns)
+        prep = m.__dict__.get("_u2pl_evalprep")
+        if prep is None or prep["key"] != key:
+            if not bns or not bns[0].running_var.is_cuda:
+                self.ids = []
+                return self
+            dev = bns[0].running_var.device
+            total = sum(b.num_features for b in bns)
+            out = torch.empty(total, dtype=torch.float32, device=dev)
+            jobs = np.zeros(len(bns), dtype=np.dtype([("rv", "<u8"), ("out", "<u8"), ("begin", "<i8"), ("C", "<i4"), ("eps", "<f4")]))
+            assert jobs.dtype.itemsize == query("u2pl_bn_eval_invstd_job_bytes")
+            off, views = 0, []
+            for i, b in enumerate(bns):
+                jobs[i] = (b.running_var.data_ptr(), out.data_ptr() + 4 * off, off, b.num_features, b.eps)
+                views.append(out[off:off + b.num_features])
+                off += b.num_features
+            from .hipops import h2d
+            prep = m.__dict__["_u2pl_evalprep"] = dict(key=key, bns=bns, out=out, views=views, total=total,
+                                                       jobs=h2d(torch.from_numpy(jobs.view(np.uint8).copy()), dev))
+        call("u2pl_bn_eval_invstd_multi_f32", prep["jobs"], len(prep["bns"]), prep["total"])
+        self.ids = [id(b) for b in prep["bns"]]
+        for b, v in zip(prep["bns"], prep["views"]):
+            _EVAL_INVSTD[id(b)] = v
+        return self
+
+    def __exit__(self, *a):
+        for i in self.ids:
+            _EVAL_INVSTD.pop(i, None)
+        return False
 
 
 def conv_bn_eval(conv, bn, x, res=None, relu=False):
@@ -955,8 +1040,7 @@ def conv_bn_eval(conv, bn, x, res=None, relu=False):
     Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (S - 1) - 1) // stride + 1
     dev = x.device
-    invstd = torch.empty(Cout, dtype=torch.float32, device=dev)
-    call("u2pl_bn_eval_invstd_f32", bn.running_var, Cout, bn.eps, invstd)
+    invstd = _eval_invstd(bn, Cout, dev)
     rr, ldr = (None, 0) if res is None else as_rows(res)
     epi = (bn.running_mean, invstd, bn.weight, bn.bias, rr, ldr, int(relu))
     y = new_act(N, Cout, Ho, Wo, dev)

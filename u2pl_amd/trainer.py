@@ -218,7 +218,8 @@ class SemiTrainer:
     # ---- the step's static segments, eager for the first calls and as HIP graphs from then on (u2pl_amd.graphs) ----
     def _teacher_eval_pass(self, image_u, hw):
         """pseudo labels (train_semi.py:317-324): eval-mode teacher, bilinear up, softmax max / arg-max"""
-        pred_u_t = self.teacher(image_u, need_aux=False, need_rep=False)["pred"]
+        with K.eval_invstd(self.teacher):
+            pred_u_t = self.teacher(image_u, need_aux=False, need_rep=False)["pred"]
         return H.pseudo_label(H.bilinear_up(pred_u_t, hw))
 
     def _teacher_train_pass(self, image_all):

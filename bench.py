@@ -243,7 +243,7 @@ def main():
     def step(i):
         il, ll, iu = batches[i % len(batches)]
         _progress(step=i)
-        return trainer.train_step(il, ll, iu, epoch=0)
+        return trainer.train_step(il, ll, iu, epoch=1)
 
     _progress("warmup")
     # HIP graphs capture a static segment at its (WARM + 1)-th execution (u2pl_amd/graphs.py): with fewer warm-up steps than
@@ -342,13 +342,13 @@ def main():
     # into the main stream (teacher passes, weight gradients) and an event at every phase boundary.  Serialised, the phases
     # add up to more than the overlapped step (`phase_sum_ms` vs `ms_per_step`): what the side streams hide is the difference.
     KNp = KN
-    trainer.train_step(*batches[0], epoch=0)     # (warm: same allocator / operand state as the timed steps)
+    trainer.train_step(*batches[0], epoch=1)     # (warm: same allocator / operand state as the timed steps)
     torch.cuda.synchronize()
     saved_side, saved_wg = getattr(trainer, "_side", None), KNp._WGRAD["enabled"]
     trainer._side, KNp._WGRAD["enabled"] = torch.cuda.current_stream(), False
     try:
         trainer.phase_log = []
-        trainer.train_step(*batches[1 % len(batches)], epoch=0)
+        trainer.train_step(*batches[1 % len(batches)], epoch=1)
         torch.cuda.synchronize()
         log = trainer.phase_log
     finally:
@@ -417,7 +417,9 @@ def main():
             "data": ("synthetic (N(0,1) images; random-init weights put into a trained-like state: BN running statistics and "
                      "the classifier's last layer calibrated on the synthetic batches to confident, class-balanced "
                      "predictions with logit std %g, student = teacher, labeled targets = teacher arg-max; lr 1e-6 so that "
-                     "state persists over the timed steps -- same launches as at lr 0.01)" % args.sharpen)
+                     "state persists over the timed steps -- same launches as at lr 0.01; steps run as epoch 1 of 200 = the "
+                     "ordinary semi-supervised step: in epoch 0 = sup_only_epoch the reference additionally aliases teacher <- "
+                     "student around every step, train_semi.py:309-315, two more 267 MB copies + operand re-splits)" % args.sharpen)
                     if not args.no_calibrate else
                     "synthetic (N(0,1) images, block labels; random-init weights, classifier last layer x%g)" % args.sharpen,
             "config": {"workload": f"U2PL semi {args.arch}-DeepLabv3+ Cityscapes-shaped {args.crop}x{args.crop}, per-GPU "

@@ -37,11 +37,11 @@ def main():
     calib = [bench.synth_batch(2, 769, C, dev, gc) for _ in range(2)]
     batches = bench.calibrate(model, teacher, calib, batches, 4.0)
     for i in range(2):
-        trainer.train_step(*batches[i % 2], epoch=0)
+        trainer.train_step(*batches[i % 2], epoch=1)
     torch.cuda.synchronize()
     trainer._side = torch.cuda.current_stream()
     _lib.PROFILE = []
-    trainer.train_step(*batches[0], epoch=0)
+    trainer.train_step(*batches[0], epoch=1)
     torch.cuda.synchronize()
     rec, _lib.PROFILE = _lib.PROFILE, None
     names = RL.MFMA_GROUPS["igemm"]

@@ -263,7 +263,7 @@ def measure(trainer, batch, args, ms_per_step):
     trainer._side = torch.cuda.current_stream()
     H.REPLAY = {}
     try:
-        agg = profile_step(lambda: trainer.train_step(il, ll, iu, epoch=0))
+        agg = profile_step(lambda: trainer.train_step(il, ll, iu, epoch=1))
         replay = replay_hbm_group()
     finally:
         trainer._side = saved

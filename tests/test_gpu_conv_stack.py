@@ -684,3 +684,38 @@ def test_fused_batchnorm_launches_give_the_separate_launches_bits():
     for n, a, b in zip(names, outs[0], outs[1]):
         assert torch.equal(a, b), n
     assert float(outs[0][4].abs().sum()) > 0
+
+
+def test_residual_gradient_folded_into_conv1_dgrad_equals_autograd_add():
+    """round 5: the block input's two gradient contributions (conv1's data gradient + the residual branch out of bn3's
+    backward) summed inside conv1's data-gradient launch (forward kernel's epilogue with identity BatchNorm parameters and the
+    residual gradient as `res`) instead of by autograd's elementwise add: same values (fl(a + b) either way) for the input
+    gradient and every parameter gradient of two stacked bottlenecks; the first one has a downsample branch (not linked)."""
+    from u2pl_amd import nn as Kn
+    from u2pl_amd.models.resnet import Bottleneck
+    saved = Kn.FUSE_RES_GRAD
+    outs = []
+    try:
+        for fused in (True, False):
+            Kn.FUSE_RES_GRAD = fused
+            torch.manual_seed(11)
+            ds = torch.nn.Sequential(Kn.Conv2d(256, 512, 1, bias=False), Kn.BatchNorm2d(512))
+            blocks = torch.nn.Sequential(Bottleneck(256, 128, downsample=ds), Bottleneck(512, 128), Bottleneck(512, 128, dilation=2)).to(DEV)
+            for m in blocks.modules():
+                if isinstance(m, Kn.BatchNorm2d):
+                    torch.nn.init.normal_(m.weight, 1.0, 0.2)
+            arena = Kn.ParamArena([list(blocks.parameters())])
+            g = torch.Generator(device=DEV).manual_seed(2)
+            x = torch.randn(2, 256, 33, 29, device=DEV, generator=g).contiguous(memory_format=CL).requires_grad_(True)
+            arena.zero_grad()
+            y = blocks(x)
+            gy = torch.randn(y.shape, device=DEV, generator=g).contiguous(memory_format=CL)
+            y.backward(gy)
+            Kn.wgrad_stream_sync()
+            torch.cuda.synchronize()
+            outs.append((y.detach().clone(), x.grad.clone(), arena.grad.clone()))
+    finally:
+        Kn.FUSE_RES_GRAD = saved
+    for n, a, b in zip(("y", "dx", "param grads"), outs[0], outs[1]):
+        assert torch.equal(a, b), (n, float((a - b).abs().max()))
+    assert float(outs[0][1].abs().sum()) > 0

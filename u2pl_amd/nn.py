@@ -423,7 +423,7 @@ def _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, mt, transposed,
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, dil, wsink, bsink, pivot=None, recording=True):
+    def forward(ctx, x, weight, bias, stride, pad, dil, wsink, bsink, pivot=None, recording=True, link=None):
         """pivot (a BatchNorm running_mean) requests the fused train-mode BN statistics of the output:
         returns (y, partials) with partials = float32 [nblk][2][C] (S1, S2 pivot-shifted, per row block of the epilogue);
         finished_sums() / the BatchNorm's fused finish turn them into the double [2C] sums."""
@@ -437,6 +437,7 @@ class _ConvFn(torch.autograd.Function):
         # the second output (the fused BatchNorm sums) is not differentiable: without this autograd materialises a zero fp64
         # gradient for it in front of every backward call (116 fill launches per step, profiles/r05_bench_serial_kernel_stats.csv)
         ctx.set_materialize_grads(False)
+        ctx.link = link
         y = new_act(N, Cout, Ho, Wo, x.device)
         col = None
         # `recording`: grad mode at the call site (inside forward() it is always off); the teacher's calls run under no_grad
@@ -492,7 +493,7 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, gsums=None):
         if gy is None:      # (only the non-differentiable sums were used downstream)
-            return (None,) * 10
+            return (None,) * 11
         x, weight, col = ctx.saved_tensors
         N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ldx = ctx.geom
         gy, ldg = as_rows(gy)
@@ -510,11 +511,27 @@ class _ConvFn(torch.autograd.Function):
         else:
             weight_k = weight
         dx = dw = db = None
+        # the gradient of the block's residual branch, left here by the BatchNorm that consumed the block input as `res`
+        # (residual_grad_link): this conv's data gradient is the OTHER contribution to the same tensor
+        res_g = ctx.link.pop("dres", None) if ctx.link is not None else None
+        if res_g is not None and not ctx.needs_input_grad[0]:
+            raise HipError("residual gradient link without a data gradient to add it to")
         if ctx.needs_input_grad[0]:
             dx = new_act(N, Cin, H, W, dev)
             mt = wino_tile(Cp, Cin, R, S, stride, pad, dil, H, W) if (Cp == Cout and not ctx.bf) else 0
             if mt:   # data gradient = the same convolution with rotated taps and swapped channel roles
                 _wino_conv(gy, ldg, weight_k, None, dx, N, H, W, Cin, Cout, dil, mt, True)[0]
+            elif (res_g is not None and R == 1 and S == 1 and stride == 1 and pad == 0 and Cp == Cout and not ctx.bf
+                  and _ws_ok(Cin, Cout) and Cin % 4 == 0):
+                # pointwise: the data gradient IS a pointwise forward convolution with the transposed weight planes -- run it
+                # through the forward kernel's eval-BatchNorm epilogue with identity parameters and the residual gradient as
+                # its `res`: dx = (gy . W) + dres in ONE pass instead of the GEMM + autograd's elementwise add over the
+                # 4x-wide block input (46 adds, 3.2 ms per step)
+                one, zero = _identity_bn(Cin, dev)
+                rr, ldr = as_rows(res_g)
+                call("u2pl_conv2d_fwd_bnact_ws_f32", gy, ldg, ws_dgrad(weight), None, dx, Cin, N, H, W, Cout, H, W, Cin, 1, 1, 1, 0, 1,
+                     zero, one, one, zero, rr, ldr, 0)
+                res_g = None
             elif Cp == Cout and not ctx.bf and _ws_ok(Cin, R * S * Cout):
                 call("u2pl_conv2d_dgrad_ws_f32", gy, ldg, ws_dgrad(weight), dx, Cin, N, H, W, Cin, Ho, Wo, Cout, R, S, stride,
                      pad, dil)
@@ -523,6 +540,8 @@ class _ConvFn(torch.autograd.Function):
                 call("u2pl_weight_transpose_f32", weight_k, wT, Cp, R * S, Cin)
                 call("u2pl_conv2d_dgrad_bf16op_f32" if ctx.bf else "u2pl_conv2d_dgrad_f32", gy, ldg, wT, dx, Cin, N, H, W, Cin,
                      Ho, Wo, Cp, R, S, stride, pad, dil)
+            if res_g is not None:      # (no fused form for this layer: the add autograd would have made)
+                dx.add_(res_g)
         side = _wgrad_stream() if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) else None
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
@@ -592,7 +611,32 @@ class _ConvFn(torch.autograd.Function):
                 if t_ is not None:   # returned to autograd on the main stream
                     torch.cuda.current_stream().wait_stream(side)
                     break
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
+
+
+_IDENT_BN = {}
+
+
+def _identity_bn(C, dev):
+    k = (C, str(dev))
+    v = _IDENT_BN.get(k)
+    if v is None:
+        v = _IDENT_BN[k] = (torch.ones(C, dtype=torch.float32, device=dev), torch.zeros(C, dtype=torch.float32, device=dev))
+    return v
+
+
+# A residual block's input feeds TWO consumers -- the block's first conv and the residual add inside the last BatchNorm -- so its
+# gradient is the sum of two tensors, which autograd forms with an elementwise add (12 B per element of the 4x-wide tensor).
+# residual_grad_link() -> a dict the block passes to both: the BatchNorm's backward leaves its residual gradient in it and reports
+# None to autograd, the conv's backward (which runs later: it is upstream) folds it into its data-gradient launch.
+# U2PL_NO_RES_GRAD_FUSION=1: off.
+FUSE_RES_GRAD = os.environ.get("U2PL_NO_RES_GRAD_FUSION") is None
+
+
+def residual_grad_link(x):
+    if FUSE_RES_GRAD and torch.is_grad_enabled() and x.requires_grad:
+        return {}
+    return None
 
 
 class Conv2d(nn.Module):
@@ -615,11 +659,12 @@ class Conv2d(nn.Module):
         else:
             self.register_parameter("bias", None)
 
-    def forward(self, x, stat_pivot=None):
-        """stat_pivot: running_mean of a following train-mode BatchNorm -> returns (y, fused BN sums)."""
+    def forward(self, x, stat_pivot=None, grad_link=None):
+        """stat_pivot: running_mean of a following train-mode BatchNorm -> returns (y, fused BN sums).
+        grad_link: see residual_grad_link()."""
         out = _ConvFn.apply(x, self.weight, self.bias, self.stride, self.padding, self.dilation,
                             _grad_sink(self.weight), _grad_sink(self.bias) if self.bias is not None else None, stat_pivot,
-                            torch.is_grad_enabled())
+                            torch.is_grad_enabled(), grad_link)
         return out
 
     def extra_repr(self):
@@ -643,11 +688,12 @@ def finished_sums(pre, C, out=None):
 
 class _BNFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, res, drop, mod, relu, gsink, bsink, pre_sums=None):
+    def forward(ctx, x, gamma, beta, res, drop, mod, relu, gsink, bsink, pre_sums=None, link=None):
         x, ldx = as_rows(x)
         N, C, H, W = x.shape
         M = N * H * W
         dev = x.device
+        ctx.link = link if res is not None else None
         rr = ldr = None
         if res is not None:
             rr, ldr = as_rows(res)
@@ -725,7 +771,10 @@ class _BNFn(torch.autograd.Function):
         elif dx is not None:
             call("u2pl_bn_bwd_apply_f32", gy, ldg, x, ldx, y, C, mean, invstd, gamma, drop, H * W,
                  sums if training else None, count, dx, C, dres, C, M, C)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+        if ctx.link is not None and dres is not None:
+            ctx.link["dres"] = dres        # picked up by the block's first conv (residual_grad_link); autograd sees no gradient here
+            dres = None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
 # ---- packed SyncBatchNorm exchanges ------------------------------------------------------------------------------------
@@ -956,9 +1005,9 @@ class BatchNorm2d(nn.Module):
         self.register_state_dict_pre_hook(_bn_write_nbt)       # (module-level functions: lambdas would make the module unpicklable)
         self.register_load_state_dict_post_hook(_bn_read_nbt)
 
-    def forward(self, x, res=None, relu=False, drop=None, pre_sums=None):
+    def forward(self, x, res=None, relu=False, drop=None, pre_sums=None, res_link=None):
         return _BNFn.apply(x, self.weight, self.bias, res, drop, self, relu, _grad_sink(self.weight),
-                           _grad_sink(self.bias), pre_sums)
+                           _grad_sink(self.bias), pre_sums, res_link)
 
 
 FUSE_EVAL_BN = os.environ.get("U2PL_NO_EVAL_BN_FUSION") is None
@@ -1063,7 +1112,7 @@ def conv_bn_eval(conv, bn, x, res=None, relu=False):
     return y
 
 
-def conv_bn(conv, bn, x, res=None, relu=False, drop=None):
+def conv_bn(conv, bn, x, res=None, relu=False, drop=None, grad_link=None, res_link=None):
     """conv -> BatchNorm (+residual, ReLU, Dropout2d scale).  In training mode the BN statistics are
     produced by the conv kernel's epilogue (no separate read pass over the conv output); in eval mode without a
     recorded graph the whole BatchNorm runs in the conv's epilogue (conv_bn_eval)."""
@@ -1073,9 +1122,9 @@ def conv_bn(conv, bn, x, res=None, relu=False, drop=None):
         if y is not None:
             return y
     if bn.training and conv.in_channels % 32 == 0:
-        y, sums = conv(x, stat_pivot=bn.running_mean)
-        return bn(y, res=res, relu=relu, drop=drop, pre_sums=sums)
-    return bn(conv(x), res=res, relu=relu, drop=drop)
+        y, sums = conv(x, stat_pivot=bn.running_mean, grad_link=grad_link)
+        return bn(y, res=res, relu=relu, drop=drop, pre_sums=sums, res_link=res_link)
+    return bn(conv(x, grad_link=grad_link), res=res, relu=relu, drop=drop, res_link=res_link)
 
 
 def use_process_group(model, group):

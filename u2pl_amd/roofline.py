@@ -81,10 +81,15 @@ def profile_step(step_fn):
         _lib.PROFILE = None
     agg, shapes = {}, {}
     agg["_dense"] = replay_dense(rec)
-    for name, args, e0, e1, nk in [r[:4] + (r[7],) for r in rec]:
+    for name, args, e0, e1, nk, full in [r[:4] + (r[7], r[6]) for r in rec]:
         d = agg.setdefault(name, dict(ms=0.0, calls=0, flops=0.0, kernels=0, bytes=0.0))
         if name in MFMA_GROUPS["igemm"]:
             d["bytes"] += _conv_bytes(name, args)
+            if "_bnact" in name and len(full) > 22 and full[22] is not None:
+                # the epilogue's residual operand is read once too (eval-mode identity; round 5: the residual GRADIENT that the
+                # pointwise data-gradient launch adds)
+                i = _CONV_GEOM[name]
+                d["bytes"] += 4.0 * args[i] * args[i + 4] * args[i + 5] * args[i + 6]
         ms = e0.elapsed_time(e1)
         d["ms"] += ms
         d["calls"] += 1

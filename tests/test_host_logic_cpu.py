@@ -301,3 +301,44 @@ def test_modules_pickle_with_a_populated_operand_cache_and_arena():
     assert torch.equal(net2[0].weight, w) and len(net2[0].weight.__dict__.get("_u2pl_derived", {})) == 0
     a2 = pickle.loads(pickle.dumps(arena))
     assert a2._works == [None] and a2._streams == () and torch.equal(a2.flat, arena.flat)
+
+
+def test_dropout_pool_hands_out_the_pass_uniforms_in_call_order():
+    """nn.dropout_pool (round 5: the Dropout2d uniforms of a pass are drawn by ONE generator call before the pass, so that no
+    generator-driven kernel sits inside a HIP graph): layers take consecutive (N, C) blocks of the buffer, the mask arithmetic is
+    `u >= p` scaled by 1 / (1 - p), an exhausted pool falls back to an inline draw, eval mode draws nothing."""
+    import torch
+    from u2pl_amd import nn as K
+
+    d1, d2 = torch.nn.Dropout2d(0.1), torch.nn.Dropout2d(0.25)
+    seq = torch.nn.Sequential(K.BatchNorm2d(8), torch.nn.ReLU(), d1, K.BatchNorm2d(4), torch.nn.ReLU(), d2)
+    assert K.dropout_uniforms_needed(seq, 3) == 3 * 8 + 3 * 4
+    u = torch.rand(3 * 8 + 3 * 4)
+    with K.dropout_pool(u):
+        s1 = K.dropout2d_scale(d1, 3, 8, "cpu")
+        s2 = K.dropout2d_scale(d2, 3, 4, "cpu")
+        s3 = K.dropout2d_scale(d2, 3, 4, "cpu")        # pool exhausted: inline draw, still a valid keep-scale
+    assert K.DROPOUT_POOL is None
+    assert torch.equal(s1, (u[:24].view(3, 8) >= 0.1).float() / 0.9)
+    assert torch.equal(s2, (u[24:].view(3, 4) >= 0.25).float() / 0.75)
+    assert all(v == 0.0 or abs(v - 1.0 / 0.75) < 1e-6 for v in s3.unique().tolist())
+    d1.eval()
+    assert K.dropout2d_scale(d1, 3, 8, "cpu") is None
+    seq.eval()
+    with K.dropout_pool(None):
+        assert K.DROPOUT_POOL is None
+
+
+def test_residual_link_and_finished_sums_host_logic():
+    import torch
+    from u2pl_amd import nn as K
+
+    x = torch.zeros(2, 4, 3, 3, requires_grad=True)
+    assert K.residual_grad_link(x) == {}
+    with torch.no_grad():
+        assert K.residual_grad_link(x) is None
+    assert K.residual_grad_link(x.detach()) is None
+    sums = torch.arange(9, dtype=torch.float64)
+    assert K.finished_sums(sums, 4) is sums                      # already-finished double sums pass through
+    out = torch.zeros(9, dtype=torch.float64)
+    assert K.finished_sums(sums, 4, out) is out and torch.equal(out, sums)

@@ -719,3 +719,42 @@ def test_residual_gradient_folded_into_conv1_dgrad_equals_autograd_add():
     for n, a, b in zip(("y", "dx", "param grads"), outs[0], outs[1]):
         assert torch.equal(a, b), (n, float((a - b).abs().max()))
     assert float(outs[0][1].abs().sum()) > 0
+
+
+def test_gradient_joins_of_downsample_blocks_and_aspp_equal_autograd_sums():
+    """nn.GradJoin beyond the plain residual: (1) a bottleneck WITH a (stride-1) downsample branch -- conv1 and the downsample conv
+    both consume the block input: fl(a + b) either way, bit-equal; (2) the ASPP -- four convolutions consume the 2048-channel
+    encoder output (pointwise, two Winograd, one direct 3x3): the chain adds the four contributions in another ORDER than
+    autograd did, so equality holds to fp32 rounding of a four-term sum; the fifth consumer (global average pool) stays with
+    autograd.  Input and parameter gradients against the un-joined path."""
+    from u2pl_amd import nn as Kn
+    from u2pl_amd.models.base import ASPP
+    from u2pl_amd.models.resnet import Bottleneck
+    saved = Kn.FUSE_RES_GRAD
+    outs = []
+    try:
+        for fused in (True, False):
+            Kn.FUSE_RES_GRAD = fused
+            torch.manual_seed(13)
+            ds = torch.nn.Sequential(Kn.Conv2d(256, 512, 1, bias=False), Kn.BatchNorm2d(512))
+            block = Bottleneck(256, 128, downsample=ds, dilation=2).to(DEV)
+            aspp = ASPP(512, inner_planes=256, dilations=(2, 12, 3)).to(DEV)       # at 25 x 25: d = 12 stays direct, d = 2 / 3 Winograd
+            arena = Kn.ParamArena([list(block.parameters()) + list(aspp.parameters())])
+            g = torch.Generator(device=DEV).manual_seed(4)
+            x = torch.randn(2, 256, 25, 25, device=DEV, generator=g).contiguous(memory_format=CL).requires_grad_(True)
+            arena.zero_grad()
+            mid = block(x)
+            y = aspp(mid)
+            kinds = [bool(Kn.dgrad_fusable(b[0], mid)) for b in (aspp.conv2, aspp.conv3, aspp.conv4, aspp.conv5)]
+            gy = torch.randn(y.shape, device=DEV, generator=g).contiguous(memory_format=CL)
+            y.backward(gy)
+            Kn.wgrad_stream_sync()
+            torch.cuda.synchronize()
+            outs.append((y.detach().clone(), x.grad.clone(), arena.grad.clone()))
+    finally:
+        Kn.FUSE_RES_GRAD = saved
+    assert kinds == [True, True, False, True], kinds          # the case exercises both the fused forms and the in-place fallback
+    assert torch.equal(outs[0][0], outs[1][0])
+    for n, a, b in zip(("dx", "param grads"), outs[0][1:], outs[1][1:]):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-6 * scale, (n, float((a - b).abs().max()), scale)

@@ -334,10 +334,20 @@ def test_residual_link_and_finished_sums_host_logic():
     from u2pl_amd import nn as K
 
     x = torch.zeros(2, 4, 3, 3, requires_grad=True)
-    assert K.residual_grad_link(x) == {}
+    j = K.residual_grad_link(x)
+    assert isinstance(j, K.GradJoin) and j.left == 2 and j.acc is None
     with torch.no_grad():
         assert K.residual_grad_link(x) is None
-    assert K.residual_grad_link(x.detach()) is None
+    assert K.residual_grad_link(x.detach()) is None and K.grad_join(x, 1) is None
+    # order-agnostic accumulation: n - 1 consumers park the running sum and report None, the last one returns the total;
+    # a consumer that already folded the running sum into its own launch says so (`included`)
+    j = K.grad_join(x, 3)
+    a, b, c = torch.full((2,), 1.0), torch.full((2,), 2.0), torch.full((2,), 10.0)
+    assert j.settle(a) is None and j.acc is a
+    assert j.settle(b) is None and torch.equal(j.acc, torch.full((2,), 3.0))          # b += a, in place
+    assert j.acc is b
+    total = j.settle(c, included=True)                                                 # c already contains the running sum
+    assert total is c and j.acc is None and j.left == 0
     sums = torch.arange(9, dtype=torch.float64)
     assert K.finished_sums(sums, 4) is sums                      # already-finished double sums pass through
     out = torch.zeros(9, dtype=torch.float64)

@@ -52,7 +52,17 @@ class ASPP(nn.Module):
         pooled = K.global_avg_pool(x)
         # five independent conv -> BN -> ReLU branches: under a process group their SyncBatchNorm statistics are exchanged
         # in ONE packed all-reduce (forward and backward); otherwise exactly run_seq's fused conv_bn per branch
+        # x has five consumers; the four convolutions share a gradient join (nn.GradJoin: their data-gradient launches add up the
+        # contributions instead of autograd's elementwise adds over the 2048-channel tensor).  The branches whose data gradient
+        # has no fused accumulate form (the direct 3x3, d = 24 at 97^2) are issued LAST, so that their backward runs first and
+        # finds nothing to add yet.
+        branches = [self.conv2, self.conv3, self.conv4, self.conv5]
+        order = sorted(range(4), key=lambda i: 0 if K.dgrad_fusable(branches[i][0], x) else 1)
+        join = K.grad_join(x, 4)
         units = [(self.conv1[1], self.conv1[2], pooled, True, None)]
-        units += [(seq[0], seq[1], x, True, None) for seq in (self.conv2, self.conv3, self.conv4, self.conv5)]
+        units += [(branches[i][0], branches[i][1], x, True, None, join) for i in order]
         f = K.conv_bn_group(units)
-        return K.cat_channels((K.upsample_bilinear(f[0], (h, w)), f[1], f[2], f[3], f[4]))
+        outs = [None] * 4
+        for k, i in enumerate(order):
+            outs[i] = f[1 + k]
+        return K.cat_channels((K.upsample_bilinear(f[0], (h, w)), outs[0], outs[1], outs[2], outs[3]))

@@ -57,6 +57,8 @@ class dec_deeplabv3_plus(nn.Module):
         h, w = low_feat.size()[-2:]
         aspp_out = K.upsample_bilinear(aspp_out, (h, w))
         aspp_out = K.cat_channels((low_feat, aspp_out))
+        # (no nn.GradJoin over the two towers: a caller may back-propagate through "pred" only -- the reference's supervised loop
+        # does -- and a join needs every wired consumer's backward to run)
         res = {"pred": K.run_seq(self.classifier, aspp_out)}
         if self.rep_head and need_rep:
             res["rep"] = K.run_seq(self.representation, aspp_out)

@@ -69,13 +69,16 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         # (the block input has two consumers, conv1 and the residual add in bn3: conv1's data-gradient launch adds the residual
         # branch's gradient instead of autograd's elementwise add -- nn.residual_grad_link)
-        link = K.residual_grad_link(x) if self.downsample is None else None
+        if self.downsample is None:
+            link = K.residual_grad_link(x)
+        else:   # conv1 and the downsample conv both consume x; joined when the downsample's data gradient has a fused form
+            link = K.grad_join(x, 2) if K.dgrad_fusable(self.downsample[0], x) and K.dgrad_fusable(self.conv1, x) else None
         out = K.conv_bn(self.conv1, self.bn1, x, relu=True, grad_link=link)
         out = K.conv_bn(self.conv2, self.bn2, out, relu=True)
         if self.downsample is None:
             return K.conv_bn(self.conv3, self.bn3, out, res=x, relu=True, res_link=link)
         # bn3 and the downsample BatchNorm are independent: under a process group their statistics share one all-reduce
-        return K.conv_bn_res_pair(self.conv3, self.bn3, out, self.downsample[0], self.downsample[1], x)
+        return K.conv_bn_res_pair(self.conv3, self.bn3, out, self.downsample[0], self.downsample[1], x, grad_link_b=link)
 
 
 class ResNet(nn.Module):

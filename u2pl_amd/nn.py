@@ -511,27 +511,33 @@ class _ConvFn(torch.autograd.Function):
         else:
             weight_k = weight
         dx = dw = db = None
-        # the gradient of the block's residual branch, left here by the BatchNorm that consumed the block input as `res`
-        # (residual_grad_link): this conv's data gradient is the OTHER contribution to the same tensor
-        res_g = ctx.link.pop("dres", None) if ctx.link is not None else None
-        if res_g is not None and not ctx.needs_input_grad[0]:
-            raise HipError("residual gradient link without a data gradient to add it to")
+        # what the OTHER consumers of this conv's input have contributed to its gradient so far (GradJoin): folded into this
+        # launch where a fused form exists, added in place otherwise; handed on or returned by join.settle below
+        join = ctx.link
+        prev = join.acc if join is not None else None
+        if join is not None and not ctx.needs_input_grad[0]:
+            raise HipError("gradient join on a convolution whose input needs no gradient")
         if ctx.needs_input_grad[0]:
             dx = new_act(N, Cin, H, W, dev)
+            included = prev is None
+            epi = None
+            if prev is not None and Cin % 4 == 0:
+                one, zero = _identity_bn(Cin, dev)
+                rr, ldr = as_rows(prev)
+                epi = (zero, one, one, zero, rr, ldr, 0)     # identity BatchNorm + `res` = the running sum: (v - 0) * 1 * 1 + 0 + res
             mt = wino_tile(Cp, Cin, R, S, stride, pad, dil, H, W) if (Cp == Cout and not ctx.bf) else 0
             if mt:   # data gradient = the same convolution with rotated taps and swapped channel roles
-                _wino_conv(gy, ldg, weight_k, None, dx, N, H, W, Cin, Cout, dil, mt, True)[0]
-            elif (res_g is not None and R == 1 and S == 1 and stride == 1 and pad == 0 and Cp == Cout and not ctx.bf
-                  and _ws_ok(Cin, Cout) and Cin % 4 == 0):
+                _wino_conv(gy, ldg, weight_k, None, dx, N, H, W, Cin, Cout, dil, mt, True, None, epi)
+                included = included or epi is not None     # (the output transform's residual epilogue)
+            elif (epi is not None and R == 1 and S == 1 and stride == 1 and pad == 0 and Cp == Cout and not ctx.bf
+                  and _ws_ok(Cin, Cout)):
                 # pointwise: the data gradient IS a pointwise forward convolution with the transposed weight planes -- run it
-                # through the forward kernel's eval-BatchNorm epilogue with identity parameters and the residual gradient as
-                # its `res`: dx = (gy . W) + dres in ONE pass instead of the GEMM + autograd's elementwise add over the
-                # 4x-wide block input (46 adds, 3.2 ms per step)
-                one, zero = _identity_bn(Cin, dev)
-                rr, ldr = as_rows(res_g)
+                # through the forward kernel's eval-BatchNorm epilogue with identity parameters and the running sum as its
+                # `res`: dx = (gy . W) + prev in ONE pass instead of the GEMM + autograd's elementwise add over the 4x-wide
+                # block input (46 adds, 3.2 ms per step before round 5)
                 call("u2pl_conv2d_fwd_bnact_ws_f32", gy, ldg, ws_dgrad(weight), None, dx, Cin, N, H, W, Cout, H, W, Cin, 1, 1, 1, 0, 1,
-                     zero, one, one, zero, rr, ldr, 0)
-                res_g = None
+                     *epi)
+                included = True
             elif Cp == Cout and not ctx.bf and _ws_ok(Cin, R * S * Cout):
                 call("u2pl_conv2d_dgrad_ws_f32", gy, ldg, ws_dgrad(weight), dx, Cin, N, H, W, Cin, Ho, Wo, Cout, R, S, stride,
                      pad, dil)
@@ -540,8 +546,8 @@ class _ConvFn(torch.autograd.Function):
                 call("u2pl_weight_transpose_f32", weight_k, wT, Cp, R * S, Cin)
                 call("u2pl_conv2d_dgrad_bf16op_f32" if ctx.bf else "u2pl_conv2d_dgrad_f32", gy, ldg, wT, dx, Cin, N, H, W, Cin,
                      Ho, Wo, Cp, R, S, stride, pad, dil)
-            if res_g is not None:      # (no fused form for this layer: the add autograd would have made)
-                dx.add_(res_g)
+            if join is not None:
+                dx = join.settle(dx, included)      # None unless this was the last consumer to report
         side = _wgrad_stream() if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) else None
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
@@ -625,18 +631,54 @@ def _identity_bn(C, dev):
     return v
 
 
-# A residual block's input feeds TWO consumers -- the block's first conv and the residual add inside the last BatchNorm -- so its
-# gradient is the sum of two tensors, which autograd forms with an elementwise add (12 B per element of the 4x-wide tensor).
-# residual_grad_link() -> a dict the block passes to both: the BatchNorm's backward leaves its residual gradient in it and reports
-# None to autograd, the conv's backward (which runs later: it is upstream) folds it into its data-gradient launch.
+# A tensor with several consumers gets its gradient as the SUM of their contributions, which autograd forms with elementwise adds
+# (12 B per element; a bottleneck's input -- conv1 + the residual add inside bn3 -- is the 4x-wide tensor of the block).  GradJoin
+# moves the sum into the consumers' own backward launches: the module that owns the fan-out creates one join for its n wired
+# consumers and hands it to each; a consumer's backward folds the running sum (`acc`) into its own launch where a fused form exists
+# (pointwise / Winograd data gradients: the forward kernels' residual epilogue with identity BatchNorm parameters), adds it in place
+# otherwise, and either parks the new sum in the join and reports None to autograd, or -- the last one -- returns the total.
+# Order-agnostic; every wired consumer's backward MUST run in the pass (they are wired only where all outputs reach the loss).
 # U2PL_NO_RES_GRAD_FUSION=1: off.
 FUSE_RES_GRAD = os.environ.get("U2PL_NO_RES_GRAD_FUSION") is None
 
 
-def residual_grad_link(x):
-    if FUSE_RES_GRAD and torch.is_grad_enabled() and x.requires_grad:
-        return {}
+class GradJoin:
+    __slots__ = ("left", "acc")
+
+    def __init__(self, n):
+        self.left, self.acc = n, None
+
+    def settle(self, t, included=False):
+        """t: this consumer's contribution (already containing `acc` when included) -> the tensor to return to autograd"""
+        if self.acc is not None and not included:
+            t.add_(self.acc)
+        self.left -= 1
+        if self.left > 0:
+            self.acc = t
+            return None
+        self.acc = None
+        return t
+
+
+def grad_join(x, n):
+    """a join for n consumers of x, or None (no graph being recorded / x needs no gradient / fewer than two consumers)"""
+    if n >= 2 and FUSE_RES_GRAD and torch.is_grad_enabled() and x.requires_grad:
+        return GradJoin(n)
     return None
+
+
+def residual_grad_link(x):
+    """bottleneck without a downsample branch: the block input feeds conv1 and the residual add of bn3"""
+    return grad_join(x, 2)
+
+
+def dgrad_fusable(conv, x):
+    """does this conv's data gradient have a fused accumulate form (pointwise stride-1 on the pre-split kernels, or Winograd)?"""
+    Cout, Cin, R, S = conv.weight.shape
+    H, W = x.shape[2], x.shape[3]
+    if R == 1 and S == 1 and conv.stride == 1 and conv.padding == 0:
+        return _ws_ok(Cin, Cout) and Cin % 4 == 0 and Cout % 32 == 0
+    return bool(wino_tile(Cout, Cin, R, S, conv.stride, conv.padding, conv.dilation, H, W)) and Cout % 32 == 0 and Cin % 4 == 0
 
 
 class Conv2d(nn.Module):
@@ -661,7 +703,7 @@ class Conv2d(nn.Module):
 
     def forward(self, x, stat_pivot=None, grad_link=None):
         """stat_pivot: running_mean of a following train-mode BatchNorm -> returns (y, fused BN sums).
-        grad_link: see residual_grad_link()."""
+        grad_link: a GradJoin shared with the other consumers of x (grad_join)."""
         out = _ConvFn.apply(x, self.weight, self.bias, self.stride, self.padding, self.dilation,
                             _grad_sink(self.weight), _grad_sink(self.bias) if self.bias is not None else None, stat_pivot,
                             torch.is_grad_enabled(), grad_link)
@@ -772,8 +814,7 @@ class _BNFn(torch.autograd.Function):
             call("u2pl_bn_bwd_apply_f32", gy, ldg, x, ldx, y, C, mean, invstd, gamma, drop, H * W,
                  sums if training else None, count, dx, C, dres, C, M, C)
         if ctx.link is not None and dres is not None:
-            ctx.link["dres"] = dres        # picked up by the block's first conv (residual_grad_link); autograd sees no gradient here
-            dres = None
+            dres = ctx.link.settle(dres)    # GradJoin: parked for the block's other consumer (conv1), or the total if it ran first
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
@@ -945,34 +986,36 @@ def _packable(bns):
             and all(b.training and b.sync for b in bns) and len({id(b.group) for b in bns}) == 1)
 
 
-def _conv_with_stats(conv, bn, x):
+def _conv_with_stats(conv, bn, x, grad_link=None):
     """conv output + its fused train-mode BN sums (None where the epilogue form does not exist: stem, pooled 1x1)"""
     if conv.in_channels % 32 == 0:
-        y, sums = conv(x, stat_pivot=bn.running_mean)
+        y, sums = conv(x, stat_pivot=bn.running_mean, grad_link=grad_link)
         return y, sums
-    return conv(x), None
+    return conv(x, grad_link=grad_link), None
 
 
 def conv_bn_group(units):
     """units: [(conv, bn, x, relu, drop)], mutually independent -> list of outputs.  Under a process group in train mode
     the SyncBatchNorm statistics of all units are exchanged in ONE all-reduce (forward and backward)."""
+    units = [tuple(u) + (None,) * (6 - len(u)) for u in units]        # optional 6th entry: a GradJoin for the conv's input
     if not _packable([u[1] for u in units]) or len(units) < 2:
-        return [conv_bn(c, b, x, relu=r, drop=d) for c, b, x, r, d in units]
+        return [conv_bn(c, b, x, relu=r, drop=d, grad_link=j) for c, b, x, r, d, j in units]
     flat, meta = [], []
-    for conv, bn, x, relu, drop in units:
-        y, sums = _conv_with_stats(conv, bn, x)
+    for conv, bn, x, relu, drop, j in units:
+        y, sums = _conv_with_stats(conv, bn, x, j)
         flat += [y, bn.weight, bn.bias, drop, sums]
         meta.append((bn, relu, _grad_sink(bn.weight), _grad_sink(bn.bias)))
     return list(_BNGroupFn.apply(len(units), *flat, meta))
 
 
-def conv_bn_res_pair(conv_a, bn_a, xa, conv_b, bn_b, xb):
-    """relu(bn_a(conv_a(xa)) + bn_b(conv_b(xb))): the tail of a bottleneck with a downsample branch"""
+def conv_bn_res_pair(conv_a, bn_a, xa, conv_b, bn_b, xb, grad_link_b=None):
+    """relu(bn_a(conv_a(xa)) + bn_b(conv_b(xb))): the tail of a bottleneck with a downsample branch; grad_link_b: a GradJoin
+    for xb (the block input, also consumed by the block's conv1)"""
     if not _packable([bn_a, bn_b]):
-        identity = conv_bn(conv_b, bn_b, xb)
+        identity = conv_bn(conv_b, bn_b, xb, grad_link=grad_link_b)
         return conv_bn(conv_a, bn_a, xa, res=identity, relu=True)
     ya, sa = _conv_with_stats(conv_a, bn_a, xa)
-    yb, sb = _conv_with_stats(conv_b, bn_b, xb)
+    yb, sb = _conv_with_stats(conv_b, bn_b, xb, grad_link_b)
     meta = ((bn_a, _grad_sink(bn_a.weight), _grad_sink(bn_a.bias)), (bn_b, _grad_sink(bn_b.weight), _grad_sink(bn_b.bias)))
     return _BNResPairFn.apply(ya, bn_a.weight, bn_a.bias, sa, yb, bn_b.weight, bn_b.bias, sb, meta)
 
@@ -1211,12 +1254,16 @@ def dropout_uniforms_needed(model, N):
     return total
 
 
-def run_seq(seq, x):
+def run_seq(seq, x, grad_link=None):
     """Execute an nn.Sequential of {Conv2d, BatchNorm2d, ReLU, Dropout2d} fusing
-    BN + ReLU + Dropout2d into one kernel (indices/names unchanged)."""
+    BN + ReLU + Dropout2d into one kernel (indices/names unchanged).  grad_link: a GradJoin for x, given to the Sequential's
+    FIRST convolution (the consumer of x)."""
     mods = list(seq)
     i = 0
     pending_conv = None
+    first_conv = next((m for m in mods if isinstance(m, Conv2d)), None) if grad_link is not None else None
+    if grad_link is not None and (first_conv is None or first_conv is not mods[0]):
+        raise HipError("run_seq: a gradient join needs the Sequential to start with its convolution")
     while i < len(mods):
         m = mods[i]
         if isinstance(m, Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], BatchNorm2d):
@@ -1231,7 +1278,7 @@ def run_seq(seq, x):
                 drop = dropout2d_scale(mods[j], x.shape[0], m.num_features, x.device)
                 j += 1
             if pending_conv is not None:
-                x = conv_bn(pending_conv, m, x, relu=relu, drop=drop)
+                x = conv_bn(pending_conv, m, x, relu=relu, drop=drop, grad_link=grad_link if pending_conv is first_conv else None)
                 pending_conv = None
             else:
                 x = m(x, relu=relu, drop=drop)

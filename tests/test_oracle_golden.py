@@ -442,3 +442,20 @@ def test_cutout_and_classmix():
     nd, nt, nl = R.classmix_apply(g["data"], tgt, g["logits"], sel)
     assert np.array_equal(nd, g["classmix_data"]) and np.array_equal(nt, g["classmix_target"])
     assert np.array_equal(nl, g["classmix_logits"])
+
+
+def test_miou_gate_inputs_regenerate_to_the_fixtures_digest():
+    """tests/miou_gate.py rebuilds the epoch's 40 x (2 + 2) training crops and the 50 validation images from a seed with numpy's
+    PCG64 stream; the fixture written next to the reference stores a digest of them -- the same bytes here (and on the GPU box,
+    where test_gpu_miou_gate.py checks it again before training)"""
+    import miou_gate as MG
+    g = golden("miou_gate")
+    seeds = [int(x) for x in g["seeds"]]
+    data = MG.gate_data(seeds[1], int(g["steps"]), MG.GATE["B"], MG.GATE["S"])
+    val = MG.gate_val(seeds[1] + 1, MG.GATE["n_val"], MG.GATE["S"])
+    assert np.array_equal(MG.data_digest(data, val), g["digest"])
+    labs = np.unique(np.concatenate([d[1].numpy().ravel() for d in data[:4]]))
+    assert set(labs.tolist()) == set(MG.USED) | {255}
+    # what the gate rests on: the reference's epoch moved the mIoU by far more than its own fp32 noise floor
+    assert 100 * (float(g["miou_teacher"]) - float(g["miou_init"])) > 20
+    assert 100 * abs(float(g["noise_miou_teacher"]) - float(g["miou_teacher"])) < 0.1

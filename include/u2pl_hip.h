@@ -306,6 +306,45 @@ int u2pl_conv2d_dgrad_ws_f32(const float* dy, long lddy, const void* wTsplit, fl
 int u2pl_gemm_batched_ws_f32(const float* x, long ldx, long zx, const void* wsplit, float* y, long ldy, long zy, long M,
                              int K, int Nn, int batch, hipStream_t stream);
 
+/* ---- split-fp16 (round 6; csrc/conv_geom.h): the same GEMMs with THREE fp16 piece products per fp32 product instead of six
+ * bf16 ones.  Each operand is scaled per tensor by a power of two chosen from its largest magnitude (exact), split into two fp16
+ * pieces (x s = h0 + h1 to 2^-25 |x s|) and multiplied as a1 b0 + a0 b1 + a0 b0 with fp32 accumulation; the accumulators are
+ * scaled back with ldexp.  Replaces the same reference lines as the *_ws_* family above (u2pl/models/resnet.py:120-140,
+ * base.py:54-100, decoder.py:60-142 forward; loss.backward() train_semi.py:527).
+ *   u2pl_absmax_f32: *out <- max |x| over [M][C] (C % 4 == 0, ld % 4 == 0; NaN if any element is NaN): the x_amax of the calls
+ *     below.  Any upper bound within ~2^8 of the true maximum keeps fp32-class accuracy; a value BELOW the maximum overflows.
+ *   u2pl_weight_split2h_*: planes [K/32][2][Np][32] fp16 + one uint32 per matrix (bit pattern of its max |w|) behind them.
+ *     job_scratch: 48 device bytes (the job record of the one-weight call).  The multi call takes the SplitJob table of
+ *     u2pl_weight_split3_multi_f32 with out = u2pl_weight_split2h_bytes buffers. */
+size_t u2pl_weight_split2h_bytes(int rows, int K, int batch);
+int u2pl_weight_split2h_f32(const float* w, long zw, int rows, int K, int batch, void* out, void* job_scratch, hipStream_t stream);
+int u2pl_weight_split2h_multi_f32(const void* jobs, int njobs, long total, hipStream_t stream);
+int u2pl_absmax_f32(const float* x, long ld, long M, int C, float* out, hipStream_t stream);
+int u2pl_conv2d_fwd_wsh_f32(const float* x, long ldx, const float* x_amax, const void* wsplit, const float* bias, float* y, long ldy,
+                            int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S, int stride, int pad,
+                            int dil, hipStream_t stream);
+int u2pl_conv2d_fwd_bnstats_wsh_f32(const float* x, long ldx, const float* x_amax, const void* wsplit, const float* bias, float* y,
+                                    long ldy, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S,
+                                    int stride, int pad, int dil, const float* pivot, float* stats_partial, hipStream_t stream);
+int u2pl_conv2d_fwd_bnact_wsh_f32(const float* x, long ldx, const float* x_amax, const void* wsplit, const float* bias, float* y,
+                                  long ldy, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S,
+                                  int stride, int pad, int dil, const float* mean, const float* invstd, const float* gamma,
+                                  const float* beta, const float* res, long ldr, int relu, hipStream_t stream);
+int u2pl_conv2d_dgrad_wsh_f32(const float* dy, long lddy, const float* dy_amax, const void* wTsplit, float* dx, long lddx, int N,
+                              int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S, int stride, int pad, int dil,
+                              hipStream_t stream);
+int u2pl_gemm_batched_wsh_f32(const float* x, long ldx, long zx, const float* x_amax, const void* wsplit, float* y, long ldy, long zy,
+                              long M, int K, int Nn, int batch, hipStream_t stream);
+/* split-fp16 weight gradients (csrc/wgrad_tr.hip; autograd of nn.Conv2d under loss.backward(), train_semi.py:527): the calls
+ * u2pl_conv2d_wgrad_f32 / u2pl_wgrad_batched_f32 with the device-scalar maxima of both operands; same workspace and slab plan;
+ * only where u2pl_wgrad_h_eligible(Cin, Cout) (Cin, Cout >= 128) -- U2PL_EINVAL otherwise. */
+int u2pl_wgrad_h_eligible(int Cin, int Cout);
+int u2pl_conv2d_wgrad_h_f32(const float* dy, long lddy, const float* dy_amax, const float* x, long ldx, const float* x_amax, float* dw,
+                            void* workspace, int accumulate, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R,
+                            int S, int stride, int pad, int dil, hipStream_t stream);
+int u2pl_wgrad_batched_h_f32(const float* dy, long lddy, long zdy, const float* dy_amax, const float* x, long ldx, long zx,
+                             const float* x_amax, float* part, long M, int Cin, int Cout, int batch, hipStream_t stream);
+
 /* ---- nn.hip ----------------------------------------------------------------- */
 /* nn.SyncBatchNorm / BatchNorm2d (base.py:6-8 get_syncbn): statistics, apply (+residual, ReLU,
  * Dropout2d scale: resnet.py:120-140, decoder.py:79-104), backward; sums are double [2][C] so the

@@ -996,6 +996,29 @@ U2PL_API int u2pl_conv2d_wgrad_f32(const float* dy, long lddy, const float* x, l
     return 0;
 }
 
+// split-fp16 weight gradient (round 6; conv_geom.h, wgrad_tr.hip): dy_amax / x_amax = device scalars max |dY|, max |X| (or upper
+// bounds within ~2^8).  Only the layers k_wgrad_tr serves (u2pl_wgrad_h_eligible); workspace / slab plan as u2pl_conv2d_wgrad_f32.
+U2PL_API int u2pl_wgrad_h_eligible(int Cin, int Cout) {
+    ConvGeom g = {1, 1, 1, Cin, 1, 1, Cout, 1, 1, 1, 0, 0, 1, 0};
+    return conv_split() && wgrad_tr_eligible(g);
+}
+U2PL_API int u2pl_conv2d_wgrad_h_f32(const float* dy, long lddy, const float* dy_amax, const float* x, long ldx, const float* x_amax,
+                                     float* dw, void* workspace, int accumulate, int N, int Hin, int Win, int Cin, int Hout,
+                                     int Wout, int Cout, int R, int S, int stride, int pad, int dil, hipStream_t stream) {
+    if (Cin % 4 || Cout % 4 || !dy_amax || !x_amax) return U2PL_EINVAL;
+    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
+    if (!(conv_split() && wgrad_tr_eligible(g))) return U2PL_EINVAL;
+    int ct, ns, cps;
+    wgrad_tr_plan(g, R * S, ct, ns, cps);
+    float* part = (float*)workspace;
+    const int rc = launch_wgrad_tr(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, 0, 0, dy_amax, x_amax);
+    if (rc) return rc;
+    const long wsz = (long)Cout * R * S * Cin;
+    U2PL_LAUNCH(k_wgrad_reduce, dim3(grid_for(wsz / 4, 256)), dim3(256), 0, stream, part, wsz, ns, accumulate, dw);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
 // weight gradient with bf16-rounded dY / X operands (fp32 accumulate); workspace as u2pl_conv2d_wgrad_workspace_bytes
 U2PL_API int u2pl_conv2d_wgrad_bf16op_f32(const float* dy, long lddy, const float* x, long ldx, float* dw,
                                           void* workspace, int accumulate, int N, int Hin, int Win, int Cin, int Hout,
@@ -1059,6 +1082,17 @@ U2PL_API int u2pl_wgrad_batched_f32(const float* dy, long lddy, long zdy, const 
     if (BM == 128) return launch_wgrad<2, 1>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx);
     if (BN == 128) return launch_wgrad<1, 2>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx);
     return launch_wgrad<1, 1>(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx);
+}
+
+// split-fp16 form of u2pl_wgrad_batched_f32 (same slab plan and workspace; u2pl_wgrad_h_eligible(Cin, Cout) layers only)
+U2PL_API int u2pl_wgrad_batched_h_f32(const float* dy, long lddy, long zdy, const float* dy_amax, const float* x, long ldx, long zx,
+                                      const float* x_amax, float* part, long M, int Cin, int Cout, int batch, hipStream_t stream) {
+    if (Cin % 4 || Cout % 4 || M <= 0 || M >= (1L << 31) || !dy_amax || !x_amax) return U2PL_EINVAL;
+    ConvGeom g = batched_wgrad_geom(M, Cin, Cout, batch);
+    if (!(conv_split() && wgrad_tr_eligible(g))) return U2PL_EINVAL;
+    int ct, ns, cps;
+    wgrad_tr_plan(g, batch, ct, ns, cps);
+    return launch_wgrad_tr(dy, lddy, x, ldx, part, g, ct, ns, cps, stream, zdy, zx, dy_amax, x_amax);
 }
 
 // ---------------------------------------------------------------------------

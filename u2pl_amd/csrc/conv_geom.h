@@ -65,3 +65,39 @@ __device__ __forceinline__ void split3_bf16(float4 v, uint2& p0, uint2& p1, uint
     p2 = pack4_bf16(r2);
 }
 
+
+// ---- "split-fp16" (round 6): fp32 products from THREE fp16 piece products -------------------------------------------------
+// An fp32 value scaled by a power of two into the fp16 range is the sum of TWO fp16 pieces to within 2^-25 of itself:
+// h0 = fp16(x s) carries 11 significant bits (error <= 2^-12 |x s|), the residual x s - h0 is exact in fp32 and
+// h1 = fp16(x s - h0) carries the next 11 (round to nearest: the sign bit of the residual is the "23rd" bit), so
+// |x s - h0 - h1| <= 2^-12 * 2^-12 * |x s| / 2.  A product a b is accumulated in fp32 from a1 b0 + a0 b1 + a0 b0 (the dropped
+// a1 b1 is <= 2^-24 |a b|: one fp32 rounding, what the six-product bf16 form drops too) -- three v_mfma_f32_32x32x16_f16
+// instead of six v_mfma_f32_32x32x16_bf16 per 32x32x16 block, two piece planes per operand in LDS instead of three.  fp16 has
+// 5 exponent bits, so the operands are scaled PER TENSOR by a power of two (exact) chosen from max|x| (split2_exp: the largest
+// magnitude lands in [2^14, 2^15)), and the accumulators are scaled back by ldexp in the epilogue (exact).  gfx950's matrix
+// cores and v_cvt_pk_f16_f32 honour fp16 subnormals (tools/micro/f16_denorm.hip), so an element far below the tensor's maximum
+// degrades gracefully: its absolute error is <= 2^-25 in scaled units = 2^-40 max|x|, i.e. elements down to 2^-16 of the
+// maximum keep full fp32 accuracy and no element contributes more error than 2^-40 max|x| |b|.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pack2_f16(float lo, float hi) {        // ONE v_cvt_pk_f16_f32 (round to nearest even)
+    f16x2_t v;
+    v[0] = (_Float16)lo;
+    v[1] = (_Float16)hi;
+    return *(unsigned*)&v;
+}
+__device__ __forceinline__ float f16_lo_f(unsigned p) { return (float)(*(f16x2_t*)&p)[0]; }
+__device__ __forceinline__ float f16_hi_f(unsigned p) { return (float)(*(f16x2_t*)&p)[1]; }
+// power-of-two scale exponent for a tensor whose largest magnitude is amax: amax * 2^e lies in [2^14, 2^15); zero / subnormal
+// maxima take the largest scale, Inf / NaN the smallest (the pieces of such elements are Inf / NaN as they should be)
+__host__ __device__ static inline int split2_exp_bits(unsigned amax_bits) {
+    const int ex = (int)((amax_bits >> 23) & 0xffu);
+    const int e = 14 - (ex - 127);
+    return e > 126 ? 126 : e;          // (ex = 255 gives -114: a normal scale)
+}
+__device__ __forceinline__ float split2_scale(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+__device__ __forceinline__ void split2_f16(float4 v, float s, uint2& p0, uint2& p1) {
+    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+    p0 = make_uint2(pack2_f16(v.x, v.y), pack2_f16(v.z, v.w));
+    p1 = make_uint2(pack2_f16(v.x - f16_lo_f(p0.x), v.y - f16_hi_f(p0.x)), pack2_f16(v.z - f16_lo_f(p0.y), v.w - f16_hi_f(p0.y)));
+}

@@ -148,6 +148,183 @@ U2PL_API int u2pl_weight_split3_f32(const float* w, long zw, int rows, int K, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// split-fp16 weight planes (round 6; conv_geom.h): out = [K/32][2 pieces][Np][32 k] fp16 in the same row padding and swizzle,
+// followed by `batch` uint32 -- the fp32 bit pattern of max |w| of each matrix (the GEMM derives the power-of-two scale from
+// it with split2_exp_bits, exactly as the split did).  Two launches per rebuild: the maxima (atomicMax on the bit patterns of
+// |w|: order-independent, deterministic), then the pieces.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned absmax8_bits(float4 a, float4 b) {
+    const float m = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                          fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+    // (fmaxf drops NaNs: a NaN weight must not hide -- OR the NaN test in: the bit pattern of a NaN is above every finite one)
+    const bool nan = (a.x != a.x) | (a.y != a.y) | (a.z != a.z) | (a.w != a.w) | (b.x != b.x) | (b.y != b.y) | (b.z != b.z) | (b.w != b.w);
+    return nan ? 0x7fc00000u : __float_as_uint(m);
+}
+// wave-level: one atomic per wave where all lanes target the same slot (the common case), one per lane otherwise
+__device__ __forceinline__ void amax_publish(unsigned bits, unsigned* slot, bool active) {
+    const unsigned long long key = active ? (unsigned long long)slot : 0ull;
+    const unsigned long long first = __builtin_amdgcn_readfirstlane((unsigned)key) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(key >> 32)) << 32);
+    if (__all(key == first)) {
+        if (!first) return;
+        unsigned m = bits;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+        if ((threadIdx.x & 63) == 0) atomicMax(slot, m);
+    } else if (active) {
+        atomicMax(slot, bits);
+    }
+}
+__host__ __device__ static inline size_t ws2_plane_bytes(int Np, int K, int batch) { return (size_t)batch * (K / 32) * 2 * Np * WS_ROW_B; }
+__global__ void k_weight_amax_clear(const SplitJob* __restrict__ jobs, int njobs) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= njobs) return;
+    const SplitJob j = jobs[t];
+    unsigned* slot = (unsigned*)((char*)j.out + ws2_plane_bytes(j.Np, j.K, j.batch));
+    for (int z = 0; z < j.batch; ++z) slot[z] = 0u;
+}
+__global__ void k_weight_absmax_multi(const SplitJob* __restrict__ jobs, int njobs, long total) {
+    // (full trips for every lane: the wave-level publish uses cross-lane operations)
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long trips = (total + stride - 1) / stride;
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    for (long t = 0; t < trips; ++t, i += stride) {
+        bool active = i < total;
+        unsigned bits = 0;
+        unsigned* slot = nullptr;
+        if (active) {
+            int lo = 0, hi = njobs - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (jobs[mid].seg_begin <= i) lo = mid; else hi = mid - 1;
+            }
+            const SplitJob j = jobs[lo];
+            const int nseg = j.K / 8;
+            const long per = (long)j.Np * nseg;
+            long r = i - j.seg_begin;
+            const int z = (int)(r / per);
+            r -= (long)z * per;
+            slot = (unsigned*)((char*)j.out + ws2_plane_bytes(j.Np, j.K, j.batch)) + z;
+            // the maximum does not depend on the element order: read the source linearly (both kinds: rows * K floats per matrix)
+            const int n = (int)(r / nseg), sg = (int)(r % nseg);
+            active = n < j.rows;
+            if (active) {
+                const float4* src = (const float4*)(j.src + ((long)z * j.rows + n) * j.K + sg * 8);
+                bits = absmax8_bits(src[0], src[1]);
+            }
+        }
+        amax_publish(bits, slot, active);
+    }
+}
+__global__ void k_weight_split2h_multi(const SplitJob* __restrict__ jobs, int njobs, long total) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = njobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].seg_begin <= i) lo = mid; else hi = mid - 1;
+        }
+        const SplitJob j = jobs[lo];
+        const int nseg = j.K / 8;
+        const long per = (long)j.Np * nseg;
+        long r = i - j.seg_begin;
+        const int z = (int)(r / per);
+        r -= (long)z * per;
+        int sg, n;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (j.kind == 0) {
+            sg = (int)(r % nseg);
+            n = (int)(r / nseg);
+            if (n < j.rows) {
+                const float4* src = (const float4*)(j.src + ((long)z * j.rows + n) * j.K + sg * 8);
+                v0 = src[0];
+                v1 = src[1];
+            }
+        } else {
+            n = (int)(r % j.Np);
+            sg = (int)(r / j.Np);
+            if (n < j.rows) {
+                const int Cout = j.K / j.RS;
+                float e[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int k = sg * 8 + q, rs = k / Cout, co = k - rs * Cout;
+                    e[q] = j.src[((long)co * j.RS + rs) * j.rows + n];
+                }
+                v0 = make_float4(e[0], e[1], e[2], e[3]);
+                v1 = make_float4(e[4], e[5], e[6], e[7]);
+            }
+        }
+        const unsigned* amax = (const unsigned*)((const char*)j.out + ws2_plane_bytes(j.Np, j.K, j.batch));
+        const float sc = split2_scale(split2_exp_bits(amax[z]));
+        uint2 a0, a1, b0, b1;
+        split2_f16(v0, sc, a0, a1);
+        split2_f16(v1, sc, b0, b1);
+        const int c = sg >> 2, s = sg & 3;
+        const long pl = (long)j.Np * 32;
+        unsigned short* out = j.out + (long)z * (j.K / 32) * 2 * pl;
+        const long base = (((long)c * 2) * j.Np + n) * 32 + ((s ^ ((n >> 2) & 3)) << 3);       // in fp16 elements
+        *(uint4*)(out + base) = make_uint4(a0.x, a0.y, b0.x, b0.y);
+        *(uint4*)(out + base + pl) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+    }
+}
+U2PL_API size_t u2pl_weight_split2h_bytes(int rows, int K, int batch) {
+    return ws2_plane_bytes(ws_pad_rows(rows), K, batch) + (((size_t)batch * 4 + 15) & ~(size_t)15);
+}
+// jobs: the SplitJob table of u2pl_weight_split3_multi_f32 (same fields; out = a u2pl_weight_split2h_bytes buffer).  Three
+// launches: the maxima behind each job's planes are cleared, computed, and consumed by the split.
+U2PL_API int u2pl_weight_split2h_multi_f32(const void* jobs, int njobs, long total, hipStream_t stream) {
+    if (njobs <= 0 || total <= 0) return njobs == 0 ? 0 : U2PL_EINVAL;
+    U2PL_LAUNCH(k_weight_amax_clear, dim3(cdiv(njobs, 256)), dim3(256), 0, stream, (const SplitJob*)jobs, njobs);
+    U2PL_LAUNCH_CHECK();
+    U2PL_LAUNCH(k_weight_absmax_multi, dim3(grid_for(total, 256, 4096)), dim3(256), 0, stream, (const SplitJob*)jobs, njobs, total);
+    U2PL_LAUNCH_CHECK();
+    U2PL_LAUNCH(k_weight_split2h_multi, dim3(grid_for(total, 256, 4096)), dim3(256), 0, stream, (const SplitJob*)jobs, njobs, total);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+// one weight (batch matrices [rows][K], zw floats apart): clears the maxima, computes them, writes the planes
+U2PL_API int u2pl_weight_split2h_f32(const float* w, long zw, int rows, int K, int batch, void* out, void* job_scratch, hipStream_t stream) {
+    if (rows <= 0 || K <= 0 || (K % 32) || batch <= 0 || !job_scratch) return U2PL_EINVAL;
+    if (batch > 1 && zw != (long)rows * K) return U2PL_EINVAL;
+    const int Np = ws_pad_rows(rows);
+    SplitJob j = {w, (unsigned short*)out, 0, rows, Np, K, 0, 1, batch};
+    const long total = (long)batch * Np * (K / 8);
+    hipError_t e = hipMemcpyAsync(job_scratch, &j, sizeof j, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return (int)e;
+    return u2pl_weight_split2h_multi_f32(job_scratch, 1, total, stream);
+}
+// max |x| of an activation operand [M][C] (row pitch ld floats) -> *out (fp32; NaN if any element is NaN): out is cleared and
+// written by this call.  The A operand's scale of the *_wsh_* entry points.
+__global__ void k_absmax_rows(const float* __restrict__ x, long ld, long M, int C4, unsigned* __restrict__ out) {
+    const long total = M * C4;
+    unsigned m = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C4;
+        const int c = (int)(i - r * C4);
+        const float4 v = *(const float4*)(x + r * ld + c * 4);
+        const unsigned b = absmax8_bits(v, v);
+        m = b > m ? b : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+    __shared__ unsigned sm[16];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = sm[w] > m ? sm[w] : m;
+        if (m) atomicMax(out, m);
+    }
+}
+U2PL_API int u2pl_absmax_f32(const float* x, long ld, long M, int C, float* out, hipStream_t stream) {
+    if (M < 0 || C <= 0 || (C & 3) || (ld & 3)) return U2PL_EINVAL;
+    hipError_t e = hipMemsetAsync(out, 0, 4, stream);
+    if (e != hipSuccess) return (int)e;
+    if (M == 0) return 0;
+    U2PL_LAUNCH(k_absmax_rows, dim3(grid_for(M * (C / 4), 512, 2048)), dim3(512), 0, stream, x, ld, M, C / 4, (unsigned*)out);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // the GEMM.  TM x TN 32x32 accumulators per wave, WM x WN waves per block.
 // ---------------------------------------------------------------------------------------------------------------
 // PW: pointwise gather (1x1, stride 1, no padding -- the GEMM view: 1x1 convolutions and the Winograd component
@@ -161,17 +338,23 @@ U2PL_API int u2pl_igemm_ws_set_stamp_buffer(void* p) { g_ws_stamps = (unsigned l
 #endif
 // the kernel body: block `bid` of a group of G persistent blocks that share the tiles [tile0, tile0 + total_tiles) of one
 // tile shape (k_igemm_ws: the whole grid is one group; k_igemm_ws_mix: a wide group and a narrow group in one launch)
-template <int TM, int TN, int WM, int WN, bool PW, int ABL = 0>
+// NP: pieces per operand.  3: bf16 pieces, six piece products (the round-3/4 arithmetic); 2: fp16 pieces of the operands scaled
+// per tensor by a power of two, three piece products (conv_geom.h "split-fp16", round 6): x_amax -> max |x| of the A operand
+// (device scalar, read once), b_amax -> max |w| per matrix of the batch (the tail of the split planes, written by the split).
+template <int TM, int TN, int WM, int WN, bool PW, int ABL = 0, int NP = 3>
 __device__ __forceinline__ void igemm_ws_body(
-    const float* __restrict__ x, long ldx, const unsigned short* __restrict__ ws, const float* __restrict__ bias,
+    const float* __restrict__ x, long ldx, const float* __restrict__ x_amax, const unsigned short* __restrict__ ws,
+    const unsigned* __restrict__ b_amax, const float* __restrict__ bias,
     float* __restrict__ y, long ldy, const ConvGeom& g, unsigned xbytes, unsigned wsbytes, unsigned ybytes, unsigned resbytes, int Np,
     float* __restrict__ stats, const float* __restrict__ pivot, long zx, long zws, long zy, const BnEpi& epi, int mtiles, int ntiles,
     int total_tiles, int tile0, const int bid, const int G) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
     constexpr int RPP = NT / 8, RA = BM / RPP;              // A: 8 threads x float4 per 32-deep row
-    constexpr int UB = 3 * BN * 4, RBU = UB / NT;           // B: 16-byte units per chunk, per thread
+    constexpr int UB = NP * BN * 4, RBU = UB / NT;          // B: 16-byte units per chunk, per thread
     static_assert(BM % RPP == 0 && UB % NT == 0, "tile / thread-count mismatch");
-    constexpr int A_ST = 3 * BM * WS_ROW_B, B_ST = 3 * BN * WS_ROW_B, ST = A_ST + B_ST;    // bytes per stage
+    static_assert(NP == 2 || NP == 3, "pieces per operand");
+    constexpr int A_ST = NP * BM * WS_ROW_B, B_ST = NP * BN * WS_ROW_B, ST = A_ST + B_ST;    // bytes per stage
+    constexpr int NPROD = NP == 3 ? 6 : 3;                  // piece products per 16-deep k block
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
 
@@ -208,6 +391,13 @@ __device__ __forceinline__ void igemm_ws_body(
     const long M = (long)g.N * g.Hout * g.Wout;
     const int K = g.R * g.S * g.Cin;
     const int nk = K / BK;
+    // split-fp16: the A operand's power-of-two scale (wave-uniform; the weight planes carry theirs already)
+    int ea = 0;
+    float sa = 1.f;
+    if constexpr (NP == 2) {
+        ea = __builtin_amdgcn_readfirstlane(split2_exp_bits(__float_as_uint(ldg(x_amax))));
+        sa = split2_scale(ea);
+    }
     // chunks per tile, made EVEN (an odd K / 32 gets one all-zero chunk: out-of-range offsets load zeros, the products add
     // +0): stage and register-set parity then restart at every tile and the tile loop below has ONE epilogue instance
     const int nk2 = (nk + 1) & ~1;
@@ -327,7 +517,7 @@ __device__ __forceinline__ void igemm_ws_body(
         boff[j] = p * Np * WS_ROW_B + wi * 16;
         blds[j] = A_ST + p * BN * WS_ROW_B + wi * 16;
     }
-    const int chunk_b = 3 * Np * WS_ROW_B;                  // bytes per chunk of the split planes
+    const int chunk_b = NP * Np * WS_ROW_B;                 // bytes per chunk of the split planes
     int b_v = bid, b_kc = 0, b_toff = 0;
     int b_nk = nk, b_nk2 = nk2, b_base = 0;                 // chunks of the B stream's tile, its first chunk in the planes
     auto b_tile_setup = [&]() __attribute__((always_inline)) {
@@ -386,24 +576,29 @@ __device__ __forceinline__ void igemm_ws_body(
     const int li = lane & 31, lh = lane >> 5;
     const int sw0 = (lh ^ ((li >> 2) & 3)) << 4;            // slot of k segment lh (gk = 0); gk = 1: ^ 32
     const int afr = (wm * 32 * TM + li) * WS_ROW_B, bfr = A_ST + (wn * 32 * TN + li) * WS_ROW_B;
+    using frag_t = std::conditional_t<NP == 3, bf16x8, f16x8>;
     auto lda = [&](int stage, int p, int a, int gk) __attribute__((always_inline)) {
-        return __builtin_bit_cast(bf16x8, *(const uint4*)(smem + stage * ST + afr + p * (BM * WS_ROW_B) + a * (32 * WS_ROW_B) + (sw0 ^ (gk << 5))));
+        return __builtin_bit_cast(frag_t, *(const uint4*)(smem + stage * ST + afr + p * (BM * WS_ROW_B) + a * (32 * WS_ROW_B) + (sw0 ^ (gk << 5))));
     };
     auto ldb = [&](int stage, int p, int b, int gk) __attribute__((always_inline)) {
-        return __builtin_bit_cast(bf16x8, *(const uint4*)(smem + stage * ST + bfr + p * (BN * WS_ROW_B) + b * (32 * WS_ROW_B) + (sw0 ^ (gk << 5))));
+        return __builtin_bit_cast(frag_t, *(const uint4*)(smem + stage * ST + bfr + p * (BN * WS_ROW_B) + b * (32 * WS_ROW_B) + (sw0 ^ (gk << 5))));
     };
-    struct Frag { bf16x8 a[3][TM], b[3][TN]; };
+    struct Frag { frag_t a[NP][TM], b[NP][TN]; };
     // ---- prologue: chunk 0 into stage 0; A(1), B(1), A(2) in flight
     load_a(C0{});
     load_b();
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
         uint2 p0, p1, p2;
-        split3_bf16(ra[0][i], p0, p1, p2);
         unsigned char* d = smem + alds[i];
+        if constexpr (NP == 3) {
+            split3_bf16(ra[0][i], p0, p1, p2);
+            *(uint2*)(d + 2 * BM * WS_ROW_B) = p2;
+        } else {
+            split2_f16(ra[0][i], sa, p0, p1);
+        }
         *(uint2*)d = p0;
         *(uint2*)(d + BM * WS_ROW_B) = p1;
-        *(uint2*)(d + 2 * BM * WS_ROW_B) = p2;
     }
 #pragma unroll
     for (int j = 0; j < RBU; ++j) store_b(0, j);
@@ -422,33 +617,35 @@ __device__ __forceinline__ void igemm_ws_body(
     ph[1] = __builtin_readcyclecounter();
 #endif
 
-    constexpr int PER = TM * TN, NMF = 12 * PER;            // matrix instructions per 16-deep block product / per chunk
-    constexpr int NRD = 3 * (TM + TN);                      // operand reads per 16-deep block
+    constexpr int PER = TM * TN, NMF = 2 * NPROD * PER;     // matrix instructions per 16-deep block product / per chunk
+    constexpr int NRD = NP * (TM + TN);                     // operand reads per 16-deep block
     constexpr int TAIL = 2 * PER;
     Frag f[2];
     // matrix instruction I of a chunk: k block I / (6 PER), product (I / PER) % 6, accumulator I % PER
     auto do_mfma = [&](auto i_c) __attribute__((always_inline)) {
         constexpr int I = decltype(i_c)::value;
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-        constexpr int gk = I / (6 * PER), q = (I / PER) % 6, ab = I % PER, a = ab / TN, b = ab % TN;
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[gk].a[PA[q]][a], f[gk].b[PB[q]][b], acc[a][b], 0, 0, 0);
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};       // NP == 3: a2b0 a1b1 a0b2 a1b0 a0b1 a0b0
+        constexpr int QA[3] = {1, 0, 0}, QB[3] = {0, 1, 0};                         // NP == 2: a1b0 a0b1 a0b0
+        constexpr int gk = I / (NPROD * PER), q = (I / PER) % NPROD, ab = I % PER, a = ab / TN, b = ab % TN;
+        if constexpr (NP == 3) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[gk].a[PA[q]][a], f[gk].b[PB[q]][b], acc[a][b], 0, 0, 0);
+        else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[gk].a[QA[q]][a], f[gk].b[QB[q]][b], acc[a][b], 0, 0, 0);
     };
     // operand read J of a k block, in the order the products need them: a2.., b0.., a1.., b1.., a0.., b2..
     auto do_read = [&](auto stage_c, auto gk_c, auto j_c) __attribute__((always_inline)) {
         constexpr int stage = decltype(stage_c)::value, gk = decltype(gk_c)::value, J = decltype(j_c)::value;
         if constexpr (J < NRD) {
             constexpr int q = J / (TM + TN), w = J % (TM + TN);
-            if constexpr (w < TM) f[gk].a[2 - q][w] = lda(stage, 2 - q, w, gk);
+            if constexpr (w < TM) f[gk].a[NP - 1 - q][w] = lda(stage, NP - 1 - q, w, gk);
             else f[gk].b[q][w - TM] = ldb(stage, q, w - TM, gk);
         }
     };
     auto zero_tail_operands = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
-            for (int a = 0; a < TM; ++a) f[1].a[p][a] = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
+            for (int a = 0; a < TM; ++a) f[1].a[p][a] = __builtin_bit_cast(frag_t, make_uint4(0, 0, 0, 0));
 #pragma unroll
-            for (int b = 0; b < TN; ++b) f[1].b[p][b] = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
+            for (int b = 0; b < TN; ++b) f[1].b[p][b] = __builtin_bit_cast(frag_t, make_uint4(0, 0, 0, 0));
         }
     };
 
@@ -463,11 +660,11 @@ __device__ __forceinline__ void igemm_ws_body(
     zero_tail_operands();
     if constexpr (ABL & 16) {   // (timing experiment: operands never read from LDS)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
-            for (int a = 0; a < TM; ++a) f[0].a[p][a] = __builtin_bit_cast(bf16x8, make_uint4(tid, 1, 2, 3));
+            for (int a = 0; a < TM; ++a) f[0].a[p][a] = __builtin_bit_cast(frag_t, make_uint4(tid, 1, 2, 3));
 #pragma unroll
-            for (int b = 0; b < TN; ++b) f[0].b[p][b] = __builtin_bit_cast(bf16x8, make_uint4(tid, 1, 2, 3));
+            for (int b = 0; b < TN; ++b) f[0].b[p][b] = __builtin_bit_cast(frag_t, make_uint4(tid, 1, 2, 3));
         }
     }
     uint2 pc[3];          // pieces of the float4 being split
@@ -487,10 +684,15 @@ __device__ __forceinline__ void igemm_ws_body(
         //                                                                     VALU), the three piece stores behind a float4's last
         //   then RBU slots                                                  | weight-piece stores, one per slot
         //   then RBU + RA slots                                             | loads B(kc+2), then A(kc+3), one per slot
+        //   NP == 2 (half the matrix instructions for 2/3 of the memory operations): the split starts at slot 0 (two steps per
+        //   value pair: 7 + 1 VALU), the operand reads share its slots; where the plan would overrun the chunk the loads move up
+        //   beside the weight-piece stores (a store precedes the load that refills its register in the same slot)
         constexpr int F0_PRE = TM + TN, F0_PER = (NRD - F0_PRE + TAIL - 1) / TAIL;
-        constexpr int F1_START = TAIL, SP_START = TAIL, BS_START = SP_START + 6 * RA, LD_START = BS_START + RBU;
-        static_assert(F1_START + NRD <= TAIL + 6 * PER, "k block 1 operands would be read after their first use");
-        static_assert(LD_START + RBU + RA <= NMF, "plan does not fit the chunk");
+        constexpr int SPS = NP, SP_N = SPS * 2 * RA;          // split steps per value pair; slots of the split
+        constexpr int F1_START = TAIL, SP_START = NP == 3 ? TAIL : 0, BS_START = SP_START + SP_N;
+        constexpr int LD_START = (BS_START + RBU + RBU + RA <= NMF) ? BS_START + RBU : NMF - RBU - RA;
+        static_assert(F1_START + NRD <= TAIL + NPROD * PER, "k block 1 operands would be read after their first use");
+        static_assert(LD_START + RBU + RA <= NMF && LD_START >= BS_START && LD_START >= SP_START + SP_N, "plan does not fit the chunk");
         using CUR = std::integral_constant<int, cur>;
 #ifdef U2PL_WS_STAMPS
         unsigned long long ts[14];
@@ -509,16 +711,23 @@ __device__ __forceinline__ void igemm_ws_body(
                     static_for<0, F0_PER>([&](auto u) __attribute__((always_inline)) { do_read(CUR{}, C0{}, std::integral_constant<int, F0_PRE + sl * F0_PER + decltype(u)::value>{}); });
                 if constexpr (sl >= F1_START) do_read(CUR{}, C1{}, std::integral_constant<int, sl - F1_START>{});
             }
-            if constexpr (sl >= SP_START && sl < SP_START + 6 * RA) {
-                constexpr int k = (sl - SP_START) / 3, step = (sl - SP_START) % 3;     // value pair k of A(kc + 1), step
+            if constexpr (sl >= SP_START && sl < SP_START + SP_N) {
+                constexpr int k = (sl - SP_START) / SPS, step = (sl - SP_START) % SPS;     // value pair k of A(kc + 1), step
                 if constexpr (step == 0) {
                     const float4 v = ra[nxt][k >> 1];
                     sp_l = (k & 1) ? v.z : v.x;
                     sp_h = (k & 1) ? v.w : v.y;
+                    if constexpr (NP == 2) { sp_l *= sa; sp_h *= sa; }
                 }
                 unsigned w;
                 if constexpr (ABL & 1) w = (__float_as_uint(sp_h) & 0xffff0000u) | (__float_as_uint(sp_l) >> 16);
-                else {
+                else if constexpr (NP == 2) {
+                    w = pack2_f16(sp_l, sp_h);
+                    if constexpr (step == 0) {
+                        sp_l = sp_l - f16_lo_f(w);
+                        sp_h = sp_h - f16_hi_f(w);
+                    }
+                } else {
                     if constexpr (step == 0) w = pack2_bf16_first(sp_l, sp_h);      // (first piece: overflow guard, conv_geom.h)
                     else w = pack2_bf16(sp_l, sp_h);
                     if constexpr (step < 2) {
@@ -527,14 +736,15 @@ __device__ __forceinline__ void igemm_ws_body(
                     }
                 }
                 if constexpr (k & 1) pc[step].y = w; else pc[step].x = w;
-                if constexpr ((k & 1) && step == 2) {
+                if constexpr ((k & 1) && step == SPS - 1) {
                     if constexpr (ABL & 4) {
-                        asm volatile("" ::"v"(pc[0].x), "v"(pc[0].y), "v"(pc[1].x), "v"(pc[1].y), "v"(pc[2].x), "v"(pc[2].y));
+                        asm volatile("" ::"v"(pc[0].x), "v"(pc[0].y), "v"(pc[1].x), "v"(pc[1].y));
+                        if constexpr (NP == 3) asm volatile("" ::"v"(pc[2].x), "v"(pc[2].y));
                     } else {
                         unsigned char* d = smem + nxt * ST + alds[k >> 1];
                         *(uint2*)d = pc[0];
                         *(uint2*)(d + BM * WS_ROW_B) = pc[1];
-                        *(uint2*)(d + 2 * BM * WS_ROW_B) = pc[2];
+                        if constexpr (NP == 3) *(uint2*)(d + 2 * BM * WS_ROW_B) = pc[2];
                     }
                 }
             }
@@ -629,9 +839,20 @@ __device__ __forceinline__ void igemm_ws_body(
             if (bn_all) { mu[b] = colparam(epi.mean, col); is[b] = colparam(epi.invstd, col); ga[b] = colparam(epi.gamma, col); be[b] = colparam(epi.beta, col); }
             if (stats) pv[b] = colparam(pivot, col);
         }
+        // split-fp16: the weight matrix's scale exponent (a scalar load, in front of every store like the parameters)
+        int dexp = 0;
+        if constexpr (NP == 2) dexp = -(ea + split2_exp_bits(__builtin_amdgcn_readfirstlane((int)ldg(b_amax + zs))));
         // (the parameter loads are in flight under the chunk's tail products)
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, TAIL>([&](auto sl) __attribute__((always_inline)) { do_mfma(std::integral_constant<int, NMF - TAIL + decltype(sl)::value>{}); });
+        if constexpr (NP == 2) {        // back to the operands' own scale: exact (a power of two), one v_ldexp_f32 per value
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[a][b][e] = __builtin_ldexpf(acc[a][b][e], dexp);
+        }
 #ifdef U2PL_WS_STAMPS
         te[1] = te[2] = __builtin_readcyclecounter();
 #endif
@@ -765,45 +986,53 @@ __device__ __forceinline__ void igemm_ws_body(
 #endif
 }
 
-template <int TM, int TN, int WM, int WN, bool PW, int ABL = 0>
+template <int TM, int TN, int WM, int WN, bool PW, int ABL = 0, int NP = 3>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_igemm_ws(
-    const float* __restrict__ x, long ldx, const unsigned short* __restrict__ ws, const float* __restrict__ bias,
+    const float* __restrict__ x, long ldx, const float* __restrict__ x_amax, const unsigned short* __restrict__ ws,
+    const unsigned* __restrict__ b_amax, const float* __restrict__ bias,
     float* __restrict__ y, long ldy, ConvGeom g, unsigned xbytes, unsigned wsbytes, unsigned ybytes, unsigned resbytes, int Np,
     float* __restrict__ stats, const float* __restrict__ pivot, long zx, long zws, long zy, BnEpi epi, int mtiles, int ntiles,
     int total_tiles, int tile0) {
-    igemm_ws_body<TM, TN, WM, WN, PW, ABL>(x, ldx, ws, bias, y, ldy, g, xbytes, wsbytes, ybytes, resbytes, Np, stats, pivot, zx, zws, zy,
-                                           epi, mtiles, ntiles, total_tiles, tile0, (int)blockIdx.x, (int)gridDim.x);
+    igemm_ws_body<TM, TN, WM, WN, PW, ABL, NP>(x, ldx, x_amax, ws, b_amax, bias, y, ldy, g, xbytes, wsbytes, ybytes, resbytes, Np, stats,
+                                               pivot, zx, zws, zy, epi, mtiles, ntiles, total_tiles, tile0, (int)blockIdx.x, (int)gridDim.x);
 }
 // MIXED tile plan in ONE launch: blocks [0, nwide) are the persistent 128 x 256 group over the wide tiles [0, wide_tiles)
 // (whole rounds: wide_tiles is a multiple of nwide), the blocks behind them take ONE 128 x 128 tile each of the remainder
 // (narrow tiles [2 wide_tiles, 2 wide_tiles + narrow_tiles): a narrow tile (z, mt, 2 nt + h) is half h of the wide tile
 // (z, mt, nt)).  A block needs a whole CU's LDS, so the hardware hands the narrow blocks to the CUs as the wide blocks
 // retire -- the remainder round starts without a second launch's drain, gap and cold start (~15 us measured).
-template <bool PW>
+template <bool PW, int NP = 3>
 __global__ __launch_bounds__(512, 2) void k_igemm_ws_mix(
-    const float* __restrict__ x, long ldx, const unsigned short* __restrict__ ws, const float* __restrict__ bias,
+    const float* __restrict__ x, long ldx, const float* __restrict__ x_amax, const unsigned short* __restrict__ ws,
+    const unsigned* __restrict__ b_amax, const float* __restrict__ bias,
     float* __restrict__ y, long ldy, ConvGeom g, unsigned xbytes, unsigned wsbytes, unsigned ybytes, unsigned resbytes, int Np,
     float* __restrict__ stats, const float* __restrict__ pivot, long zx, long zws, long zy, BnEpi epi, int mtiles, int ntiles_w,
     int nwide, int wide_tiles, int narrow_tiles) {
     if ((int)blockIdx.x < nwide)
-        igemm_ws_body<2, 2, 2, 4, PW>(x, ldx, ws, bias, y, ldy, g, xbytes, wsbytes, ybytes, resbytes, Np, stats, pivot, zx, zws, zy, epi,
-                                      mtiles, ntiles_w, wide_tiles, 0, (int)blockIdx.x, nwide);
+        igemm_ws_body<2, 2, 2, 4, PW, 0, NP>(x, ldx, x_amax, ws, b_amax, bias, y, ldy, g, xbytes, wsbytes, ybytes, resbytes, Np, stats, pivot,
+                                             zx, zws, zy, epi, mtiles, ntiles_w, wide_tiles, 0, (int)blockIdx.x, nwide);
     else
-        igemm_ws_body<2, 1, 2, 4, PW>(x, ldx, ws, bias, y, ldy, g, xbytes, wsbytes, ybytes, resbytes, Np, stats, pivot, zx, zws, zy, epi,
-                                      mtiles, 2 * ntiles_w, narrow_tiles, 2 * wide_tiles, (int)blockIdx.x - nwide, (int)gridDim.x - nwide);
+        igemm_ws_body<2, 1, 2, 4, PW, 0, NP>(x, ldx, x_amax, ws, b_amax, bias, y, ldy, g, xbytes, wsbytes, ybytes, resbytes, Np, stats, pivot,
+                                             zx, zws, zy, epi, mtiles, 2 * ntiles_w, narrow_tiles, 2 * wide_tiles, (int)blockIdx.x - nwide,
+                                             (int)gridDim.x - nwide);
 }
 
 #define WS_NUM_CUS 256
 // U2PL_WS_PERSIST = 1 (default): at most one block per CU, each working through its tiles; 0: one block per tile (A/B switch,
 // same results; u2pl_igemm_ws_set_persist returns the previous value)
+static double ws_fix2() {        // U2PL_WS_FIX2: fixed-cost multiplier of the tile-plan model for the split-fp16 kernels
+    static double v = -1.0;
+    if (v < 0) { const char* e = getenv("U2PL_WS_FIX2"); v = (e && *e) ? atof(e) : 2.0; }
+    return v;
+}
 static int g_ws_persist = -1;
 static int ws_persist() {
     if (g_ws_persist < 0) { const char* e = getenv("U2PL_WS_PERSIST"); g_ws_persist = (e && *e) ? (atoi(e) != 0) : 1; }
     return g_ws_persist;
 }
 U2PL_API int u2pl_igemm_ws_set_persist(int on) { const int old = ws_persist(); g_ws_persist = on != 0; return old; }
-template <int TM, int TN, int WM, int WN, bool PW, int ABL = 0>
-static int launch_igemm_ws(const float* x, long ldx, const void* ws, const float* bias, float* y, long ldy,
+template <int TM, int TN, int WM, int WN, bool PW, int ABL = 0, int NP = 3>
+static int launch_igemm_ws(const float* x, long ldx, const float* x_amax, const void* ws, const float* bias, float* y, long ldy,
                            const ConvGeom& g, hipStream_t stream, float* stats, const float* pivot, int batch, long zx,
                            long zy, const BnEpi* epi, long tile_first = 0, long tile_count = -1) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -811,15 +1040,17 @@ static int launch_igemm_ws(const float* x, long ldx, const void* ws, const float
     if (M <= 0) return 0;
     const int K = g.R * g.S * g.Cin, Np = ws_pad_rows(g.Cout);
     const BnEpi ep = epi ? *epi : BnEpi{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
-    const size_t lds = (size_t)2 * 3 * (BM + BN) * WS_ROW_B + (size_t)8 * BN * sizeof(float);      // two stages + statistics scratch
+    const size_t lds = (size_t)2 * NP * (BM + BN) * WS_ROW_B + (size_t)8 * BN * sizeof(float);      // two stages + statistics scratch
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_igemm_ws<TM, TN, WM, WN, PW, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_igemm_ws<TM, TN, WM, WN, PW, ABL, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
+    if (NP == 2 && !x_amax) return U2PL_EINVAL;
     const long xb = (((long)g.N * g.Hin * g.Win - 1) * ldx + g.Cin) * 4;
     const long yb = ((M - 1) * ldy + g.Cout) * 4;
-    const long wsb1 = (long)(K / 32) * 3 * Np * WS_ROW_B;           // one matrix
+    const long wsb1 = (long)(K / 32) * NP * Np * WS_ROW_B;          // one matrix
+    const unsigned* b_amax = (const unsigned*)((const char*)ws + (size_t)batch * wsb1);       // split-fp16: behind the planes
     // every MATRIX of the batch within 2 GiB (32-bit byte offsets inside a matrix); the batch itself may be larger: the kernel
     // rebuilds the buffer descriptors per matrix from a 64-bit base (x + z * zx, ws + z * zws, y + z * zy)
     if (xb >= (1L << 31) || wsb1 >= (1L << 31) || yb >= (1L << 31)) return U2PL_EINVAL;
@@ -834,36 +1065,38 @@ static int launch_igemm_ws(const float* x, long ldx, const void* ws, const float
 #ifdef U2PL_WS_STAMPS
     (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(d_ws_stamps), &g_ws_stamps, sizeof(void*), 0, hipMemcpyHostToDevice, stream);
 #endif
-    U2PL_LAUNCH((k_igemm_ws<TM, TN, WM, WN, PW, ABL>), dim3(grid), dim3(64 * WM * WN), lds, stream, x, ldx,
-                (const unsigned short*)ws, bias, y, ldy, g, (unsigned)xb, (unsigned)wsb1, (unsigned)yb, (unsigned)resb, Np, stats, pivot, zx,
+    U2PL_LAUNCH((k_igemm_ws<TM, TN, WM, WN, PW, ABL, NP>), dim3(grid), dim3(64 * WM * WN), lds, stream, x, ldx, x_amax,
+                (const unsigned short*)ws, b_amax, bias, y, ldy, g, (unsigned)xb, (unsigned)wsb1, (unsigned)yb, (unsigned)resb, Np, stats, pivot, zx,
                 wsb1 / 2, zy, ep, mtiles, ntiles, (int)total, (int)tile_first);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
 
-template <bool PW>
-static int launch_igemm_ws_mix(const float* x, long ldx, const void* ws, const float* bias, float* y, long ldy,
+template <bool PW, int NP = 3>
+static int launch_igemm_ws_mix(const float* x, long ldx, const float* x_amax, const void* ws, const float* bias, float* y, long ldy,
                                const ConvGeom& g, hipStream_t stream, float* stats, const float* pivot, int batch, long zx,
                                long zy, const BnEpi* epi, long wide_tiles, long narrow_tiles) {
     const long M = (long)g.N * g.Hout * g.Wout;
     const int K = g.R * g.S * g.Cin, Np = ws_pad_rows(g.Cout);
     const BnEpi ep = epi ? *epi : BnEpi{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
-    const size_t lds = (size_t)2 * 3 * (128 + 256) * WS_ROW_B + (size_t)8 * 256 * sizeof(float);       // the wide body's
+    const size_t lds = (size_t)2 * NP * (128 + 256) * WS_ROW_B + (size_t)8 * 256 * sizeof(float);       // the wide body's
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_igemm_ws_mix<PW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_igemm_ws_mix<PW, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
+    if (NP == 2 && !x_amax) return U2PL_EINVAL;
     const long xb = (((long)g.N * g.Hin * g.Win - 1) * ldx + g.Cin) * 4;
     const long yb = ((M - 1) * ldy + g.Cout) * 4;
-    const long wsb1 = (long)(K / 32) * 3 * Np * WS_ROW_B;
+    const long wsb1 = (long)(K / 32) * NP * Np * WS_ROW_B;
+    const unsigned* b_amax = (const unsigned*)((const char*)ws + (size_t)batch * wsb1);
     if (xb >= (1L << 31) || wsb1 >= (1L << 31) || yb >= (1L << 31)) return U2PL_EINVAL;
     const long resb = ep.res ? ((M - 1) * ep.ldr + g.Cout) * 4 : 0;
     if (resb >= (1L << 31)) return U2PL_EINVAL;
     const int mtiles = cdiv(M, 128), ntw = cdiv(g.Cout, 256);
     if ((long)mtiles * 2 * ntw * batch >= (1L << 30)) return U2PL_EINVAL;
-    U2PL_LAUNCH((k_igemm_ws_mix<PW>), dim3((unsigned)(WS_NUM_CUS + narrow_tiles)), dim3(512), lds, stream, x, ldx,
-                (const unsigned short*)ws, bias, y, ldy, g, (unsigned)xb, (unsigned)wsb1, (unsigned)yb, (unsigned)resb, Np, stats, pivot, zx,
+    U2PL_LAUNCH((k_igemm_ws_mix<PW, NP>), dim3((unsigned)(WS_NUM_CUS + narrow_tiles)), dim3(512), lds, stream, x, ldx, x_amax,
+                (const unsigned short*)ws, b_amax, bias, y, ldy, g, (unsigned)xb, (unsigned)wsb1, (unsigned)yb, (unsigned)resb, Np, stats, pivot, zx,
                 wsb1 / 2, zy, ep, mtiles, ntw, WS_NUM_CUS, (int)wide_tiles, (int)narrow_tiles);
     U2PL_LAUNCH_CHECK();
     return 0;
@@ -879,23 +1112,24 @@ U2PL_API int u2pl_igemm_ws_set_ablate(int v) { const int old = g_ws_abl; g_ws_ab
 
 // tile choice: 128 x 256 on 8 waves where Cout fills it, 128 x 128 (8 waves of 64 x 32) below; Cout <= 64 is not
 // served here (the callers keep those layers -- 1 % of the network's multiplies -- on k_conv_igemm)
-static int run_igemm_ws(const float* x, long ldx, const void* ws, const float* bias, float* y, long ldy, const ConvGeom& g,
-                        hipStream_t stream, float* stats = nullptr, const float* pivot = nullptr, int batch = 1,
-                        long zx = 0, long zy = 0, const BnEpi* epi = nullptr) {
+template <int NP>
+static int run_igemm_ws_np(const float* x, long ldx, const float* x_amax, const void* ws, const float* bias, float* y, long ldy,
+                           const ConvGeom& g, hipStream_t stream, float* stats, const float* pivot, int batch, long zx, long zy,
+                           const BnEpi* epi) {
     if (g.Cin % BK || !ws) return U2PL_EINVAL;
     if (epi && (stats || batch != 1 || (g.Cout & 3))) return U2PL_EINVAL;
     // pointwise: 1x1, stride 1, no padding, forward or data-gradient geometry alike
     const bool pw = g.R == 1 && g.S == 1 && g.mul == 1 && g.off_h == 0 && g.off_w == 0 && g.log2div == 0 &&
                     g.Hin == g.Hout && g.Win == g.Wout;
     auto go = [&](bool narrow, long first, long count) {
-        if (!narrow) return pw ? launch_igemm_ws<2, 2, 2, 4, true>(x, ldx, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi, first, count)
-                               : launch_igemm_ws<2, 2, 2, 4, false>(x, ldx, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi, first, count);
-        return pw ? launch_igemm_ws<2, 1, 2, 4, true>(x, ldx, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi, first, count)
-                  : launch_igemm_ws<2, 1, 2, 4, false>(x, ldx, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi, first, count);
+        if (!narrow) return pw ? launch_igemm_ws<2, 2, 2, 4, true, 0, NP>(x, ldx, x_amax, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi, first, count)
+                               : launch_igemm_ws<2, 2, 2, 4, false, 0, NP>(x, ldx, x_amax, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi, first, count);
+        return pw ? launch_igemm_ws<2, 1, 2, 4, true, 0, NP>(x, ldx, x_amax, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi, first, count)
+                  : launch_igemm_ws<2, 1, 2, 4, false, 0, NP>(x, ldx, x_amax, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi, first, count);
     };
 #ifdef U2PL_WS_ABLATE
     if (g_ws_abl && g.Cout > 128 && pw) {
-#define WS_ABL(A_) case A_: return launch_igemm_ws<2, 2, 2, 4, true, A_>(x, ldx, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi)
+#define WS_ABL(A_) case A_: return launch_igemm_ws<2, 2, 2, 4, true, A_, NP>(x, ldx, x_amax, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi)
         switch (g_ws_abl) { WS_ABL(1); WS_ABL(2); WS_ABL(4); WS_ABL(8); WS_ABL(16); WS_ABL(32); WS_ABL(7); WS_ABL(15); WS_ABL(31); WS_ABL(63); default: return U2PL_EINVAL; }
 #undef WS_ABL
     }
@@ -920,7 +1154,9 @@ static int run_igemm_ws(const float* x, long ldx, const void* ws, const float* b
     const long mt = cdiv(M_, 128), nkc = (long)(g.R * g.S * g.Cin) / BK;
     const long ntw = cdiv(g.Cout, 256), ntn = cdiv(g.Cout, 128);
     const long tw = mt * ntw * batch, tn = mt * ntn * batch;
-    const double cw1 = nkc + 4.0, cn1 = 0.5 * 1.15 * nkc + 2.0;
+    // (split-fp16: a chunk takes half the time, the fixed cost per tile -- prologue, stores -- does not)
+    const double fix = NP == 3 ? 1.0 : ws_fix2();
+    const double cw1 = nkc + 4.0 * fix, cn1 = 0.5 * 1.15 * nkc + 2.0 * fix;
     const double cw = (double)cdiv(tw, WS_NUM_CUS) * cw1, cn = (double)cdiv(tn, WS_NUM_CUS) * cn1;
     if (force == 0) return go(false, 0, -1);
     if (force == 1) return go(g.Cout <= 256, 0, -1);
@@ -928,11 +1164,11 @@ static int run_igemm_ws(const float* x, long ldx, const void* ws, const float* b
     const bool can_mix = force != 2 && ws_persist() && ntn == 2 * ntw && full > 0 && rem > 0 && 2 * rem <= WS_NUM_CUS;
     static int two_launch = -1;      // U2PL_WS_MIX2=1: the mixed plan as two launches (A/B of the one-launch form)
     if (two_launch < 0) { const char* e = getenv("U2PL_WS_MIX2"); two_launch = (e && *e) ? (atoi(e) != 0) : 0; }
-    const double cm = can_mix ? (double)(full / WS_NUM_CUS) * cw1 + cn1 + (two_launch ? 8.0 : 2.0) : 1e30;
+    const double cm = can_mix ? (double)(full / WS_NUM_CUS) * cw1 + cn1 + (two_launch ? 8.0 : 2.0) * fix : 1e30;
     if (cm < 0.97 * cw && cm < cn) {
         if (!two_launch)
-            return pw ? launch_igemm_ws_mix<true>(x, ldx, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi, full, 2 * rem)
-                      : launch_igemm_ws_mix<false>(x, ldx, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi, full, 2 * rem);
+            return pw ? launch_igemm_ws_mix<true, NP>(x, ldx, x_amax, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi, full, 2 * rem)
+                      : launch_igemm_ws_mix<false, NP>(x, ldx, x_amax, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi, full, 2 * rem);
         const int rc = go(false, 0, full);
         return rc ? rc : go(true, 2 * full, 2 * rem);
     }
@@ -940,6 +1176,15 @@ static int run_igemm_ws(const float* x, long ldx, const void* ws, const float* b
     // (Measured and dropped: the 128 x 256 tile on FOUR waves of 128 x 64 -- one wave per SIMD with 512 registers, 18 operand
     // reads per 48 matrix instructions instead of 12 per 24: bit-identical, 5-13 % slower on every wide-tile shape of
     // tools/bench_igemm_ws.py; the second wave of a SIMD does cover stalls of the first.)
+}
+
+// x_amax == NULL: the bf16 three-piece planes of u2pl_weight_split3_f32 (six products); x_amax != NULL: split-fp16 -- the planes
+// of u2pl_weight_split2h_f32 and the device scalar max |x| of the activation operand (three products)
+static int run_igemm_ws(const float* x, long ldx, const void* ws, const float* bias, float* y, long ldy, const ConvGeom& g,
+                        hipStream_t stream, float* stats = nullptr, const float* pivot = nullptr, int batch = 1,
+                        long zx = 0, long zy = 0, const BnEpi* epi = nullptr, const float* x_amax = nullptr) {
+    return x_amax ? run_igemm_ws_np<2>(x, ldx, x_amax, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi)
+                  : run_igemm_ws_np<3>(x, ldx, nullptr, ws, bias, y, ldy, g, stream, stats, pivot, batch, zx, zy, epi);
 }
 
 // ---- entry points: the conv.hip calls with the weight operand given as split planes (u2pl_weight_split3_f32 of the
@@ -986,4 +1231,51 @@ U2PL_API int u2pl_gemm_batched_ws_f32(const float* x, long ldx, long zx, const v
     if (M >= (1L << 31)) return U2PL_EINVAL;
     ConvGeom g = {1, (int)M, 1, K, (int)M, 1, Nn, 1, 1, 1, 0, 0, 1, 0};
     return run_igemm_ws(x, ldx, wsplit, nullptr, y, ldy, g, stream, nullptr, nullptr, batch, zx, zy);
+}
+
+// ---- split-fp16 entry points (round 6): the same calls with the planes of u2pl_weight_split2h_f32 and x_amax = the device scalar
+//      max |x| of the activation operand (u2pl_absmax_f32, or a producer's fused maximum; any upper bound within 2^8 of the true
+//      maximum keeps fp32-class accuracy, a bound BELOW the maximum overflows fp16)
+U2PL_API int u2pl_conv2d_fwd_wsh_f32(const float* x, long ldx, const float* x_amax, const void* wsplit, const float* bias, float* y, long ldy,
+                                     int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S,
+                                     int stride, int pad, int dil, hipStream_t stream) {
+    if (!x_amax) return U2PL_EINVAL;
+    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
+    return run_igemm_ws(x, ldx, wsplit, bias, y, ldy, g, stream, nullptr, nullptr, 1, 0, 0, nullptr, x_amax);
+}
+U2PL_API int u2pl_conv2d_fwd_bnstats_wsh_f32(const float* x, long ldx, const float* x_amax, const void* wsplit, const float* bias, float* y,
+                                             long ldy, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
+                                             int R, int S, int stride, int pad, int dil, const float* pivot,
+                                             float* stats_partial, hipStream_t stream) {
+    if (!x_amax) return U2PL_EINVAL;
+    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
+    return run_igemm_ws(x, ldx, wsplit, bias, y, ldy, g, stream, stats_partial, pivot, 1, 0, 0, nullptr, x_amax);
+}
+U2PL_API int u2pl_conv2d_fwd_bnact_wsh_f32(const float* x, long ldx, const float* x_amax, const void* wsplit, const float* bias, float* y,
+                                           long ldy, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R,
+                                           int S, int stride, int pad, int dil, const float* mean, const float* invstd,
+                                           const float* gamma, const float* beta, const float* res, long ldr, int relu,
+                                           hipStream_t stream) {
+    if (!x_amax || !mean || !invstd || !gamma || !beta || (Cout & 3) || (res && (ldr & 3))) return U2PL_EINVAL;
+    ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
+    const BnEpi epi = {mean, invstd, gamma, beta, res, ldr, relu};
+    return run_igemm_ws(x, ldx, wsplit, bias, y, ldy, g, stream, nullptr, nullptr, 1, 0, 0, &epi, x_amax);
+}
+U2PL_API int u2pl_conv2d_dgrad_wsh_f32(const float* dy, long lddy, const float* dy_amax, const void* wTsplit, float* dx, long lddx, int N,
+                                       int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S, int stride, int pad,
+                                       int dil, hipStream_t stream) {
+    if (!dy_amax) return U2PL_EINVAL;
+    int l2 = 0;
+    while ((1 << l2) < stride) ++l2;
+    if ((1 << l2) != stride) return U2PL_EINVAL;
+    ConvGeom g = {N, Hout, Wout, Cout, Hin, Win, Cin, R, S, 1, pad, pad, -dil, l2};
+    return run_igemm_ws(dy, lddy, wTsplit, nullptr, dx, lddx, g, stream, nullptr, nullptr, 1, 0, 0, nullptr, dy_amax);
+}
+U2PL_API int u2pl_gemm_batched_wsh_f32(const float* x, long ldx, long zx, const float* x_amax, const void* wsplit, float* y, long ldy,
+                                       long zy, long M, int K, int Nn, int batch, hipStream_t stream) {
+    if (!x_amax) return U2PL_EINVAL;
+    if (M <= 0 || batch <= 0) return 0;
+    if (M >= (1L << 31)) return U2PL_EINVAL;
+    ConvGeom g = {1, (int)M, 1, K, (int)M, 1, Nn, 1, 1, 1, 0, 0, 1, 0};
+    return run_igemm_ws(x, ldx, wsplit, nullptr, y, ldy, g, stream, nullptr, nullptr, batch, zx, zy, nullptr, x_amax);
 }

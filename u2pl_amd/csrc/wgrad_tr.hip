@@ -33,16 +33,27 @@ typedef short v4s16 __attribute__((ext_vector_type(4)));
 typedef short v8s16 __attribute__((ext_vector_type(8)));
 #define WT_LDS(p) ((__attribute__((address_space(3))) v4s16*)(p))
 
-template <int TN, bool PW>
+// NP: pieces per operand (igemm_ws.hip): 3 = bf16 pieces, six products; 2 = split-fp16 (conv_geom.h, round 6): both operands
+// scaled by the power of two derived from their device-scalar maxima dy_amax / x_amax, three products, the slab scaled back.
+template <int TN, bool PW, int NP = 3>
 __global__ __launch_bounds__(512, 2) void k_wgrad_tr(const float* __restrict__ dy, long lddy, const float* __restrict__ x,
                                                      long ldx, float* __restrict__ part, ConvGeom g, int ctiles,
                                                      int chunks_per_split, unsigned dybytes, unsigned xbytes, long zdy,
-                                                     long zx) {
+                                                     long zx, const float* __restrict__ dy_amax, const float* __restrict__ x_amax) {
     constexpr int TM = 2, WN = 4, BM = 128, BN = 32 * TN * WN, CH = BM + BN;
     constexpr int PITCH = CH * 2 + 64;                    // bytes per pixel row of one piece plane (see the bank note below)
-    constexpr int PL = BK * PITCH, ST = 3 * PL;           // piece plane / stage bytes
+    constexpr int PL = BK * PITCH, ST = NP * PL;          // piece plane / stage bytes
     constexpr int NLA = BM / 64, NLB = BN / 64, NLD = NLA + NLB;      // float4 loads per thread and chunk
-    constexpr int PER = TM * TN, NMF = 12 * PER, NRD = 3 * (TM + TN) * 2;   // per chunk and wave: matrix instr.; tr reads per k block
+    constexpr int NPROD = NP == 3 ? 6 : 3;
+    constexpr int PER = TM * TN, NMF = 2 * NPROD * PER, NRD = NP * (TM + TN) * 2;   // per chunk and wave: matrix instr.; tr reads per k block
+    int e_dy = 0, e_x = 0;
+    float s_dy = 1.f, s_x = 1.f;
+    if constexpr (NP == 2) {
+        e_dy = __builtin_amdgcn_readfirstlane(split2_exp_bits(__float_as_uint(ldg(dy_amax))));
+        e_x = __builtin_amdgcn_readfirstlane(split2_exp_bits(__float_as_uint(ldg(x_amax))));
+        s_dy = split2_scale(e_dy);
+        s_x = split2_scale(e_x);
+    }
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
     // Bank note: a wave's ds_read_b64_tr_b16 touches, per 32-lane half, two [4 px][16 ch] blocks = 4 rows x 64 bytes; with
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_tr(const float* __restrict__ d
         unsigned char* d = smem + stage * ST + st_off(i);
         *(uint2*)d = p0;
         *(uint2*)(d + PL) = p1;
-        *(uint2*)(d + 2 * PL) = p2;
+        if constexpr (NP == 3) *(uint2*)(d + 2 * PL) = p2;
     };
 
     f32x16 acc[TM][TN];
@@ -128,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_tr(const float* __restrict__ d
     const int li = lane & 31, lh = lane >> 5, lj = lane & 15, lblk = (lane >> 4) & 1;
     const int lbase = (8 * lh + (lj >> 2)) * PITCH + (16 * lblk + 4 * (lj & 3)) * 2;
     const int afr = lbase + (wm * 64) * 2, bfr = lbase + (BM + wn * 32 * TN) * 2;
-    struct Frag { v4s16 a[3][TM][2], b[3][TN][2]; };      // [piece][block][pixel half]
+    struct Frag { v4s16 a[NP][TM][2], b[NP][TN][2]; };    // [piece][block][pixel half]
     Frag f[2];
     // read J of a k block: product order (a2.., b0.., a1.., b1.., a0.., b2..), two halves each
     auto do_read = [&](auto stage_c, auto gk_c, auto j_c) __attribute__((always_inline)) {
@@ -137,28 +148,32 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_tr(const float* __restrict__ d
             constexpr int h = J & 1, F = J >> 1, qq = F / (TM + TN), w = F % (TM + TN);
             constexpr int rowoff = (16 * gk + 4 * h) * PITCH;
             if constexpr (w < TM)
-                f[gk].a[2 - qq][w][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(WT_LDS(smem + stage * ST + (2 - qq) * PL + rowoff + w * 64 + afr));
+                f[gk].a[NP - 1 - qq][w][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(WT_LDS(smem + stage * ST + (NP - 1 - qq) * PL + rowoff + w * 64 + afr));
             else
                 f[gk].b[qq][w - TM][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(WT_LDS(smem + stage * ST + qq * PL + rowoff + (w - TM) * 64 + bfr));
         }
     };
+    using frag_t = std::conditional_t<NP == 3, bf16x8, f16x8>;
     auto frag8 = [&](const v4s16 (&hh)[2]) __attribute__((always_inline)) {
         v8s16 v = __builtin_shufflevector(hh[0], hh[1], 0, 1, 2, 3, 4, 5, 6, 7);
-        return __builtin_bit_cast(bf16x8, v);
+        return __builtin_bit_cast(frag_t, v);
     };
     auto do_mfma = [&](auto i_c) __attribute__((always_inline)) {
         constexpr int I = decltype(i_c)::value;
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-        constexpr int gk = I / (6 * PER), qq = (I / PER) % 6, ab = I % PER, a = ab / TN, b = ab % TN;
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag8(f[gk].a[PA[qq]][a]), frag8(f[gk].b[PB[qq]][b]), acc[a][b], 0, 0, 0);
+        constexpr int QA[3] = {1, 0, 0}, QB[3] = {0, 1, 0};
+        constexpr int gk = I / (NPROD * PER), qq = (I / PER) % NPROD, ab = I % PER, a = ab / TN, b = ab % TN;
+        if constexpr (NP == 3) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag8(f[gk].a[PA[qq]][a]), frag8(f[gk].b[PB[qq]][b]), acc[a][b], 0, 0, 0);
+        else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag8(f[gk].a[QA[qq]][a]), frag8(f[gk].b[QB[qq]][b]), acc[a][b], 0, 0, 0);
     };
 
     // ---- prologue: chunk 0 into stage 0; chunks 1 (set 1) and 2 (set 0) in flight, in the loop's own issue order
     load_all(C0{});
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        uint2 p0, p1, p2;
-        split3_bf16(r[0][i], p0, p1, p2);
+        uint2 p0, p1, p2 = make_uint2(0, 0);
+        if constexpr (NP == 3) split3_bf16(r[0][i], p0, p1, p2);
+        else split2_f16(r[0][i], i < NLA ? s_dy : s_x, p0, p1);
         store_f4(0, i, p0, p1, p2);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -168,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_tr(const float* __restrict__ d
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < NP; ++p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -191,10 +206,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_tr(const float* __restrict__ d
         constexpr int TAIL = 2 * PER;
         constexpr int F0_PRE = 2 * (TM + TN), F0_PER = (NRD - F0_PRE + TAIL - 1) / TAIL;       // reads before slot 0; per tail slot
         constexpr int LD_SLOTS = (NLD + 1) / 2;                                               // two loads per slot
-        constexpr int SPP = (NMF - TAIL - LD_SLOTS) / (2 * NLD) >= 3 ? 3 : 2;                  // slots per value pair (3 steps)
-        constexpr int F1_START = TAIL, F1_PER = (NRD + 6 * PER - 1) / (6 * PER);               // all of them BEFORE k block 1's products
-        constexpr int SP_START = TAIL, SP_END = SP_START + SPP * 2 * NLD, LD_START = SP_END;
-        static_assert(F1_START + (NRD + F1_PER - 1) / F1_PER <= TAIL + 6 * PER, "k block 1 operands would be read after their first use");
+        // slots per value pair (NP steps): NP == 3: 3 or 2 behind the tail; NP == 2: from slot 0, 2 or 1
+        constexpr int SP_START = NP == 3 ? TAIL : 0;
+        constexpr int SPP = NP == 3 ? ((NMF - TAIL - LD_SLOTS) / (2 * NLD) >= 3 ? 3 : 2) : ((NMF - LD_SLOTS) / (2 * NLD) >= 2 ? 2 : 1);
+        constexpr int F1_START = TAIL, F1_PER = (NRD + NPROD * PER - 1) / (NPROD * PER);       // all of them BEFORE k block 1's products
+        constexpr int SP_END = SP_START + SPP * 2 * NLD, LD_START = SP_END;
+        static_assert(F1_START + (NRD + F1_PER - 1) / F1_PER <= TAIL + NPROD * PER, "k block 1 operands would be read after their first use");
         static_assert(LD_START + LD_SLOTS <= NMF, "split + loads do not fit the chunk");
         wt_static_for<0, F0_PRE>([&](auto j) __attribute__((always_inline)) { do_read(CUR{}, C0{}, j); });
         __builtin_amdgcn_sched_barrier(0);
@@ -207,21 +224,36 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_tr(const float* __restrict__ d
                 wt_static_for<0, F1_PER>([&](auto u) __attribute__((always_inline)) { do_read(CUR{}, C1{}, std::integral_constant<int, (sl - F1_START) * F1_PER + decltype(u)::value>{}); });
             if constexpr (sl >= SP_START && sl < SP_END) {
                 constexpr int k = (sl - SP_START) / SPP, s_in = (sl - SP_START) % SPP;     // value pair k (float4 k / 2), slot in pair
-                constexpr int st0 = SPP == 3 ? s_in : (s_in == 0 ? 0 : 2), st1 = SPP == 3 ? s_in : (s_in == 0 ? 1 : 2);
+                constexpr int st0 = NP == 3 ? (SPP == 3 ? s_in : (s_in == 0 ? 0 : 2)) : (SPP == 2 ? s_in : 0);
+                constexpr int st1 = NP == 3 ? (SPP == 3 ? s_in : (s_in == 0 ? 1 : 2)) : (SPP == 2 ? s_in : 1);
                 wt_static_for<st0, st1 + 1>([&](auto step_c) __attribute__((always_inline)) {
                     constexpr int step = decltype(step_c)::value;
                     if constexpr (step == 0) {
                         const float4 v = r[nxt][k >> 1];
                         sp_l = (k & 1) ? v.z : v.x;
                         sp_h = (k & 1) ? v.w : v.y;
+                        if constexpr (NP == 2) {
+                            const float sc = (k >> 1) < NLA ? s_dy : s_x;
+                            sp_l *= sc;
+                            sp_h *= sc;
+                        }
                     }
-                    const unsigned w = step == 0 ? pack2_bf16_first(sp_l, sp_h) : pack2_bf16(sp_l, sp_h);
-                    if constexpr (step < 2) {
-                        sp_l = sp_l - bf16_lo_f(w);
-                        sp_h = sp_h - bf16_hi_f(w);
+                    unsigned w;
+                    if constexpr (NP == 2) {
+                        w = pack2_f16(sp_l, sp_h);
+                        if constexpr (step == 0) {
+                            sp_l = sp_l - f16_lo_f(w);
+                            sp_h = sp_h - f16_hi_f(w);
+                        }
+                    } else {
+                        w = step == 0 ? pack2_bf16_first(sp_l, sp_h) : pack2_bf16(sp_l, sp_h);
+                        if constexpr (step < 2) {
+                            sp_l = sp_l - bf16_lo_f(w);
+                            sp_h = sp_h - bf16_hi_f(w);
+                        }
                     }
                     if constexpr (k & 1) pc[step].y = w; else pc[step].x = w;
-                    if constexpr ((k & 1) && step == 2) store_f4(nxt, k >> 1, pc[0], pc[1], pc[2]);
+                    if constexpr ((k & 1) && step == NP - 1) store_f4(nxt, k >> 1, pc[0], pc[1], pc[NP - 1]);
                 });
             }
             if constexpr (sl == LD_START - 1) row_offsets(n_dyo, n_xo);          // address arithmetic one slot ahead of the loads
@@ -258,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_tr(const float* __restrict__ d
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = co0 + wm * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (co < g.Cout) out[(long)co * rowlen + (long)tap * g.Cin + ci] = acc[a][b][e];
+                if (co < g.Cout) out[(long)co * rowlen + (long)tap * g.Cin + ci] = NP == 2 ? __builtin_ldexpf(acc[a][b][e], -(e_dy + e_x)) : acc[a][b][e];
             }
         }
 }
@@ -300,33 +332,41 @@ void wgrad_tr_plan(const ConvGeom& g, int taps, int& ctiles, int& nsplit, int& c
     nsplit = (int)((nchunks + cps - 1) / cps);
 }
 
-template <int TN, bool PW>
+template <int TN, bool PW, int NP>
 static int launch1(const float* dy, long lddy, const float* x, long ldx, float* part, const ConvGeom& g, int ctiles, int nsplit,
-                   int cps, int taps, hipStream_t stream, long zdy, long zx) {
+                   int cps, int taps, hipStream_t stream, long zdy, long zx, const float* dy_amax, const float* x_amax) {
     constexpr int CH = 128 + 128 * TN, PITCH = CH * 2 + 64;
-    const size_t lds = (size_t)2 * 3 * BK * PITCH;
+    const size_t lds = (size_t)2 * NP * BK * PITCH;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_wgrad_tr<TN, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_wgrad_tr<TN, PW, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const long dyb = (((long)g.N * g.Hout * g.Wout - 1) * lddy + g.Cout) * 4;
     const long xb = (((long)g.N * g.Hin * g.Win - 1) * ldx + g.Cin) * 4;
     if (dyb >= (1L << 31) || xb >= (1L << 31)) return U2PL_EINVAL;
     dim3 grid((unsigned)(ctiles * taps), (unsigned)cdiv(g.Cout, 128), (unsigned)nsplit);
-    U2PL_LAUNCH((k_wgrad_tr<TN, PW>), grid, dim3(512), lds, stream, dy, lddy, x, ldx, part, g, ctiles, cps, (unsigned)dyb,
-                (unsigned)xb, zdy, zx);
+    U2PL_LAUNCH((k_wgrad_tr<TN, PW, NP>), grid, dim3(512), lds, stream, dy, lddy, x, ldx, part, g, ctiles, cps, (unsigned)dyb,
+                (unsigned)xb, zdy, zx, dy_amax, x_amax);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
-int launch_wgrad_tr(const float* dy, long lddy, const float* x, long ldx, float* part, const ConvGeom& g, int ctiles, int nsplit,
-                    int cps, hipStream_t stream, long zdy, long zx) {
+template <int NP>
+static int launch_np(const float* dy, long lddy, const float* x, long ldx, float* part, const ConvGeom& g, int ctiles, int nsplit,
+                     int cps, hipStream_t stream, long zdy, long zx, const float* dy_amax, const float* x_amax) {
     const int taps = g.R * g.S;
     // pointwise: identity gather (1x1 stride 1 without padding; the Winograd component batches pass step = 0, offsets 0)
     const bool pw = g.mul == 1 && g.off_h == 0 && g.off_w == 0 && g.Hin == g.Hout && g.Win == g.Wout && (g.step == 0 || taps == 1);
     if (wt_bn(g) == 256)
-        return pw ? launch1<2, true>(dy, lddy, x, ldx, part, g, ctiles, nsplit, cps, taps, stream, zdy, zx)
-                  : launch1<2, false>(dy, lddy, x, ldx, part, g, ctiles, nsplit, cps, taps, stream, zdy, zx);
-    return pw ? launch1<1, true>(dy, lddy, x, ldx, part, g, ctiles, nsplit, cps, taps, stream, zdy, zx)
-              : launch1<1, false>(dy, lddy, x, ldx, part, g, ctiles, nsplit, cps, taps, stream, zdy, zx);
+        return pw ? launch1<2, true, NP>(dy, lddy, x, ldx, part, g, ctiles, nsplit, cps, taps, stream, zdy, zx, dy_amax, x_amax)
+                  : launch1<2, false, NP>(dy, lddy, x, ldx, part, g, ctiles, nsplit, cps, taps, stream, zdy, zx, dy_amax, x_amax);
+    return pw ? launch1<1, true, NP>(dy, lddy, x, ldx, part, g, ctiles, nsplit, cps, taps, stream, zdy, zx, dy_amax, x_amax)
+              : launch1<1, false, NP>(dy, lddy, x, ldx, part, g, ctiles, nsplit, cps, taps, stream, zdy, zx, dy_amax, x_amax);
+}
+// dy_amax / x_amax both NULL: the six-product bf16 form; both given: split-fp16 (three products)
+int launch_wgrad_tr(const float* dy, long lddy, const float* x, long ldx, float* part, const ConvGeom& g, int ctiles, int nsplit,
+                    int cps, hipStream_t stream, long zdy, long zx, const float* dy_amax, const float* x_amax) {
+    if ((dy_amax == nullptr) != (x_amax == nullptr)) return U2PL_EINVAL;
+    return dy_amax ? launch_np<2>(dy, lddy, x, ldx, part, g, ctiles, nsplit, cps, stream, zdy, zx, dy_amax, x_amax)
+                   : launch_np<3>(dy, lddy, x, ldx, part, g, ctiles, nsplit, cps, stream, zdy, zx, nullptr, nullptr);
 }

@@ -311,15 +311,33 @@ int u2pl_gemm_batched_ws_f32(const float* x, long ldx, long zx, const void* wspl
  * pieces (x s = h0 + h1 to 2^-25 |x s|) and multiplied as a1 b0 + a0 b1 + a0 b0 with fp32 accumulation; the accumulators are
  * scaled back with ldexp.  Replaces the same reference lines as the *_ws_* family above (u2pl/models/resnet.py:120-140,
  * base.py:54-100, decoder.py:60-142 forward; loss.backward() train_semi.py:527).
- *   u2pl_absmax_f32: *out <- max |x| over [M][C] (C % 4 == 0, ld % 4 == 0; NaN if any element is NaN): the x_amax of the calls
- *     below.  Any upper bound within ~2^8 of the true maximum keeps fp32-class accuracy; a value BELOW the maximum overflows.
+ *   "amax object": u2pl_amax_words() (= 2048) device floats, ZEROED by the caller before its producer runs -- 64 shards, one per
+ *     128-byte line (same-line atomics serialise; tools/micro/atomic_shard.hip); the tensor's maximum is the maximum over the
+ *     shards (bit patterns of |x|: NaN if any element is NaN).  Every x_amax / dy_amax / *_amax argument below is one.
+ *   u2pl_absmax_f32: out <- max |x| over [M][C] (C % 4 == 0, ld % 4 == 0); clear != 0 zeroes the object first.  Any upper bound
+ *     within ~2^8 of the true maximum keeps fp32-class accuracy; a value BELOW the maximum overflows fp16.
  *   u2pl_weight_split2h_*: planes [K/32][2][Np][32] fp16 + one uint32 per matrix (bit pattern of its max |w|) behind them.
  *     job_scratch: 48 device bytes (the job record of the one-weight call).  The multi call takes the SplitJob table of
  *     u2pl_weight_split3_multi_f32 with out = u2pl_weight_split2h_bytes buffers. */
 size_t u2pl_weight_split2h_bytes(int rows, int K, int batch);
 int u2pl_weight_split2h_f32(const float* w, long zw, int rows, int K, int batch, void* out, void* job_scratch, hipStream_t stream);
 int u2pl_weight_split2h_multi_f32(const void* jobs, int njobs, long total, hipStream_t stream);
-int u2pl_absmax_f32(const float* x, long ld, long M, int C, float* out, hipStream_t stream);
+int u2pl_amax_words(void);
+int u2pl_absmax_f32(const float* x, long ld, long M, int C, float* out, int clear, hipStream_t stream);
+/* producers that leave the maximum of what they write (fused: no extra pass): the entry points of the same name without
+ * `_amax` plus caller-ZEROED device floats that receive max |output| (bit-pattern atomicMax: deterministic; NULL = not wanted).
+ * Reference lines as for the plain forms (BatchNorm base.py:6-8 forward / backward; Winograd transforms of resnet.py:25-41). */
+int u2pl_bn_apply_amax_f32(const float* x, long ldx, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           const float* res, long ldr, int relu, const float* drop, long rows_per_image, float* y, long ldy, long M,
+                           int C, float* y_amax, hipStream_t stream);
+int u2pl_bn_bwd_apply_amax_f32(const float* dy, long lddy, const float* x, long ldx, const float* y, long ldy, const float* mean,
+                               const float* invstd, const float* gamma, const float* drop, long rows_per_image, const double* sums,
+                               double count, float* dx, long lddx, float* dres, long lddr, long M, int C, const double* psums,
+                               float* gsink, float* bsink, int accumulate, float* dx_amax, float* dres_amax, hipStream_t stream);
+int u2pl_wino_input_amax_f32(const float* x, long ldx, int N, int H, int W, int C, int dil, int mt, float* V, float* v_amax,
+                             hipStream_t stream);
+int u2pl_wino_gy_amax_f32(const float* gy, long ldg, int N, int H, int W, int O, int dil, int mt, float* Mg, float* mg_amax,
+                          hipStream_t stream);
 int u2pl_conv2d_fwd_wsh_f32(const float* x, long ldx, const float* x_amax, const void* wsplit, const float* bias, float* y, long ldy,
                             int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S, int stride, int pad,
                             int dil, hipStream_t stream);

@@ -55,7 +55,7 @@ def main():
     for kind, N, H, Cin, Cout, k, dil, stride in SHAPES:
         pad = dil * (k // 2)
         Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
-        amax = torch.zeros(1, device=DEV)
+        amax = torch.zeros(2048, device=DEV)
         ref = None
         if kind == "gemm":
             tiles = query("u2pl_wino_tiles", N, H, H, dil, 4)
@@ -66,7 +66,7 @@ def main():
             wsb = torch.empty(query("u2pl_weight_split3_bytes", Nn, K, batch), dtype=torch.uint8, device=DEV)
             call("u2pl_weight_split3_f32", w, Nn * K, Nn, K, batch, wsb)
             wsh = split2h(w, Nn, K, batch)
-            call("u2pl_absmax_f32", x, K, batch * M, K, amax)
+            call("u2pl_absmax_f32", x, K, batch * M, K, amax, 1)
             flops = 2.0 * M * K * Nn * batch
             old = lambda y: call("u2pl_gemm_batched_ws_f32", x, K, M * K, wsb, y, Nn, M * Nn, M, K, Nn, batch)          # noqa: E731
             new = lambda y: call("u2pl_gemm_batched_wsh_f32", x, K, M * K, amax, wsh, y, Nn, M * Nn, M, K, Nn, batch)   # noqa: E731
@@ -79,7 +79,7 @@ def main():
             wsb = torch.empty(query("u2pl_weight_split3_bytes", Cout, k * k * Cin, 1), dtype=torch.uint8, device=DEV)
             call("u2pl_weight_split3_f32", w, 0, Cout, k * k * Cin, 1, wsb)
             wsh = split2h(w, Cout, k * k * Cin, 1)
-            call("u2pl_absmax_f32", x, Cin, N * H * H, Cin, amax)
+            call("u2pl_absmax_f32", x, Cin, N * H * H, Cin, amax, 1)
             flops = 2.0 * N * Ho * Ho * Cout * k * k * Cin
             g = (N, H, H, Cin, Ho, Ho, Cout, k, k, stride, pad, dil)
             old = lambda y: call("u2pl_conv2d_fwd_ws_f32", x, Cin, wsb, None, y, Cout, *g)            # noqa: E731
@@ -93,7 +93,7 @@ def main():
             wsb = torch.empty(query("u2pl_weight_split3_bytes", Cin, k * k * Cout, 1), dtype=torch.uint8, device=DEV)
             call("u2pl_weight_split3_f32", wT, 0, Cin, k * k * Cout, 1, wsb)
             wsh = split2h(wT, Cin, k * k * Cout, 1)
-            call("u2pl_absmax_f32", dy, Cout, N * Ho * Ho, Cout, amax)
+            call("u2pl_absmax_f32", dy, Cout, N * Ho * Ho, Cout, amax, 1)
             flops = 2.0 * N * H * H * Cin * k * k * Cout
             g = (N, H, H, Cin, Ho, Ho, Cout, k, k, stride, pad, dil)
             old = lambda y: call("u2pl_conv2d_dgrad_ws_f32", dy, Cout, wsb, y, Cin, *g)               # noqa: E731

@@ -29,7 +29,7 @@ tot = {"b6": 0.0, "h3": 0.0}
 for kind, N, H, Cin, Cout, k, dil in SHAPES:
     torch.manual_seed(1)
     pad = dil * (k // 2)
-    a_dy, a_x = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    a_dy, a_x = torch.zeros(2048, device=DEV), torch.zeros(2048, device=DEV)
     ref = None
     if kind == "conv":
         M = N * H * H
@@ -39,8 +39,8 @@ for kind, N, H, Cin, Cout, k, dil in SHAPES:
         g = (N, H, H, Cin, H, H, Cout, k, k, 1, pad, dil)
         ws = torch.empty(query("u2pl_conv2d_wgrad_workspace_bytes", N, H, H, Cin, Cout, k, k), dtype=torch.uint8, device=DEV)
         outs = {"b6": torch.empty(Cout * k * k * Cin, device=DEV), "h3": torch.empty(Cout * k * k * Cin, device=DEV)}
-        call("u2pl_absmax_f32", dy, Cout, M, Cout, a_dy)
-        call("u2pl_absmax_f32", x, Cin, M, Cin, a_x)
+        call("u2pl_absmax_f32", dy, Cout, M, Cout, a_dy, 1)
+        call("u2pl_absmax_f32", x, Cin, M, Cin, a_x, 1)
         fns = {"b6": lambda: call("u2pl_conv2d_wgrad_f32", dy, Cout, x, Cin, outs["b6"], ws, 0, *g),
                "h3": lambda: call("u2pl_conv2d_wgrad_h_f32", dy, Cout, a_dy, x, Cin, a_x, outs["h3"], ws, 0, *g)}
         if k == 1:
@@ -54,8 +54,8 @@ for kind, N, H, Cin, Cout, k, dil in SHAPES:
         flops = 2.0 * M * Cout * Cin * batch
         ns = query("u2pl_wgrad_batched_splits", M, Cin, Cout, batch)
         outs = {"b6": torch.empty(ns * Cout * batch * Cin, device=DEV), "h3": torch.empty(ns * Cout * batch * Cin, device=DEV)}
-        call("u2pl_absmax_f32", dy, Cout, batch * M, Cout, a_dy)
-        call("u2pl_absmax_f32", x, Cin, batch * M, Cin, a_x)
+        call("u2pl_absmax_f32", dy, Cout, batch * M, Cout, a_dy, 1)
+        call("u2pl_absmax_f32", x, Cin, batch * M, Cin, a_x, 1)
         fns = {"b6": lambda: call("u2pl_wgrad_batched_f32", dy, Cout, M * Cout, x, Cin, M * Cin, outs["b6"], M, Cin, Cout, batch),
                "h3": lambda: call("u2pl_wgrad_batched_h_f32", dy, Cout, M * Cout, a_dy, x, Cin, M * Cin, a_x, outs["h3"], M, Cin, Cout, batch)}
         z = 7

@@ -101,6 +101,45 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- fused operand maxima (split-fp16 GEMMs, conv_geom.h) ---------------------------------------------------------------
+// A producer of a GEMM operand leaves max |x| of what it wrote in an "amax object" the caller zeroed: U2PL_AMAX_WORDS uint32 =
+// 64 shards, one per 128-byte line; the tensor's maximum is the maximum over the shards.  Per thread a running integer maximum of
+// the bit patterns of |x| (order-preserving for non-negative floats; a NaN's pattern is above every finite one, so a NaN anywhere
+// makes the maximum NaN), per wave ONE fire-and-forget atomicMax on the shard (global wave index) % 64.  Why shards: same-LINE
+// atomics serialise at ~88 / us (tools/micro/atomic_shard.hip: 16384 waves on one word 189 us, on 64 lines 6.6 us; a relaxed
+// pre-read of the slot to skip redundant atomics costs more than it saves: the reads queue on the same line).
+// Every lane of the wave must call amax_wave_publish; a consumer reads the object with amax_read (one load per lane).
+#define U2PL_AMAX_SHARDS 64
+#define U2PL_AMAX_STRIDE 32                                   // words between shards
+#define U2PL_AMAX_WORDS (U2PL_AMAX_SHARDS * U2PL_AMAX_STRIDE)
+__device__ __forceinline__ unsigned amax_bits(unsigned m, float v) {
+    const unsigned b = __float_as_uint(v) & 0x7fffffffu;
+    return b > m ? b : m;
+}
+__device__ __forceinline__ unsigned amax_bits4(unsigned m, float4 v) {
+    return amax_bits(amax_bits(amax_bits(amax_bits(m, v.x), v.y), v.z), v.w);
+}
+__device__ __forceinline__ unsigned wave_max_u(unsigned m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)m, o, 64);
+        m = t > m ? t : m;
+    }
+    return m;
+}
+__device__ __forceinline__ void amax_wave_publish(unsigned m, unsigned* __restrict__ obj) {
+    m = wave_max_u(m);
+    if ((threadIdx.x & 63) == 0 && m != 0u) {
+        const unsigned wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        atomicMax(obj + (wave & (U2PL_AMAX_SHARDS - 1)) * U2PL_AMAX_STRIDE, m);
+    }
+}
+// the object's maximum as a wave-uniform bit pattern (all 64 lanes of the calling wave participate)
+__device__ __forceinline__ unsigned amax_read(const unsigned* __restrict__ obj) {
+    const unsigned v = *(const __attribute__((address_space(1))) unsigned*)(obj + (threadIdx.x & 63) * U2PL_AMAX_STRIDE);
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)wave_max_u(v));
+}
+
 // Same-address device atomics serialise at ~88/us (MI355X_MICROARCH "dequeue"): counters are reduced
 // per BLOCK (LDS) and flushed with ONE global atomic per block; kernels that use this cap their grid at
 // a few hundred blocks.

@@ -153,27 +153,6 @@ U2PL_API int u2pl_weight_split3_f32(const float* w, long zw, int rows, int K, in
 // it with split2_exp_bits, exactly as the split did).  Two launches per rebuild: the maxima (atomicMax on the bit patterns of
 // |w|: order-independent, deterministic), then the pieces.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned absmax8_bits(float4 a, float4 b) {
-    const float m = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
-                          fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
-    // (fmaxf drops NaNs: a NaN weight must not hide -- OR the NaN test in: the bit pattern of a NaN is above every finite one)
-    const bool nan = (a.x != a.x) | (a.y != a.y) | (a.z != a.z) | (a.w != a.w) | (b.x != b.x) | (b.y != b.y) | (b.z != b.z) | (b.w != b.w);
-    return nan ? 0x7fc00000u : __float_as_uint(m);
-}
-// wave-level: one atomic per wave where all lanes target the same slot (the common case), one per lane otherwise
-__device__ __forceinline__ void amax_publish(unsigned bits, unsigned* slot, bool active) {
-    const unsigned long long key = active ? (unsigned long long)slot : 0ull;
-    const unsigned long long first = __builtin_amdgcn_readfirstlane((unsigned)key) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(key >> 32)) << 32);
-    if (__all(key == first)) {
-        if (!first) return;
-        unsigned m = bits;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
-        if ((threadIdx.x & 63) == 0) atomicMax(slot, m);
-    } else if (active) {
-        atomicMax(slot, bits);
-    }
-}
 __host__ __device__ static inline size_t ws2_plane_bytes(int Np, int K, int batch) { return (size_t)batch * (K / 32) * 2 * Np * WS_ROW_B; }
 __global__ void k_weight_amax_clear(const SplitJob* __restrict__ jobs, int njobs) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -182,37 +161,55 @@ __global__ void k_weight_amax_clear(const SplitJob* __restrict__ jobs, int njobs
     unsigned* slot = (unsigned*)((char*)j.out + ws2_plane_bytes(j.Np, j.K, j.batch));
     for (int z = 0; z < j.batch; ++z) slot[z] = 0u;
 }
-__global__ void k_weight_absmax_multi(const SplitJob* __restrict__ jobs, int njobs, long total) {
-    // (full trips for every lane: the wave-level publish uses cross-lane operations)
-    const long stride = (long)gridDim.x * blockDim.x;
-    const long trips = (total + stride - 1) / stride;
-    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    for (long t = 0; t < trips; ++t, i += stride) {
-        bool active = i < total;
-        unsigned bits = 0;
-        unsigned* slot = nullptr;
-        if (active) {
-            int lo = 0, hi = njobs - 1;
+// block b covers the contiguous segments [b * WS_AMAX_SPAN, (b + 1) * WS_AMAX_SPAN): a thread keeps a running maximum for the
+// matrix it is in and publishes when it crosses into another (rare) and at its end -- per wave one atomic where the lanes agree on
+// the matrix.  (One atomic per wave and segment-strided blocks: 590 K same-line atomics per rebuild, 27 ms -- measured.)
+#define WS_AMAX_SPAN 8192
+__global__ __launch_bounds__(256) void k_weight_absmax_multi(const SplitJob* __restrict__ jobs, int njobs, long total) {
+    const long begin = (long)blockIdx.x * WS_AMAX_SPAN, end = begin + WS_AMAX_SPAN < total ? begin + WS_AMAX_SPAN : total;
+    unsigned* slot = nullptr;
+    unsigned m = 0u;
+    int lo = 0;
+    SplitJob j = jobs[0];
+    bool have = false;
+    for (long i = begin + threadIdx.x; i < end; i += 256) {
+        if (!have || i < j.seg_begin || i >= j.seg_begin + (long)j.batch * j.Np * (j.K / 8)) {
+            lo = 0;
+            int hi = njobs - 1;
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
                 if (jobs[mid].seg_begin <= i) lo = mid; else hi = mid - 1;
             }
-            const SplitJob j = jobs[lo];
-            const int nseg = j.K / 8;
-            const long per = (long)j.Np * nseg;
-            long r = i - j.seg_begin;
-            const int z = (int)(r / per);
-            r -= (long)z * per;
-            slot = (unsigned*)((char*)j.out + ws2_plane_bytes(j.Np, j.K, j.batch)) + z;
-            // the maximum does not depend on the element order: read the source linearly (both kinds: rows * K floats per matrix)
-            const int n = (int)(r / nseg), sg = (int)(r % nseg);
-            active = n < j.rows;
-            if (active) {
-                const float4* src = (const float4*)(j.src + ((long)z * j.rows + n) * j.K + sg * 8);
-                bits = absmax8_bits(src[0], src[1]);
-            }
+            j = jobs[lo];
+            have = true;
         }
-        amax_publish(bits, slot, active);
+        const int nseg = j.K / 8;
+        const long per = (long)j.Np * nseg;
+        long r = i - j.seg_begin;
+        const int z = (int)(r / per);
+        r -= (long)z * per;
+        unsigned* sl = (unsigned*)((char*)j.out + ws2_plane_bytes(j.Np, j.K, j.batch)) + z;
+        if (sl != slot) {
+            if (slot && m) atomicMax(slot, m);
+            slot = sl;
+            m = 0u;
+        }
+        // the maximum does not depend on the element order: read the source linearly (both kinds: rows * K floats per matrix)
+        const int n = (int)(r / nseg), sg = (int)(r % nseg);
+        if (n < j.rows) {
+            const float4* src = (const float4*)(j.src + ((long)z * j.rows + n) * j.K + sg * 8);
+            m = amax_bits4(amax_bits4(m, src[0]), src[1]);
+        }
+    }
+    // (all lanes arrive here; lanes that never entered the loop hold slot == nullptr)
+    const unsigned long long key = (unsigned long long)slot;
+    const unsigned long long first = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)key) |
+                                     ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(key >> 32)) << 32);
+    if (__all(key == first)) {
+        m = wave_max_u(m);
+        if ((threadIdx.x & 63) == 0 && slot && m) atomicMax(slot, m);
+    } else if (slot && m) {
+        atomicMax(slot, m);
     }
 }
 __global__ void k_weight_split2h_multi(const SplitJob* __restrict__ jobs, int njobs, long total) {
@@ -275,7 +272,7 @@ U2PL_API int u2pl_weight_split2h_multi_f32(const void* jobs, int njobs, long tot
     if (njobs <= 0 || total <= 0) return njobs == 0 ? 0 : U2PL_EINVAL;
     U2PL_LAUNCH(k_weight_amax_clear, dim3(cdiv(njobs, 256)), dim3(256), 0, stream, (const SplitJob*)jobs, njobs);
     U2PL_LAUNCH_CHECK();
-    U2PL_LAUNCH(k_weight_absmax_multi, dim3(grid_for(total, 256, 4096)), dim3(256), 0, stream, (const SplitJob*)jobs, njobs, total);
+    U2PL_LAUNCH(k_weight_absmax_multi, dim3((unsigned)cdiv(total, WS_AMAX_SPAN)), dim3(256), 0, stream, (const SplitJob*)jobs, njobs, total);
     U2PL_LAUNCH_CHECK();
     U2PL_LAUNCH(k_weight_split2h_multi, dim3(grid_for(total, 256, 4096)), dim3(256), 0, stream, (const SplitJob*)jobs, njobs, total);
     U2PL_LAUNCH_CHECK();
@@ -292,32 +289,25 @@ U2PL_API int u2pl_weight_split2h_f32(const float* w, long zw, int rows, int K, i
     if (e != hipSuccess) return (int)e;
     return u2pl_weight_split2h_multi_f32(job_scratch, 1, total, stream);
 }
-// max |x| of an activation operand [M][C] (row pitch ld floats) -> *out (fp32; NaN if any element is NaN): out is cleared and
-// written by this call.  The A operand's scale of the *_wsh_* entry points.
+// max |x| of an activation operand [M][C] (row pitch ld floats) -> the amax object `out` (U2PL_AMAX_WORDS floats, common.h; NaN if
+// any element is NaN); clear != 0: zeroed here first.  The A operand's scale of the *_wsh_* entry points.
 __global__ void k_absmax_rows(const float* __restrict__ x, long ld, long M, int C4, unsigned* __restrict__ out) {
     const long total = M * C4;
     unsigned m = 0;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / C4;
         const int c = (int)(i - r * C4);
-        const float4 v = *(const float4*)(x + r * ld + c * 4);
-        const unsigned b = absmax8_bits(v, v);
-        m = b > m ? b : m;
+        m = amax_bits4(m, *(const float4*)(x + r * ld + c * 4));
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
-    __shared__ unsigned sm[16];
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = sm[w] > m ? sm[w] : m;
-        if (m) atomicMax(out, m);
-    }
+    amax_wave_publish(m, out);
 }
-U2PL_API int u2pl_absmax_f32(const float* x, long ld, long M, int C, float* out, hipStream_t stream) {
+U2PL_API int u2pl_amax_words(void) { return U2PL_AMAX_WORDS; }
+U2PL_API int u2pl_absmax_f32(const float* x, long ld, long M, int C, float* out, int clear, hipStream_t stream) {
     if (M < 0 || C <= 0 || (C & 3) || (ld & 3)) return U2PL_EINVAL;
-    hipError_t e = hipMemsetAsync(out, 0, 4, stream);
-    if (e != hipSuccess) return (int)e;
+    if (clear) {            // (clear == 0: the caller hands a zeroed slot -- one fill for a whole pool of them)
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)U2PL_AMAX_WORDS * 4, stream);
+        if (e != hipSuccess) return (int)e;
+    }
     if (M == 0) return 0;
     U2PL_LAUNCH(k_absmax_rows, dim3(grid_for(M * (C / 4), 512, 2048)), dim3(512), 0, stream, x, ld, M, C / 4, (unsigned*)out);
     U2PL_LAUNCH_CHECK();
@@ -395,7 +385,7 @@ __device__ __forceinline__ void igemm_ws_body(
     int ea = 0;
     float sa = 1.f;
     if constexpr (NP == 2) {
-        ea = __builtin_amdgcn_readfirstlane(split2_exp_bits(__float_as_uint(ldg(x_amax))));
+        ea = split2_exp_bits(amax_read((const unsigned*)x_amax));
         sa = split2_scale(ea);
     }
     // chunks per tile, made EVEN (an odd K / 32 gets one all-zero chunk: out-of-range offsets load zeros, the products add

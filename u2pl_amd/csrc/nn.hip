@@ -321,9 +321,10 @@ __global__ U2PL_HBM_KERNEL void k_bn_apply(const float* __restrict__ x, long ldx
                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                            const float* __restrict__ beta, const float* __restrict__ res, long ldr, int relu,
                            const float* __restrict__ drop, long rows_per_image, float* __restrict__ y, long ldy,
-                           long M, int C) {
+                           long M, int C, unsigned* __restrict__ y_amax) {
     const int C4 = C >> 2;
     const long total = M * C4;
+    unsigned am = 0u;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / C4;
         const int c = (int)(i % C4) * 4;
@@ -336,14 +337,26 @@ __global__ U2PL_HBM_KERNEL void k_bn_apply(const float* __restrict__ x, long ldx
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (drop) v = f4mul(v, *(const float4*)(drop + (r / rows_per_image) * C + c));
         *(float4*)(y + r * ldy + c) = v;
+        am = amax_bits4(am, v);
     }
+    if (y_amax) amax_wave_publish(am, y_amax);       // (uniform branch; split-fp16: the output is a GEMM operand)
 }
 U2PL_API int u2pl_bn_apply_f32(const float* x, long ldx, const float* mean, const float* invstd, const float* gamma,
                                const float* beta, const float* res, long ldr, int relu, const float* drop,
                                long rows_per_image, float* y, long ldy, long M, int C, hipStream_t stream) {
     if (C % 4) return U2PL_EINVAL;
     U2PL_LAUNCH(k_bn_apply, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, x, ldx, mean, invstd, gamma,
-                       beta, res, ldr, relu, drop, rows_per_image, y, ldy, M, C);
+                       beta, res, ldr, relu, drop, rows_per_image, y, ldy, M, C, (unsigned*)nullptr);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+// the same + max |y| into *y_amax (a device float the caller zeroed: the x_amax of the split-fp16 GEMMs that read y)
+U2PL_API int u2pl_bn_apply_amax_f32(const float* x, long ldx, const float* mean, const float* invstd, const float* gamma,
+                                    const float* beta, const float* res, long ldr, int relu, const float* drop,
+                                    long rows_per_image, float* y, long ldy, long M, int C, float* y_amax, hipStream_t stream) {
+    if (C % 4) return U2PL_EINVAL;
+    U2PL_LAUNCH(k_bn_apply, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, x, ldx, mean, invstd, gamma,
+                       beta, res, ldr, relu, drop, rows_per_image, y, ldy, M, C, (unsigned*)y_amax);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -356,7 +369,9 @@ __global__ U2PL_HBM_KERNEL void k_bn_bwd_apply(const float* __restrict__ dy, lon
                                const float* __restrict__ drop, long rows_per_image,
                                const double* __restrict__ sums, double count, float* __restrict__ dx, long lddx,
                                float* __restrict__ dres, long lddr, long M, int C, const double* __restrict__ psums,
-                               float* __restrict__ gsink, float* __restrict__ bsink, int accumulate) {
+                               float* __restrict__ gsink, float* __restrict__ bsink, int accumulate,
+                               unsigned* __restrict__ dx_amax, unsigned* __restrict__ dres_amax) {
+    unsigned am_x = 0u, am_r = 0u;
     if (psums) {   // (u2pl_bn_bwd_apply_pg_f32) the parameter gradients ride along: k_sums_to_f32's arithmetic, dgamma = S1, dbeta = S0
         for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < C; i += (long)gridDim.x * blockDim.x) {
             gsink[i] = (accumulate ? gsink[i] : 0.f) + (float)(psums[C + i] * (double)1.0f);
@@ -376,6 +391,7 @@ __global__ U2PL_HBM_KERNEL void k_bn_bwd_apply(const float* __restrict__ dy, lon
         }
         if (drop) g = f4mul(g, *(const float4*)(drop + (r / rows_per_image) * C + c));
         if (dres) *(float4*)(dres + r * lddr + c) = g;
+        am_r = amax_bits4(am_r, g);
         const float4 is = *(const float4*)(invstd + c), ga = *(const float4*)(gamma + c);
         float4 o;
         if (sums) {
@@ -392,7 +408,10 @@ __global__ U2PL_HBM_KERNEL void k_bn_bwd_apply(const float* __restrict__ dy, lon
             o = f4mul(f4mul(ga, is), g);
         }
         *(float4*)(dx + r * lddx + c) = o;
+        am_x = amax_bits4(am_x, o);
     }
+    if (dx_amax) amax_wave_publish(am_x, dx_amax);
+    if (dres_amax) amax_wave_publish(am_r, dres_amax);
 }
 U2PL_API int u2pl_bn_bwd_apply_f32(const float* dy, long lddy, const float* x, long ldx, const float* y, long ldy,
                                    const float* mean, const float* invstd, const float* gamma, const float* drop,
@@ -401,7 +420,7 @@ U2PL_API int u2pl_bn_bwd_apply_f32(const float* dy, long lddy, const float* x, l
     if (C % 4) return U2PL_EINVAL;
     U2PL_LAUNCH(k_bn_bwd_apply, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, dy, lddy, x, ldx, y, ldy,
                        mean, invstd, gamma, drop, rows_per_image, sums, count, dx, lddx, dres, lddr, M, C, (const double*)nullptr,
-                       (float*)nullptr, (float*)nullptr, 0);
+                       (float*)nullptr, (float*)nullptr, 0, (unsigned*)nullptr, (unsigned*)nullptr);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -415,7 +434,21 @@ U2PL_API int u2pl_bn_bwd_apply_pg_f32(const float* dy, long lddy, const float* x
     if (C % 4 || !psums || !gsink || !bsink) return U2PL_EINVAL;
     U2PL_LAUNCH(k_bn_bwd_apply, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, dy, lddy, x, ldx, y, ldy,
                        mean, invstd, gamma, drop, rows_per_image, sums, count, dx, lddx, dres, lddr, M, C, psums, gsink, bsink,
-                       accumulate);
+                       accumulate, (unsigned*)nullptr, (unsigned*)nullptr);
+    U2PL_LAUNCH_CHECK();
+    return 0;
+}
+// u2pl_bn_bwd_apply_f32 (psums == NULL) / u2pl_bn_bwd_apply_pg_f32 + max |dx| and max |dres| into the caller-zeroed device floats
+// dx_amax / dres_amax (either may be NULL): the dy_amax of the split-fp16 data- and weight-gradient GEMMs that read them
+U2PL_API int u2pl_bn_bwd_apply_amax_f32(const float* dy, long lddy, const float* x, long ldx, const float* y, long ldy,
+                                        const float* mean, const float* invstd, const float* gamma, const float* drop,
+                                        long rows_per_image, const double* sums, double count, float* dx, long lddx,
+                                        float* dres, long lddr, long M, int C, const double* psums, float* gsink, float* bsink,
+                                        int accumulate, float* dx_amax, float* dres_amax, hipStream_t stream) {
+    if (C % 4 || (psums && (!gsink || !bsink))) return U2PL_EINVAL;
+    U2PL_LAUNCH(k_bn_bwd_apply, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, dy, lddy, x, ldx, y, ldy,
+                       mean, invstd, gamma, drop, rows_per_image, sums, count, dx, lddx, dres, lddr, M, C, psums, gsink, bsink,
+                       accumulate, (unsigned*)dx_amax, (unsigned*)dres_amax);
     U2PL_LAUNCH_CHECK();
     return 0;
 }

@@ -49,8 +49,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_tr(const float* __restrict__ d
     int e_dy = 0, e_x = 0;
     float s_dy = 1.f, s_x = 1.f;
     if constexpr (NP == 2) {
-        e_dy = __builtin_amdgcn_readfirstlane(split2_exp_bits(__float_as_uint(ldg(dy_amax))));
-        e_x = __builtin_amdgcn_readfirstlane(split2_exp_bits(__float_as_uint(ldg(x_amax))));
+        e_dy = split2_exp_bits(amax_read((const unsigned*)dy_amax));
+        e_x = split2_exp_bits(amax_read((const unsigned*)x_amax));
         s_dy = split2_scale(e_dy);
         s_x = split2_scale(e_x);
     }

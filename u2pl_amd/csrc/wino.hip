@@ -125,11 +125,14 @@ __device__ __forceinline__ void tile_coords(const WinoGeom& g, long t, int& n, i
 // ---- input transform: one thread per (tile, 4 channels) ----------------------------------------------------
 template <int MT>
 __global__ __launch_bounds__(256) U2PL_HBM_KERNEL void k_wino_input(const float* __restrict__ x, long ldx, unsigned xbytes, WinoGeom g,
-                                                    float* __restrict__ V) {
+                                                    float* __restrict__ V, unsigned* __restrict__ v_amax) {
     constexpr int A = WinoT<MT>::A;
     const int C4 = g.C >> 2;
-    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (idx >= g.tiles * C4) return;
+    long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= g.tiles * C4) {
+        if (!v_amax) return;
+        idx = g.tiles * C4 - 1;      // (fused maximum: whole waves reach the publish; the surplus lanes redo the last element)
+    }
     const int c4 = (int)(idx % C4);
     const long t = idx / C4;
     int n, py, px, ty, tx;
@@ -163,13 +166,18 @@ __global__ __launch_bounds__(256) U2PL_HBM_KERNEL void k_wino_input(const float*
     // rows: V[i, :] = B^T (t[i, :])^T   (t B == (B^T t^T)^T)
     const long comp_stride = g.tiles * (long)g.C;
     float* out = V + t * g.C + c4 * 4;
+    unsigned am = 0u;
 #pragma unroll
     for (int i = 0; i < A; ++i) {
         float4 r[A];
         WinoT<MT>::bt(d[i], r);
 #pragma unroll
-        for (int j = 0; j < A; ++j) *(float4*)(out + (long)(i * A + j) * comp_stride) = r[j];
+        for (int j = 0; j < A; ++j) {
+            *(float4*)(out + (long)(i * A + j) * comp_stride) = r[j];
+            am = amax_bits4(am, r[j]);
+        }
     }
+    if (v_amax) amax_wave_publish(am, v_amax);       // split-fp16: V is the component GEMMs' A operand
 }
 
 // ---- weight transform: one thread per (o, c) ------------------------------------------------------------------
@@ -333,11 +341,14 @@ __global__ __launch_bounds__(256) U2PL_HBM_KERNEL void k_wino_output(const float
 // gy transform: one thread per (tile, 4 channels of dY): MT x MT output-gradient tile -> a x a components
 template <int MT>
 __global__ __launch_bounds__(256) U2PL_HBM_KERNEL void k_wino_gy(const float* __restrict__ gy, long ldg, unsigned gbytes, WinoGeom g,
-                                                 float* __restrict__ Mg) {
+                                                 float* __restrict__ Mg, unsigned* __restrict__ mg_amax) {
     constexpr int A = WinoT<MT>::A;
     const int C4 = g.C >> 2;
-    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (idx >= g.tiles * C4) return;
+    long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= g.tiles * C4) {
+        if (!mg_amax) return;
+        idx = g.tiles * C4 - 1;
+    }
     const int c4 = (int)(idx % C4);
     const long t = idx / C4;
     int n, py, px, ty, tx;
@@ -368,13 +379,18 @@ __global__ __launch_bounds__(256) U2PL_HBM_KERNEL void k_wino_gy(const float* __
     }
     const long comp_stride = g.tiles * (long)g.C;
     float* out = Mg + t * g.C + c4 * 4;
+    unsigned am = 0u;
 #pragma unroll
     for (int i = 0; i < A; ++i) {
         float4 r[A];
         WinoT<MT>::av(tmp[i], r);
 #pragma unroll
-        for (int j = 0; j < A; ++j) *(float4*)(out + (long)(i * A + j) * comp_stride) = r[j];
+        for (int j = 0; j < A; ++j) {
+            *(float4*)(out + (long)(i * A + j) * comp_stride) = r[j];
+            am = amax_bits4(am, r[j]);
+        }
     }
+    if (mg_amax) amax_wave_publish(am, mg_amax);
 }
 
 // part: [nsplit][O][a*a][C] partial slabs of the batched weight-gradient GEMMs -> dw [O][3][3][C]
@@ -459,18 +475,27 @@ U2PL_API int u2pl_wino_stat_blocks(long tiles, int O) {
     return (int)((tiles + tpb - 1) / tpb);
 }
 
-U2PL_API int u2pl_wino_input_f32(const float* x, long ldx, int N, int H, int W, int C, int dil, int mt, float* V,
-                                 hipStream_t stream) {
+// v_amax: NULL, or a caller-zeroed device float that receives max |V| (split-fp16: the x_amax of u2pl_gemm_batched_wsh_f32)
+static int run_wino_input(const float* x, long ldx, int N, int H, int W, int C, int dil, int mt, float* V, float* v_amax,
+                          hipStream_t stream) {
     WinoGeom g;
     if (wino_geom(N, H, W, C, dil, mt, g)) return U2PL_EINVAL;
     const long xb = (((long)N * H * W - 1) * ldx + C) * 4;
     if (xb >= (1L << 31)) return U2PL_EINVAL;
     const long total = g.tiles * (C / 4);
     const dim3 grid((unsigned)cdiv(total, 256)), block(256);
-    if (mt == 4) U2PL_LAUNCH(k_wino_input<4>, grid, block, 0, stream, x, ldx, (unsigned)xb, g, V);
-    else U2PL_LAUNCH(k_wino_input<2>, grid, block, 0, stream, x, ldx, (unsigned)xb, g, V);
+    if (mt == 4) U2PL_LAUNCH(k_wino_input<4>, grid, block, 0, stream, x, ldx, (unsigned)xb, g, V, (unsigned*)v_amax);
+    else U2PL_LAUNCH(k_wino_input<2>, grid, block, 0, stream, x, ldx, (unsigned)xb, g, V, (unsigned*)v_amax);
     U2PL_LAUNCH_CHECK();
     return 0;
+}
+U2PL_API int u2pl_wino_input_f32(const float* x, long ldx, int N, int H, int W, int C, int dil, int mt, float* V,
+                                 hipStream_t stream) {
+    return run_wino_input(x, ldx, N, H, W, C, dil, mt, V, nullptr, stream);
+}
+U2PL_API int u2pl_wino_input_amax_f32(const float* x, long ldx, int N, int H, int W, int C, int dil, int mt, float* V, float* v_amax,
+                                      hipStream_t stream) {
+    return run_wino_input(x, ldx, N, H, W, C, dil, mt, V, v_amax, stream);
 }
 
 // jobs: device array of njobs WinoWeightJob {w, U, begin, O, C, transposed, mt} (begin = prefix sum of O * C), total = sum of O * C
@@ -516,18 +541,26 @@ U2PL_API int u2pl_wino_output_bnact_f32(const float* Mb, int N, int H, int W, in
     return run_wino_output(Mb, N, H, W, O, dil, mt, bias, y, ldy, nullptr, nullptr, epi, stream);
 }
 
-U2PL_API int u2pl_wino_gy_f32(const float* gy, long ldg, int N, int H, int W, int O, int dil, int mt, float* Mg,
-                              hipStream_t stream) {
+static int run_wino_gy(const float* gy, long ldg, int N, int H, int W, int O, int dil, int mt, float* Mg, float* mg_amax,
+                       hipStream_t stream) {
     WinoGeom g;
     if (wino_geom(N, H, W, O, dil, mt, g)) return U2PL_EINVAL;
     const long gb = (((long)N * H * W - 1) * ldg + O) * 4;
     if (gb >= (1L << 31)) return U2PL_EINVAL;
     const long total = g.tiles * (O / 4);
     const dim3 grid((unsigned)cdiv(total, 256)), block(256);
-    if (mt == 4) U2PL_LAUNCH(k_wino_gy<4>, grid, block, 0, stream, gy, ldg, (unsigned)gb, g, Mg);
-    else U2PL_LAUNCH(k_wino_gy<2>, grid, block, 0, stream, gy, ldg, (unsigned)gb, g, Mg);
+    if (mt == 4) U2PL_LAUNCH(k_wino_gy<4>, grid, block, 0, stream, gy, ldg, (unsigned)gb, g, Mg, (unsigned*)mg_amax);
+    else U2PL_LAUNCH(k_wino_gy<2>, grid, block, 0, stream, gy, ldg, (unsigned)gb, g, Mg, (unsigned*)mg_amax);
     U2PL_LAUNCH_CHECK();
     return 0;
+}
+U2PL_API int u2pl_wino_gy_f32(const float* gy, long ldg, int N, int H, int W, int O, int dil, int mt, float* Mg,
+                              hipStream_t stream) {
+    return run_wino_gy(gy, ldg, N, H, W, O, dil, mt, Mg, nullptr, stream);
+}
+U2PL_API int u2pl_wino_gy_amax_f32(const float* gy, long ldg, int N, int H, int W, int O, int dil, int mt, float* Mg, float* mg_amax,
+                                   hipStream_t stream) {
+    return run_wino_gy(gy, ldg, N, H, W, O, dil, mt, Mg, mg_amax, stream);
 }
 
 U2PL_API int u2pl_wino_wgrad_finish_f32(const float* part, int nsplit, int O, int C, int mt, int accumulate, float* dw,

@@ -51,13 +51,17 @@ class _Capture:
 
     def __enter__(self):
         self.nbt0 = [m._nbt for m in self.bns]
-        self.ctx = torch.cuda.graph(self.graph, pool=self.pool)
+        # (thread_local: a DataLoader's pin-memory thread may call hipHostMalloc while the multi-hundred-ms capture of a whole
+        # pass is open; under the default "global" mode that invalidates the capture or raises in the loader thread -- ADVICE r5)
+        self.ctx = torch.cuda.graph(self.graph, pool=self.pool, capture_error_mode="thread_local")
         self.ctx.__enter__()
         _lib.CAPTURING[0] = True
+        K.amax_pool_reset()         # the segment zeroes its own operand-maximum slots inside the graph
         return self
 
     def __exit__(self, et, ev, tb):
         _lib.CAPTURING[0] = False
+        K.amax_pool_reset()         # eager code must not take slots from the graph's private pool
         try:
             self.ctx.__exit__(et, ev, tb)
         finally:
@@ -90,7 +94,7 @@ def _refresh_operands(ent, modules, owner):
 def _key(xs, modules):
     """what a captured segment is valid for: input shapes, train / eval mode, and the convolution algorithm switches (a graph
     recorded with Winograd kernels must not be replayed after U2PL_CONV_WINO / _BF16 / _SPLIT / _WS changed)"""
-    algo = tuple(sorted(K.CONV_ALGO.items())) + (K.CONV_WS["on"], _lib.query("u2pl_conv_get_split"), K.FUSE_EVAL_BN)
+    algo = tuple(sorted(K.CONV_ALGO.items())) + (K.CONV_WS["on"], K.CONV_H["on"], _lib.query("u2pl_conv_get_split"), K.FUSE_EVAL_BN)
     return tuple((tuple(x.shape), x.dtype, x.device.index) for x in xs) + tuple(m.training for m in modules) + algo
 
 

@@ -261,6 +261,62 @@ def _derived(weight, kind, nbytes, build):
     return ent["buf"]
 
 
+# ---- split-fp16 (round 6, csrc/conv_geom.h): the pre-split GEMMs with THREE fp16 piece products per fp32 product ------------------
+# Each operand is scaled per tensor by a power of two taken from its largest magnitude.  Weights: the split kernels compute the
+# maxima themselves.  Activations / gradients: the kernel that PRODUCES a GEMM operand (BatchNorm apply / backward apply, the
+# Winograd input and gradient transforms) leaves max |output| in a device scalar as it writes -- carried to the consumer as a
+# Python attribute of the tensor, valid for the tensor's version counter -- and any operand without a current maximum gets one
+# stand-alone pass (u2pl_absmax_f32).  U2PL_CONV_H=0: the six-product bf16 form of rounds 3-5 everywhere.
+CONV_H = {"on": os.environ.get("U2PL_CONV_H", "1") != "0"}
+AMAX_STATS = {"fused": 0, "standalone": 0}
+_AMAX_POOL = {}
+
+
+def amax_pool_reset():
+    """forget the current slot chunks (u2pl_amd.graphs calls this when a capture begins and ends: a captured segment must zero
+    the slots it uses inside the graph, eager code must not take slots from a graph's private pool)"""
+    _AMAX_POOL.clear()
+
+
+_AMAX_WORDS = [0]
+
+
+def amax_slot(dev):
+    """a zeroed "amax object" (include/u2pl_hip.h: u2pl_amax_words() floats, 64 shards on separate 128-byte lines); objects come
+    out of 128-object chunks zeroed by ONE fill on the stream that uses them (each object is written once; a chunk lives as long
+    as a tensor refers to one of its objects)"""
+    if not _AMAX_WORDS[0]:
+        _AMAX_WORDS[0] = query("u2pl_amax_words")
+    n = _AMAX_WORDS[0]
+    key = _lib.stream_ptr()
+    p = _AMAX_POOL.get(key)
+    if p is None or p[1] >= 128 or p[0].device != dev:
+        p = _AMAX_POOL[key] = [torch.zeros(128 * n, dtype=torch.float32, device=dev), 0]
+    s = p[0][p[1] * n:(p[1] + 1) * n]
+    p[1] += 1
+    return s
+
+
+def set_amax(t, slot):
+    t._u2pl_amax = (slot, t._version)
+    AMAX_STATS["fused"] += 1
+
+
+def amax_of(t, rows=None, ld=None):
+    """amax object holding max |t|: the producer's fused maximum when `t` carries a current one, else one pass over it"""
+    ent = getattr(t, "_u2pl_amax", None)
+    if ent is not None and ent[1] == t._version:
+        return ent[0]
+    if rows is None:
+        rows, ld = as_rows(t)
+    N, C, H, W = rows.shape
+    a = amax_slot(rows.device)
+    call("u2pl_absmax_f32", rows, ld, N * H * W, C, a, 0)
+    t._u2pl_amax = (a, t._version)
+    AMAX_STATS["standalone"] += 1
+    return a
+
+
 def _ws_ok(n_cols, k_depth):
     """can this GEMM (n_cols output channels, reduction depth k_depth) take the pre-split-weight kernel?"""
     # (config 5: the STUDENT's bf16-operand calls never ask -- their call sites test ctx.bf / use_bf first -- so the fp32 teacher
@@ -268,37 +324,43 @@ def _ws_ok(n_cols, k_depth):
     return CONV_WS["on"] and n_cols > 64 and k_depth % 32 == 0 and query("u2pl_conv_get_split") == 1
 
 
-def _split_of(weight, kind, rows, K, batch, src, spec):
+def _split_of(weight, kind, rows, K, batch, src, spec, h=None):
     """split planes of `batch` matrices [rows][K]; src() -> the fp32 source tensor (a temporary is fine); spec: how presplit()
-    rebuilds the same planes in its batched launches"""
-    nbytes = query("u2pl_weight_split3_bytes", rows, K, batch)
+    rebuilds the same planes in its batched launches.  h (default CONV_H): two fp16 piece planes + the matrices' maxima
+    (u2pl_weight_split2h_f32) instead of three bf16 ones; cached under its own kind."""
+    h = CONV_H["on"] if h is None else h
+    nbytes = query("u2pl_weight_split2h_bytes" if h else "u2pl_weight_split3_bytes", rows, K, batch)
 
     def build(buf):
         w = src()
-        call("u2pl_weight_split3_f32", w, rows * K, rows, K, batch, buf)
+        if h:
+            call("u2pl_weight_split2h_f32", w, rows * K, rows, K, batch, buf, torch.empty(64, dtype=torch.uint8, device=buf.device))
+        else:
+            call("u2pl_weight_split3_f32", w, rows * K, rows, K, batch, buf)
+    kind = kind + ("h" if h else "")
     buf = _derived(weight, kind, nbytes, build)
     ent = weight.__dict__["_u2pl_derived"][kind]
     if "spec" not in ent:
-        ent["spec"] = dict(spec, rows=rows, K=K, batch=batch)
+        ent["spec"] = dict(spec, rows=rows, K=K, batch=batch, h=bool(h))
     return buf
 
 
-def ws_forward(weight):
+def ws_forward(weight, h=None):
     Cout, Cin, R, S = weight.shape
-    return _split_of(weight, "f", Cout, R * S * Cin, 1, lambda: weight, dict(how="plain"))
+    return _split_of(weight, "f", Cout, R * S * Cin, 1, lambda: weight, dict(how="plain"), h)
 
 
-def ws_dgrad(weight):
+def ws_dgrad(weight, h=None):
     Cout, Cin, R, S = weight.shape
 
     def src():
         wT = torch.empty(Cin * R * S * Cout, dtype=torch.float32, device=weight.device)
         call("u2pl_weight_transpose_f32", weight, wT, Cout, R * S, Cin)
         return wT
-    return _split_of(weight, "d", Cin, R * S * Cout, 1, src, dict(how="transposed", RS=R * S))
+    return _split_of(weight, "d", Cin, R * S * Cout, 1, src, dict(how="transposed", RS=R * S), h)
 
 
-def ws_wino(weight, transposed, mt):
+def ws_wino(weight, transposed, mt, h=None):
     Cout, Cin = weight.shape[:2]
     a2 = (mt + 2) ** 2
     rows, K = (Cin, Cout) if transposed else (Cout, Cin)
@@ -308,7 +370,7 @@ def ws_wino(weight, transposed, mt):
         call("u2pl_wino_weight_f32", weight, Cout, Cin, int(transposed), mt, U)
         return U
     return _split_of(weight, ("wd" if transposed else "wf") + str(mt), rows, K, a2, src,
-                     dict(how="wino", transposed=int(transposed), mt=mt, O=Cout, C=Cin))
+                     dict(how="wino", transposed=int(transposed), mt=mt, O=Cout, C=Cin), h)
 
 
 # ---- all derived operands of a model rebuilt in two launches ----------------------------------------------------
@@ -339,7 +401,9 @@ def presplit(params, owner=None):
     cur = torch.cuda.current_stream()
     for st in {s_ for _, e, _ in todo for s_ in (list(e["readers"]) + [e["stream"]]) if s_ != cur}:
         cur.wait_stream(st)          # nobody reads the old planes any more, the previous build is complete
-    key = tuple((w.data_ptr(), e["buf"].data_ptr(), e["spec"]["how"]) for w, e, _ in todo)
+    todo.sort(key=lambda t_: bool(t_[1]["spec"].get("h")))           # the bf16-plane jobs first, then the fp16-plane ones
+    n_plain = sum(1 for _, e, _ in todo if not e["spec"].get("h"))
+    key = tuple((w.data_ptr(), e["buf"].data_ptr(), e["spec"]["how"], bool(e["spec"].get("h"))) for w, e, _ in todo)
     tab = PRESPLIT["tables"].get(id(owner))
     if tab is None or tab["key"] != key:
         dev = todo[0][0].device
@@ -360,20 +424,28 @@ def presplit(params, owner=None):
             sp = e["spec"]
             wj[i] = (w.data_ptr(), scratch.data_ptr() + 4 * u_off[id(e)], begin, sp["O"], sp["C"], sp["transposed"], sp["mt"])
             begin += sp["O"] * sp["C"]
-        seg = 0
+        seg, segs = 0, [0, 0]
         for i, (w, e, _) in enumerate(todo):
             sp = e["spec"]
+            if i == n_plain:
+                seg = 0                 # (the fp16-plane jobs form a table of their own: segment numbers restart)
             Np = query("u2pl_weight_split3_pad_rows", sp["rows"])
             src = scratch.data_ptr() + 4 * u_off[id(e)] if sp["how"] == "wino" else w.data_ptr()
             sj[i] = (src, e["buf"].data_ptr(), seg, sp["rows"], Np, sp["K"], 1 if sp["how"] == "transposed" else 0,
                      sp.get("RS", 1), sp["batch"])
             seg += sp["batch"] * Np * (sp["K"] // 8)
+            segs[int(i >= n_plain)] = seg
+        sj_dev = torch.from_numpy(sj.view(np.uint8).copy()).to(dev)
         tab = PRESPLIT["tables"][id(owner)] = dict(
-            key=key, scratch=scratch, n_split=len(todo), seg=seg, n_wino=len(wino), wino_total=begin,
-            sj=torch.from_numpy(sj.view(np.uint8).copy()).to(dev), wj=torch.from_numpy(wj.view(np.uint8).copy()).to(dev))
+            key=key, scratch=scratch, n_plain=n_plain, n_h=len(todo) - n_plain, seg=segs[0], seg_h=segs[1], n_wino=len(wino),
+            wino_total=begin, sj=sj_dev, sj_h=sj_dev[n_plain * sj.dtype.itemsize:],
+            wj=torch.from_numpy(wj.view(np.uint8).copy()).to(dev))
     if tab["n_wino"]:
         call("u2pl_wino_weight_multi_f32", tab["wj"], tab["n_wino"], tab["wino_total"])
-    call("u2pl_weight_split3_multi_f32", tab["sj"], tab["n_split"], tab["seg"])
+    if tab["n_plain"]:
+        call("u2pl_weight_split3_multi_f32", tab["sj"], tab["n_plain"], tab["seg"])
+    if tab["n_h"]:
+        call("u2pl_weight_split2h_multi_f32", tab["sj_h"], tab["n_h"], tab["seg_h"])
     ev = torch.cuda.Event()
     ev.record(cur)
     for w, e, stamp in todo:
@@ -401,12 +473,20 @@ def _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, mt, transposed,
     Ci, Co = (Cout, Cin) if transposed else (Cin, Cout)
     tiles = query("u2pl_wino_tiles", N, H, W, dil, mt)
     V = torch.empty(a2 * tiles * Ci, dtype=torch.float32, device=dev)
-    call("u2pl_wino_input_f32", x, ldx, N, H, W, Ci, dil, mt, V)
+    ws = _ws_ok(Co, Ci) and weight.is_leaf
     Mb = torch.empty(a2 * tiles * Co, dtype=torch.float32, device=dev)
-    if _ws_ok(Co, Ci) and weight.is_leaf:
-        call("u2pl_gemm_batched_ws_f32", V, Ci, tiles * Ci, ws_wino(weight, transposed, mt), Mb, Co, tiles * Co, tiles, Ci,
+    if ws and CONV_H["on"]:      # split-fp16: the transform leaves max |V| as it writes
+        v_amax = amax_slot(dev)
+        call("u2pl_wino_input_amax_f32", x, ldx, N, H, W, Ci, dil, mt, V, v_amax)
+        set_amax(V, v_amax)
+        call("u2pl_gemm_batched_wsh_f32", V, Ci, tiles * Ci, v_amax, ws_wino(weight, transposed, mt, True), Mb, Co, tiles * Co,
+             tiles, Ci, Co, a2)
+    elif ws:
+        call("u2pl_wino_input_f32", x, ldx, N, H, W, Ci, dil, mt, V)
+        call("u2pl_gemm_batched_ws_f32", V, Ci, tiles * Ci, ws_wino(weight, transposed, mt, False), Mb, Co, tiles * Co, tiles, Ci,
              Co, a2)
     else:
+        call("u2pl_wino_input_f32", x, ldx, N, H, W, Ci, dil, mt, V)
         U = torch.empty(a2 * Cout * Cin, dtype=torch.float32, device=dev)
         call("u2pl_wino_weight_f32", weight, Cout, Cin, int(transposed), mt, U)
         call("u2pl_gemm_batched_f32", V, Ci, tiles * Ci, U, Co * Ci, Mb, Co, tiles * Co, tiles, Ci, Co, a2)
@@ -427,6 +507,7 @@ class _ConvFn(torch.autograd.Function):
         """pivot (a BatchNorm running_mean) requests the fused train-mode BN statistics of the output:
         returns (y, partials) with partials = float32 [nblk][2][C] (S1, S2 pivot-shifted, per row block of the epilogue);
         finished_sums() / the BatchNorm's fused finish turn them into the double [2C] sums."""
+        x_in = x
         x, ldx = as_rows(x)
         N, Cin, H, W = x.shape
         Cout, _, R, S = weight.shape
@@ -438,6 +519,7 @@ class _ConvFn(torch.autograd.Function):
         # gradient for it in front of every backward call (116 fill launches per step, profiles/r05_bench_serial_kernel_stats.csv)
         ctx.set_materialize_grads(False)
         ctx.link = link
+        ctx.x_amax = ctx.col_amax = None        # split-fp16: maxima of the saved operands (device scalars), where the forward had them
         y = new_act(N, Cout, Ho, Wo, x.device)
         col = None
         # `recording`: grad mode at the call site (inside forward() it is always off); the teacher's calls run under no_grad
@@ -461,22 +543,33 @@ class _ConvFn(torch.autograd.Function):
             part, V = _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, mt, False, pivot)
             if ctx.needs_input_grad[1]:
                 col = V     # the transformed input is the weight gradient's operand: keep it instead of redoing it
+                ent = getattr(V, "_u2pl_amax", None)
+                ctx.col_amax = ent[0] if ent is not None else None
             if pivot is not None:
                 sums = part      # raw [nblk][2][Cout] partials: the BatchNorm finishes them (fused with its finalisation, round 5)
         elif pivot is not None and pivot is not False:
             ws = not use_bf and _ws_ok(Cout, R * S * Cin)
             nblk = query("u2pl_igemm_ws_stat_blocks", N, Ho, Wo) if ws else query("u2pl_conv2d_fwd_stat_blocks", N, Ho, Wo, Cout)
             part = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=x.device)
-            if ws:
-                call("u2pl_conv2d_fwd_bnstats_ws_f32", x, ldx, ws_forward(weight), bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout,
+            if ws and CONV_H["on"]:
+                ctx.x_amax = amax_of(x_in, x, ldx)
+                call("u2pl_conv2d_fwd_bnstats_wsh_f32", x, ldx, ctx.x_amax, ws_forward(weight, True), bias, y, Cout, N, H, W, Cin,
+                     Ho, Wo, Cout, R, S, stride, pad, dil, pivot, part)
+            elif ws:
+                call("u2pl_conv2d_fwd_bnstats_ws_f32", x, ldx, ws_forward(weight, False), bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout,
                      R, S, stride, pad, dil, pivot, part)
             else:
                 call("u2pl_conv2d_fwd_bnstats" + sfx, x, ldx, weight, bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S, stride,
                      pad, dil, pivot, part)
             sums = part          # raw partials, see above
         elif not use_bf and _ws_ok(Cout, R * S * Cin):
-            call("u2pl_conv2d_fwd_ws_f32", x, ldx, ws_forward(weight), bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S,
-                 stride, pad, dil)
+            if CONV_H["on"]:
+                ctx.x_amax = amax_of(x_in, x, ldx)
+                call("u2pl_conv2d_fwd_wsh_f32", x, ldx, ctx.x_amax, ws_forward(weight, True), bias, y, Cout, N, H, W, Cin, Ho, Wo,
+                     Cout, R, S, stride, pad, dil)
+            else:
+                call("u2pl_conv2d_fwd_ws_f32", x, ldx, ws_forward(weight, False), bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S,
+                     stride, pad, dil)
         else:
             call("u2pl_conv2d_fwd" + sfx, x, ldx, weight, bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil)
         ctx.save_for_backward(x, weight, col)
@@ -496,6 +589,7 @@ class _ConvFn(torch.autograd.Function):
             return (None,) * 11
         x, weight, col = ctx.saved_tensors
         N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ldx = ctx.geom
+        gy_in = gy          # (the tensor autograd handed over: it carries the producer's fused maximum, if any)
         gy, ldg = as_rows(gy)
         dev = gy.device
         M = N * Ho * Wo
@@ -535,12 +629,20 @@ class _ConvFn(torch.autograd.Function):
                 # through the forward kernel's eval-BatchNorm epilogue with identity parameters and the running sum as its
                 # `res`: dx = (gy . W) + prev in ONE pass instead of the GEMM + autograd's elementwise add over the 4x-wide
                 # block input (46 adds, 3.2 ms per step before round 5)
-                call("u2pl_conv2d_fwd_bnact_ws_f32", gy, ldg, ws_dgrad(weight), None, dx, Cin, N, H, W, Cout, H, W, Cin, 1, 1, 1, 0, 1,
-                     *epi)
+                if CONV_H["on"]:
+                    call("u2pl_conv2d_fwd_bnact_wsh_f32", gy, ldg, amax_of(gy_in, gy, ldg), ws_dgrad(weight, True), None, dx, Cin, N,
+                         H, W, Cout, H, W, Cin, 1, 1, 1, 0, 1, *epi)
+                else:
+                    call("u2pl_conv2d_fwd_bnact_ws_f32", gy, ldg, ws_dgrad(weight, False), None, dx, Cin, N, H, W, Cout, H, W, Cin, 1, 1,
+                         1, 0, 1, *epi)
                 included = True
             elif Cp == Cout and not ctx.bf and _ws_ok(Cin, R * S * Cout):
-                call("u2pl_conv2d_dgrad_ws_f32", gy, ldg, ws_dgrad(weight), dx, Cin, N, H, W, Cin, Ho, Wo, Cout, R, S, stride,
-                     pad, dil)
+                if CONV_H["on"]:
+                    call("u2pl_conv2d_dgrad_wsh_f32", gy, ldg, amax_of(gy_in, gy, ldg), ws_dgrad(weight, True), dx, Cin, N, H, W, Cin,
+                         Ho, Wo, Cout, R, S, stride, pad, dil)
+                else:
+                    call("u2pl_conv2d_dgrad_ws_f32", gy, ldg, ws_dgrad(weight, False), dx, Cin, N, H, W, Cin, Ho, Wo, Cout, R, S,
+                         stride, pad, dil)
             else:
                 wT = torch.empty(Cin * R * S * Cp, dtype=torch.float32, device=dev)
                 call("u2pl_weight_transpose_f32", weight_k, wT, Cp, R * S, Cin)
@@ -548,11 +650,19 @@ class _ConvFn(torch.autograd.Function):
                      Ho, Wo, Cp, R, S, stride, pad, dil)
             if join is not None:
                 dx = join.settle(dx, included)      # None unless this was the last consumer to report
+        # split-fp16 weight gradients (k_wgrad_tr only): the operands' maxima are taken on THIS stream, before the side stream forks
+        wg_h = (CONV_H["on"] and ctx.needs_input_grad[1] and Cp == Cout and not ctx.bf and Cin % 32 == 0
+                and query("u2pl_wgrad_h_eligible", Cin, Cout) == 1)
+        wg_wino = wg_h and bool(CONV_ALGO.get("wgrad", 1) and wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W))
+        gy_amax = x_amax = None
+        if wg_h and not wg_wino:
+            gy_amax = amax_of(gy_in, gy, ldg)
+            x_amax = ctx.x_amax if ctx.x_amax is not None else amax_of(x, x, ldx)
         side = _wgrad_stream() if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) else None
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
             _lib.SIDE_WORK.add("wgrad")
-            for t_ in (gy, x, col):
+            for t_ in (gy, x, col, gy_amax, x_amax, ctx.col_amax):
                 if t_ is not None:
                     t_.record_stream(side)
             _queue_wgrad_join()
@@ -575,15 +685,28 @@ class _ConvFn(torch.autograd.Function):
                 mt = wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W)
                 a2 = (mt + 2) ** 2
                 tiles = query("u2pl_wino_tiles", N, H, W, dil, mt)
-                V = col      # saved by the forward
+                V, v_amax = col, ctx.col_amax      # saved by the forward
                 if V is None:
                     V = torch.empty(a2 * tiles * Cin, dtype=torch.float32, device=dev)
-                    call("u2pl_wino_input_f32", x, ldx, N, H, W, Cin, dil, mt, V)
+                    if wg_h:
+                        v_amax = amax_slot(dev)
+                        call("u2pl_wino_input_amax_f32", x, ldx, N, H, W, Cin, dil, mt, V, v_amax)
+                    else:
+                        call("u2pl_wino_input_f32", x, ldx, N, H, W, Cin, dil, mt, V)
                 Mg = torch.empty(a2 * tiles * Cout, dtype=torch.float32, device=dev)
-                call("u2pl_wino_gy_f32", gy, ldg, N, H, W, Cout, dil, mt, Mg)
                 ns = query("u2pl_wgrad_batched_splits", tiles, Cin, Cout, a2)
                 part = torch.empty(ns * Cout * a2 * Cin, dtype=torch.float32, device=dev)
-                call("u2pl_wgrad_batched_f32", Mg, Cout, tiles * Cout, V, Cin, tiles * Cin, part, tiles, Cin, Cout, a2)
+                if wg_h:
+                    if v_amax is None:
+                        v_amax = amax_slot(dev)
+                        call("u2pl_absmax_f32", V, Cin, a2 * tiles, Cin, v_amax, 0)
+                    mg_amax = amax_slot(dev)
+                    call("u2pl_wino_gy_amax_f32", gy, ldg, N, H, W, Cout, dil, mt, Mg, mg_amax)
+                    call("u2pl_wgrad_batched_h_f32", Mg, Cout, tiles * Cout, mg_amax, V, Cin, tiles * Cin, v_amax, part, tiles, Cin,
+                         Cout, a2)
+                else:
+                    call("u2pl_wino_gy_f32", gy, ldg, N, H, W, Cout, dil, mt, Mg)
+                    call("u2pl_wgrad_batched_f32", Mg, Cout, tiles * Cout, V, Cin, tiles * Cin, part, tiles, Cin, Cout, a2)
                 tgt = sink if sink is not None else torch.empty_like(weight)
                 call("u2pl_wino_wgrad_finish_f32", part, ns, Cout, Cin, mt, int(sink is not None), tgt)
                 if sink is None:
@@ -592,8 +715,12 @@ class _ConvFn(torch.autograd.Function):
                 wsb = _ws(query("u2pl_conv2d_wgrad_workspace_bytes", N, Ho, Wo, Cin, Cp, R, S), dev)
                 direct = sink is not None and Cp == Cout
                 tgt = sink if direct else torch.empty_like(weight_k)
-                call("u2pl_conv2d_wgrad_bf16op_f32" if ctx.bf else "u2pl_conv2d_wgrad_f32", gy, ldg, x, ldx, tgt, wsb,
-                     int(direct), N, H, W, Cin, Ho, Wo, Cp, R, S, stride, pad, dil)
+                if gy_amax is not None:
+                    call("u2pl_conv2d_wgrad_h_f32", gy, ldg, gy_amax, x, ldx, x_amax, tgt, wsb, int(direct), N, H, W, Cin, Ho, Wo,
+                         Cp, R, S, stride, pad, dil)
+                else:
+                    call("u2pl_conv2d_wgrad_bf16op_f32" if ctx.bf else "u2pl_conv2d_wgrad_f32", gy, ldg, x, ldx, tgt, wsb,
+                         int(direct), N, H, W, Cin, Ho, Wo, Cp, R, S, stride, pad, dil)
                 if not direct:
                     if sink is not None:
                         sink.add_(tgt[:Cout])
@@ -769,7 +896,12 @@ class _BNFn(torch.autograd.Function):
             mean = mod.running_mean
             invstd = _eval_invstd(mod, C, dev)
             count = float(M)
-        call("u2pl_bn_apply_f32", x, ldx, mean, invstd, gamma, beta, rr, ldr or 0, int(relu), drop, H * W, y, C, M, C)
+        if CONV_H["on"]:        # split-fp16: max |y| for the convolutions that read y
+            y_amax = amax_slot(dev)
+            call("u2pl_bn_apply_amax_f32", x, ldx, mean, invstd, gamma, beta, rr, ldr or 0, int(relu), drop, H * W, y, C, M, C, y_amax)
+            set_amax(y, y_amax)
+        else:
+            call("u2pl_bn_apply_f32", x, ldx, mean, invstd, gamma, beta, rr, ldr or 0, int(relu), drop, H * W, y, C, M, C)
         ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma, drop)
         ctx.meta = (N, C, H, W, ldx, training, sync, count, res is not None)
         ctx.gsink, ctx.bsink, ctx.group = gsink, bsink, mod.group
@@ -805,7 +937,19 @@ class _BNFn(torch.autograd.Function):
             _all_reduce(sums, "syncbn_allreduce", group=ctx.group)
         dx = new_act(N, C, H, W, dev) if ctx.needs_input_grad[0] else None
         dres = new_act(N, C, H, W, dev) if has_res and ctx.needs_input_grad[3] else None
-        if pg_fused:
+        if CONV_H["on"] and dx is not None:      # split-fp16: max |dx| / max |dres| for the data / weight gradients that read them
+            dx_amax = amax_slot(dev)
+            dres_amax = amax_slot(dev) if dres is not None else None
+            call("u2pl_bn_bwd_apply_amax_f32", gy, ldg, x, ldx, y, C, mean, invstd, gamma, drop, H * W,
+                 sums if training else None, count, dx, C, dres, C, M, C, sums if pg_fused else None,
+                 ctx.gsink if pg_fused else None, ctx.bsink if pg_fused else None, 1, dx_amax, dres_amax)
+            set_amax(dx, dx_amax)
+            if dres is not None:
+                set_amax(dres, dres_amax)
+            if pg_fused:
+                _mark_ready(ctx.gsink)
+                _mark_ready(ctx.bsink)
+        elif pg_fused:
             call("u2pl_bn_bwd_apply_pg_f32", gy, ldg, x, ldx, y, C, mean, invstd, gamma, drop, H * W,
                  sums if training else None, count, dx, C, dres, C, M, C, sums, ctx.gsink, ctx.bsink, 1)
             _mark_ready(ctx.gsink)
@@ -1122,6 +1266,7 @@ def conv_bn_eval(conv, bn, x, res=None, relu=False):
     arithmetic of u2pl_bn_apply_f32, so the result has the bits of the two-kernel form.  No autograd graph: only for
     calls that record nothing (teacher pseudo-label pass, validate(), eval.py).  Returns None when the layer has no
     fused form (pooled 1x1 branch)."""
+    x_in = x
     x, ldx = as_rows(x)
     N, Cin, H, W = x.shape
     weight, bias = conv.weight, conv.bias
@@ -1146,8 +1291,11 @@ def conv_bn_eval(conv, bn, x, res=None, relu=False):
     elif wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W):
         _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W),
                    False, None, epi)
+    elif _ws_ok(Cout, R * S * Cin) and CONV_H["on"]:
+        call("u2pl_conv2d_fwd_bnact_wsh_f32", x, ldx, amax_of(x_in, x, ldx), ws_forward(weight, True), bias, y, Cout, N, H, W, Cin, Ho,
+             Wo, Cout, R, S, stride, pad, dil, *epi)
     elif _ws_ok(Cout, R * S * Cin):
-        call("u2pl_conv2d_fwd_bnact_ws_f32", x, ldx, ws_forward(weight), bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S,
+        call("u2pl_conv2d_fwd_bnact_ws_f32", x, ldx, ws_forward(weight, False), bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S,
              stride, pad, dil, *epi)
     else:
         call("u2pl_conv2d_fwd_bnact_f32", x, ldx, weight, bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil,

@@ -169,15 +169,20 @@ def test_split_fp32_products_are_as_accurate_as_the_fp32_matrix_instruction(C, O
         assert errs[1][n] < 1e-5, (n, errs)
 
 
+@pytest.mark.parametrize("arith", ["fp16x2", "bf16x3"])
 @pytest.mark.parametrize("kind", ["relu_heavy_tail", "mixed_magnitudes", "cancellation"])
 @pytest.mark.parametrize("C,O,k,d,H,W", [(256, 256, 1, 1, 33, 29), (128, 128, 3, 1, 25, 25), (1024, 256, 1, 1, 21, 21)])
-def test_split_fp32_products_on_adversarial_operands(kind, C, O, k, d, H, W):
+def test_split_fp32_products_on_adversarial_operands(kind, C, O, k, d, H, W, arith):
     """The split arithmetic away from N(0,1) data, forward / data gradient / weight gradient against
     float64, measured like fp32 arithmetic should be -- against the CONDITION of the sums, sum |a||b| -- and compared with the
     fp32 matrix instruction on the same kernels:
       relu_heavy_tail   post-ReLU activations: 60 % exact zeros, the rest |N(0,1)|^3 (a few values carry the sums)
       mixed_magnitudes  input channels scaled 10^U(-6, 6), the weights of a channel by the inverse: every product is O(1)
-                        but each operand spans 12 decades inside one reduction (pieces of very different exponents)
+                        but each operand spans 12 decades inside one reduction (pieces of very different exponents).  The
+                        three-product fp16 form (arith fp16x2, the default since round 6) scales each TENSOR by one power of two:
+                        it keeps fp32 accuracy for elements down to 2^-16 of the tensor's maximum and an absolute error of
+                        2^-40 of the maximum below that, so its case spans 4 decades (10^U(-2, 2))
+                        under the same bound, and the 12-decade case is held to the documented absolute bound instead
       cancellation      weights +w, -w on neighbouring input channels with nearly equal activations: the sums are ~1e-4 of
                         their terms (the Winograd-domain weight gradient's regime)
     Dropped piece products are <= 2^-23 |ab| each, so the error bound is a small multiple of eps32 * sum |a||b| -- the bound of
@@ -194,7 +199,8 @@ def test_split_fp32_products_on_adversarial_operands(kind, C, O, k, d, H, W):
         x = torch.relu(x - 0.25) ** 3
         gy = gy * (torch.rand(gy.shape, generator=g) < 0.3)
     elif kind == "mixed_magnitudes":
-        sc = 10.0 ** (torch.rand(C, generator=g) * 12 - 6)
+        dec = 12 if arith == "bf16x3" else 4
+        sc = 10.0 ** (torch.rand(C, generator=g) * dec - dec / 2)
         x = x * sc.view(1, C, 1, 1)
         w = w / sc.view(1, C, 1, 1)
     else:
@@ -212,10 +218,11 @@ def test_split_fp32_products_on_adversarial_operands(kind, C, O, k, d, H, W):
     ya = F.conv2d(xa, wa, padding=pad, dilation=d)
     ya.backward(gy.double().abs())
     cond = dict(y=ya.detach(), dx=xa.grad, dw=wa.grad)
-    saved, old = dict(Kn.CONV_ALGO), L.u2pl_conv_get_split()
+    saved, old, saved_h = dict(Kn.CONV_ALGO), L.u2pl_conv_get_split(), dict(Kn.CONV_H)
     errs = {}
     try:
         Kn.CONV_ALGO.update(wino=0)
+        Kn.CONV_H["on"] = arith == "fp16x2"
         for mode in (0, 1):
             L.u2pl_conv_set_split(mode)
             conv = Kn.Conv2d(C, O, k, padding=pad, dilation=d, bias=False).to(DEV)
@@ -231,11 +238,40 @@ def test_split_fp32_products_on_adversarial_operands(kind, C, O, k, d, H, W):
     finally:
         L.u2pl_conv_set_split(old)
         Kn.CONV_ALGO.update(saved)
-    print(kind, "max error in eps32 * sum|a||b| (0: fp32 MFMA, 1: split):", errs)
+        Kn.CONV_H.update(saved_h)
+    print(kind, arith, "max error in eps32 * sum|a||b| (0: fp32 MFMA, 1: split):", errs)
     for n in ("y", "dx", "dw"):
         # an fp32 dot product of length K is good to ~sqrt(K) .. K roundings; both arithmetics measured 1 .. 30 here
         assert errs[1][n] <= 1.5 * errs[0][n] + 4.0, (kind, n, errs)
         assert errs[1][n] < 64.0, (kind, n, errs)
+
+
+def test_split_fp16_twelve_decades_inside_one_tensor_meet_the_documented_absolute_bound():
+    """the case the per-tensor scale cannot serve at fp32 accuracy (channels scaled 10^U(-6, 6), weights by the inverse): every term
+    still carries at most 2^-40 max|x| |w| + 2^-40 max|w| |x| + 2^-23 |x w| of error -- the documented floor, checked term-wise
+    against float64"""
+    Kn = K()
+    saved, saved_h = dict(Kn.CONV_ALGO), dict(Kn.CONV_H)
+    g = torch.Generator().manual_seed(77)
+    N, C, O, H, W = 2, 256, 256, 19, 17
+    sc = 10.0 ** (torch.rand(C, generator=g) * 12 - 6)
+    x = torch.randn(N, C, H, W, generator=g) * sc.view(1, C, 1, 1)
+    w = torch.randn(O, C, 1, 1, generator=g) / C ** 0.5 / sc.view(1, C, 1, 1)
+    try:
+        Kn.CONV_ALGO.update(wino=0)
+        Kn.CONV_H["on"] = True
+        conv = Kn.Conv2d(C, O, 1, bias=False).to(DEV)
+        with torch.no_grad():
+            conv.weight.copy_(w.to(DEV))
+            y = conv(x.to(DEV).contiguous(memory_format=CL))
+        ref = F.conv2d(x.double(), w.double())
+        xa, wa = x.double().abs(), w.double().abs()
+        bound = (2.0 ** -40 * (float(xa.max()) * F.conv2d(torch.ones_like(xa), wa) + float(wa.max()) * F.conv2d(xa, torch.ones_like(wa)))
+                 + 2.0 ** -22 * F.conv2d(xa, wa))
+        assert bool(((y.cpu().double() - ref).abs() <= bound).all())
+    finally:
+        Kn.CONV_ALGO.update(saved)
+        Kn.CONV_H.update(saved_h)
 
 
 def test_conv_large_pixel_count_splitk():

@@ -20,11 +20,27 @@ def K():
 
 @pytest.fixture
 def ws_switch():
+    """the six-product bf16 form (U2PL_CONV_H=0): the arithmetic the pre-split kernels share bit for bit with conv.hip's in-loop
+    split.  The three-product fp16 form (the default since round 6) has its own tests at the end of this file (wsh_switch)."""
     Kn = K()
-    saved = (dict(Kn.CONV_ALGO), dict(Kn.CONV_WS))
+    saved = (dict(Kn.CONV_ALGO), dict(Kn.CONV_WS), dict(Kn.CONV_H))
+    Kn.CONV_H["on"] = False
     yield Kn
     Kn.CONV_ALGO.update(saved[0])
     Kn.CONV_WS.update(saved[1])
+    Kn.CONV_H.update(saved[2])
+
+
+@pytest.fixture
+def wsh_switch():
+    Kn = K()
+    saved = (dict(Kn.CONV_ALGO), dict(Kn.CONV_WS), dict(Kn.CONV_H))
+    Kn.CONV_H["on"] = True
+    Kn.CONV_WS["on"] = True
+    yield Kn
+    Kn.CONV_ALGO.update(saved[0])
+    Kn.CONV_WS.update(saved[1])
+    Kn.CONV_H.update(saved[2])
 
 
 # Cin, Cout, k, stride, dil, H, W, N, bias        (Cout > 64: the layers the ws kernel serves)
@@ -356,3 +372,268 @@ def test_split_guard_finite_operands_above_bf16_max_stay_finite(ws_switch):
             conv.weight[7, 9, 0, 0] = w0
         torch.cuda.synchronize()
         assert torch.isfinite(y2).all() and float(y2[:, 7].abs().max()) > 1e30
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# split-fp16 (round 6): three fp16 piece products per fp32 product, operands scaled per tensor by a power of two taken from the
+# maxima their producers leave (csrc/conv_geom.h).  Not the bits of the six-product form -- an independent arithmetic of the same
+# class: checked against float64 (never worse than the six-product form by more than 25 %), against itself across tile plans,
+# and its plumbing (fused maxima == the tensor's max |x|, stale maxima are never used, batched plane rebuilds == lazy ones).
+# ---------------------------------------------------------------------------------------------------------------------------
+def _conv64(x, w, stride, pad, dil, gy):
+    import torch.nn.functional as F
+    xd = x.detach().cpu().double().contiguous().requires_grad_(True)
+    wd = w.detach().cpu().double().contiguous().requires_grad_(True)
+    y = F.conv2d(xd, wd, stride=stride, padding=pad, dilation=dil)
+    y.backward(gy.detach().cpu().double().contiguous())
+    return y.detach(), xd.grad, wd.grad
+
+
+def _run_h(Kn, h, conv, x, gy, pivot=None):
+    Kn.CONV_H["on"] = h
+    Kn.CONV_WS["on"] = True
+    xx = x.detach().clone().requires_grad_(True)
+    conv.weight.grad = None
+    if pivot is None:
+        y, sums = conv(xx), None
+    else:
+        y, sums = conv(xx, stat_pivot=pivot)
+        sums = Kn.finished_sums(sums, conv.out_channels)
+    y.backward(gy)
+    torch.cuda.synchronize()
+    return y.detach(), xx.grad.detach(), conv.weight.grad.detach().clone(), sums
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,dil,H,W,N,bias", CASES)
+def test_wsh_forward_dgrad_wgrad_stats_against_float64(Cin, Cout, k, stride, dil, H, W, N, bias, wsh_switch):
+    Kn = wsh_switch
+    Kn.CONV_ALGO.update(wino=0)
+    torch.manual_seed(Cin * 7 + Cout + k + dil)
+    conv = Kn.Conv2d(Cin, Cout, k, stride=stride, padding=dil * (k // 2), dilation=dil, bias=bias).to(DEV)
+    # post-ReLU-like activations and a gradient whose rows span six decades (what the loss heads hand back)
+    x = torch.relu(torch.randn(N, Cin, H, W, device=DEV) + 0.3).contiguous(memory_format=CL)
+    Ho = (H + 2 * dil * (k // 2) - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * dil * (k // 2) - dil * (k - 1) - 1) // stride + 1
+    gy = (torch.randn(N, Cout, Ho, Wo, device=DEV) * 1e-4 * 10.0 ** (-6 * torch.rand(N, 1, Ho, Wo, device=DEV))).contiguous(memory_format=CL)
+    pivot = torch.randn(Cout, device=DEV) * 0.1
+    ref = _conv64(x, conv.weight, stride, dil * (k // 2), dil, gy)
+    if bias:
+        ref = (ref[0] + conv.bias.detach().cpu().double().view(1, -1, 1, 1),) + ref[1:]
+    got = {h: _run_h(Kn, h, conv, x, gy) for h in (False, True)}
+    for i, name in enumerate(("y", "dx", "dw")):
+        sc = ref[i].abs().max()
+        e6 = float((got[False][i].cpu().double() - ref[i]).abs().max() / sc)
+        e3 = float((got[True][i].cpu().double() - ref[i]).abs().max() / sc)
+        assert e3 <= 1.25 * e6 + 2e-7, (name, e3, e6)
+        assert e3 < 3e-6, (name, e3)
+    # the fused BatchNorm statistics describe THIS arithmetic's output: equal to the stand-alone statistics pass over it to fp32
+    # rounding of the column sums (both are pivot-shifted sums of the same values, added in different orders)
+    ys, _, _, sums = _run_h(Kn, True, conv, x, gy, pivot)
+    assert torch.equal(ys, got[True][0])
+    if Cout % 4:
+        return          # (the stand-alone statistics pass reads float4 columns)
+    from u2pl_amd._lib import call, query
+    rows, ld = Kn.as_rows(ys)
+    M = ys.shape[0] * ys.shape[2] * ys.shape[3]
+    alone = torch.empty(2 * Cout + 1, dtype=torch.float64, device=DEV)
+    wsb = torch.empty(query("u2pl_colreduce_workspace_bytes", M, 1, Cout), dtype=torch.uint8, device=DEV)
+    call("u2pl_bn_stats_f32", rows, ld, M, Cout, pivot, wsb, alone)
+    torch.cuda.synchronize()
+    tol = 1e-5 * (alone[: 2 * Cout].abs().max() + 1)
+    assert float((sums[: 2 * Cout] - alone[: 2 * Cout]).abs().max()) <= float(tol)
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,dil,H,W,N,bias", [c for c in CASES if c[0] * c[2] * c[2] >= 128][:10])
+def test_wsh_same_bits_across_tile_plans(Cin, Cout, k, stride, dil, H, W, N, bias, wsh_switch):
+    """persistent blocks walking (tile, chunk) streams == one block per tile: the plan changes which block computes a tile and
+    in which LDS stage, never the order of a tile's products"""
+    from u2pl_amd._lib import query
+    Kn = wsh_switch
+    Kn.CONV_ALGO.update(wino=0)
+    torch.manual_seed(3 + Cin + Cout)
+    conv = Kn.Conv2d(Cin, Cout, k, stride=stride, padding=dil * (k // 2), dilation=dil, bias=bias).to(DEV)
+    x = torch.randn(N, Cin, H, W, device=DEV).contiguous(memory_format=CL)
+    Ho = (H + 2 * dil * (k // 2) - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * dil * (k // 2) - dil * (k - 1) - 1) // stride + 1
+    gy = torch.randn(N, Cout, Ho, Wo, device=DEV).contiguous(memory_format=CL)
+    outs = []
+    old = query("u2pl_igemm_ws_set_persist", 1)
+    try:
+        for persist in (1, 0):
+            query("u2pl_igemm_ws_set_persist", persist)
+            outs.append(_run_h(Kn, True, conv, x, gy, torch.zeros(Cout, device=DEV)))
+    finally:
+        query("u2pl_igemm_ws_set_persist", old)
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[0][3][: 2 * Cout], outs[1][3][: 2 * Cout])          # (slot 2C, the row count, is the BatchNorm's to fill)
+
+
+@pytest.mark.parametrize("Cin,Cout,dil,H,W,N", [(256, 256, 2, 33, 29, 2), (512, 512, 4, 21, 21, 1), (128, 128, 1, 37, 37, 1)])
+def test_wsh_winograd_layers_against_float64(Cin, Cout, dil, H, W, N, wsh_switch):
+    Kn = wsh_switch
+    Kn.CONV_ALGO.update(wino=4, min_gain=0.0)
+    torch.manual_seed(Cin + Cout + dil)
+    conv = Kn.Conv2d(Cin, Cout, 3, padding=dil, dilation=dil, bias=False).to(DEV)
+    x = torch.relu(torch.randn(N, Cin, H, W, device=DEV)).contiguous(memory_format=CL)
+    gy = (torch.randn(N, Cout, H, W, device=DEV) * 1e-5).contiguous(memory_format=CL)
+    ref = _conv64(x, conv.weight, 1, dil, dil, gy)
+    got = {h: _run_h(Kn, h, conv, x, gy) for h in (False, True)}
+    for i, name in enumerate(("y", "dx", "dw")):
+        sc = ref[i].abs().max()
+        e6 = float((got[False][i].cpu().double() - ref[i]).abs().max() / sc)
+        e3 = float((got[True][i].cpu().double() - ref[i]).abs().max() / sc)
+        assert e3 <= 1.25 * e6 + 2e-7, (name, e3, e6)        # (the Winograd transforms dominate both: ~1e-5)
+
+
+def test_fused_operand_maxima_equal_the_tensors_maxima(wsh_switch):
+    """BatchNorm apply / backward apply and the Winograd transforms leave max |output| in an amax object as they write; the
+    stand-alone pass gives the same value; NaN anywhere makes the maximum NaN"""
+    from u2pl_amd._lib import call, query
+    Kn = wsh_switch
+    torch.manual_seed(9)
+    nw = query("u2pl_amax_words")
+
+    def value(obj):
+        return obj.view(torch.int32).max().view(torch.float32)
+
+    bn = Kn.BatchNorm2d(96).to(DEV).train()
+    x = torch.randn(3, 96, 23, 17, device=DEV).contiguous(memory_format=CL).requires_grad_(True)
+    res = torch.randn(3, 96, 23, 17, device=DEV).contiguous(memory_format=CL).requires_grad_(True)
+    y = bn(x, res=res, relu=True)
+    obj, ver = y._u2pl_amax
+    assert obj.numel() == nw and ver == y._version
+    assert float(value(obj)) == float(y.detach().abs().max())
+    gy = (torch.randn_like(y) * 1e-3).contiguous(memory_format=CL)
+    gx, gres = torch.autograd.grad(y, (x, res), gy)
+    assert float(value(gx._u2pl_amax[0])) == float(gx.abs().max())
+    assert float(value(gres._u2pl_amax[0])) == float(gres.abs().max())
+    # stand-alone pass; a torch in-place op invalidates a carried maximum
+    t = torch.randn(2, 64, 9, 9, device=DEV).contiguous(memory_format=CL)
+    a = Kn.amax_of(t)
+    assert float(value(a)) == float(t.abs().max())
+    assert Kn.amax_of(t) is a                       # cached for this version of the tensor
+    t.mul_(3.0)
+    b = Kn.amax_of(t)
+    assert b is not a and float(value(b)) == float(t.abs().max())
+    t[1, 3, 2, 2] = float("nan")
+    assert torch.isnan(value(Kn.amax_of(t)))
+    # Winograd input transform
+    tiles = query("u2pl_wino_tiles", 2, 9, 9, 1, 4)
+    V = torch.empty(36 * tiles * 64, device=DEV)
+    slot = Kn.amax_slot(t.device)
+    t2 = torch.randn(2, 64, 9, 9, device=DEV).contiguous(memory_format=CL)
+    call("u2pl_wino_input_amax_f32", t2, 64, 2, 9, 9, 64, 1, 4, V, slot)
+    assert float(value(slot)) == float(V.abs().max())
+    Mg = torch.empty(36 * tiles * 64, device=DEV)
+    slot2 = Kn.amax_slot(t.device)
+    call("u2pl_wino_gy_amax_f32", t2, 64, 2, 9, 9, 64, 1, 4, Mg, slot2)
+    assert float(value(slot2)) == float(Mg.abs().max())
+
+
+def test_wsh_eval_batchnorm_epilogue_has_the_two_kernel_forms_bits(wsh_switch):
+    Kn = wsh_switch
+    Kn.CONV_ALGO.update(wino=0)
+    torch.manual_seed(5)
+    conv = Kn.Conv2d(256, 384, 1, bias=False).to(DEV)
+    bn = Kn.BatchNorm2d(384).to(DEV).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.2)
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.weight.normal_(1.0, 0.2)
+        bn.bias.normal_(0, 0.2)
+        x = torch.randn(2, 256, 27, 23, device=DEV).contiguous(memory_format=CL)
+        r = torch.randn(2, 384, 27, 23, device=DEV).contiguous(memory_format=CL)
+        fused = Kn.conv_bn_eval(conv, bn, x, res=r, relu=True)
+        two = bn(conv(x), res=r, relu=True)
+    torch.cuda.synchronize()
+    assert torch.equal(fused, two)
+
+
+def test_wsh_presplit_planes_equal_the_lazy_paths(wsh_switch):
+    """fp16 planes + per-matrix maxima: the batched rebuild after an optimizer step (clear + maxima + split: three launches, plus
+    the Winograd filter transform) writes the bytes the per-weight lazy path writes"""
+    from u2pl_amd._lib import query
+    Kn = wsh_switch
+    Kn.CONV_ALGO.update(wino=4, min_gain=0.0)
+    saved = Kn.PRESPLIT["on"]
+    torch.manual_seed(21)
+    convs = [Kn.Conv2d(128, 256, 1, bias=False).to(DEV), Kn.Conv2d(256, 128, 3, padding=2, dilation=2, bias=False).to(DEV),
+             Kn.Conv2d(128, 160, 3, stride=2, padding=1, bias=False).to(DEV), Kn.Conv2d(160, 96, 1, bias=True).to(DEV)]
+    arena = Kn.ParamArena([[p for c in convs for p in c.parameters()]])
+    x = torch.randn(2, 128, 21, 19, device=DEV).contiguous(memory_format=CL)
+
+    def step():
+        h = x.clone().requires_grad_(True)
+        y = h
+        for c in convs:
+            y = c(y)
+        y.square().mean().backward()
+        torch.cuda.synchronize()
+        return y.detach().clone(), h.grad.clone()
+
+    try:
+        Kn.PRESPLIT["on"] = False
+        step()
+        kinds = sorted(k for c in convs for k in c.weight._u2pl_derived)
+        assert kinds == sorted(["fh", "dh", "wf4h", "wd4h", "fh", "dh", "fh", "dh"]), kinds
+        arena.grad.normal_(0, 1.0)
+        arena.sgd_step([0.05], 0.9, 1e-4)
+        y_lazy, dx_lazy = step()
+        lazy = {(i, k): e["buf"].clone() for i, c in enumerate(convs) for k, e in c.weight._u2pl_derived.items()}
+        Kn.PRESPLIT["on"] = True
+        for c in convs:
+            for e in c.weight._u2pl_derived.values():
+                e["buf"].zero_()
+        Kn.bump_weight_epoch()
+        k0 = query("u2pl_kernel_launches")
+        n = Kn.presplit(arena.params, arena)
+        assert n == 8 and query("u2pl_kernel_launches") - k0 == 4
+        torch.cuda.synchronize()
+        for (i, k), b in lazy.items():
+            e = convs[i].weight._u2pl_derived[k]
+            assert torch.equal(e["buf"], b), (i, k)
+        y_pre, dx_pre = step()
+        assert torch.equal(y_pre, y_lazy) and torch.equal(dx_pre, dx_lazy)
+    finally:
+        Kn.PRESPLIT["on"] = saved
+
+
+def test_wsh_operand_range_semantics(wsh_switch):
+    """what the per-tensor power-of-two scale promises: finite operands of any magnitude (1e-30 .. 3e38)
+    give finite, accurate results; an element 2^-16 of the tensor's maximum or larger keeps fp32 accuracy; smaller elements are
+    carried with an ABSOLUTE error of 2^-40 of the maximum; NaN / Inf operands give non-finite outputs in the rows they touch"""
+    Kn = wsh_switch
+    Kn.CONV_ALGO.update(wino=0)
+    torch.manual_seed(4)
+    conv = Kn.Conv2d(128, 128, 1, bias=False).to(DEV)
+    w64 = conv.weight.detach().double().reshape(128, 128)
+    for scale in (1e-30, 1.0, 1e30):
+        x = (torch.randn(2, 128, 9, 9, device=DEV) * scale).contiguous(memory_format=CL).requires_grad_(True)
+        y = conv(x)
+        gy = (torch.randn_like(y) * (1e-6 / scale if scale > 1 else 1e-6)).contiguous(memory_format=CL)
+        conv.weight.grad = None
+        y.backward(gy)
+        torch.cuda.synchronize()
+        ref = torch.einsum("nchw,oc->nohw", x.detach().double(), w64)
+        assert float((y.double() - ref).abs().max() / ref.abs().max()) < 1e-6
+        dref = torch.einsum("nohw,oc->nchw", gy.double(), w64)
+        assert float((x.grad.double() - dref).abs().max() / dref.abs().max()) < 1e-6
+        wref = torch.einsum("nohw,nchw->oc", gy.double(), x.detach().double())
+        assert float((conv.weight.grad.double().reshape(128, 128) - wref).abs().max() / wref.abs().max()) < 1e-6
+    # one huge finite element: the others keep an absolute error of 2^-40 of it per term
+    x = torch.randn(2, 128, 9, 9, device=DEV).contiguous(memory_format=CL)
+    x[0, 5, 3, 4] = 3.0e38
+    with torch.no_grad():
+        y = conv(x)
+    assert torch.isfinite(y).all()
+    ref = torch.einsum("nchw,oc->nohw", x.double(), w64)
+    cond = torch.einsum("nchw,oc->nohw", x.double().abs(), w64.abs())
+    bound = 128 * 2.0 ** -39 * 3.0e38 * float(w64.abs().max()) + 2.0 ** -22 * cond          # the floor + the usual relative term
+    assert bool(((y.double() - ref).abs() <= bound).all())
+    # non-finite operands
+    x = torch.randn(2, 128, 9, 9, device=DEV).contiguous(memory_format=CL)
+    x[1, 7, 2, 2] = float("nan")
+    with torch.no_grad():
+        y = conv(x)
+    assert not torch.isfinite(y[1, :, 2, 2]).any()

@@ -84,3 +84,69 @@ def test_split_is_exact_for_finite_values_above_the_largest_bfloat16():
     assert np.array_equal(np.abs(x0), np.full(len(x), BF16_MAX))
     total = x0.astype(np.float64) + x1.astype(np.float64) + x2.astype(np.float64)
     assert np.array_equal(total, x.astype(np.float64))
+
+
+# ---- split-fp16 (round 6; u2pl_amd/csrc/conv_geom.h): two fp16 pieces of the power-of-two-scaled operand, three piece products ----
+def split2_exp(amax):
+    """the kernels' scale exponent: amax * 2^e lies in [2^14, 2^15) (split2_exp_bits: from the exponent field of max |x|)"""
+    ex = int((np.float32(amax).view(np.uint32) >> 23) & 0xFF)
+    return min(14 - (ex - 127), 126)
+
+
+def split2(x, e):
+    xs = (np.asarray(x, dtype=np.float32) * np.float32(2.0) ** e).astype(np.float32)      # exact (power of two)
+    with np.errstate(over="ignore"):
+        h0 = xs.astype(np.float16)                                                         # round to nearest even, subnormals kept
+    r = (xs - h0.astype(np.float32)).astype(np.float32)                                    # exact in fp32
+    h1 = r.astype(np.float16)
+    return xs, h0, h1
+
+
+def test_two_fp16_pieces_carry_an_fp32_value_to_one_fp32_ulp():
+    """h0 + h1 = x s to within 2^-23 |x s| (one fp32 ulp: TWICE the rounding fp32 itself commits; rms 2^-24.4 against fp32's 2^-25.2,
+    unbiased): h0 keeps 11 bits, the residual is at most 2^-11 |x s| and h1 keeps 11 bits of IT"""
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.standard_normal(200000).astype(np.float32) * s for s in (1e-3, 1.0, 37.0)])
+    e = split2_exp(np.abs(x).max())
+    xs, h0, h1 = split2(x, e)
+    assert 2.0 ** 14 <= np.abs(xs).max() < 2.0 ** 15 and np.isfinite(h0.astype(np.float32)).all()
+    err = np.abs(xs.astype(np.float64) - h0.astype(np.float64) - h1.astype(np.float64))
+    big = np.abs(xs) >= 2.0 ** -2                      # >= 2^-17 of the maximum: a subnormal second piece is still good to 2^-25 absolute
+    rel = err[big] / np.abs(xs[big].astype(np.float64))
+    assert rel.max() <= 2.0 ** -23 and np.sqrt((rel ** 2).mean()) <= 2.0 ** -24
+    # below that: an ABSOLUTE error of half the fp16 subnormal spacing, 2^-25 (= 2^-40 of the maximum)
+    assert np.all(err <= np.maximum(np.abs(xs.astype(np.float64)) * 2.0 ** -23, 2.0 ** -25))
+
+
+def test_three_fp16_piece_products_give_an_fp32_class_dot_product():
+    """the GEMMs' arithmetic restated: a1 b0 + a0 b1 + a0 b0 per 16-deep block, fp32 accumulate, scaled back by 2^-(ea + eb) --
+    against float64, next to the six-product bf16 form and a plain fp32 chain on the same data"""
+    rng = np.random.default_rng(3)
+    M, K = 512, 2304
+    a = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)                       # post-ReLU activations
+    b = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
+    ref = np.einsum("mk,mk->m", a.astype(np.float64), b.astype(np.float64))
+    ea, eb = split2_exp(np.abs(a).max()), split2_exp(np.abs(b).max())
+    _, a0, a1 = split2(a, ea)
+    _, b0, b1 = split2(b, eb)
+    acc = np.zeros(M, dtype=np.float32)
+    for k0 in range(0, K, 16):
+        s = slice(k0, k0 + 16)
+        for pa, pb in ((a1, b0), (a0, b1), (a0, b0)):
+            acc = (acc + np.einsum("mk,mk->m", pa[:, s].astype(np.float64), pb[:, s].astype(np.float64)).astype(np.float32)).astype(np.float32)
+    got = np.ldexp(acc.astype(np.float64), -(ea + eb))
+    chain = np.zeros(M, dtype=np.float32)
+    for k in range(K):
+        chain = (chain + a[:, k] * b[:, k]).astype(np.float32)
+    scale = np.abs(ref).max()
+    e3 = np.abs(got - ref).max() / scale
+    ec = np.abs(chain.astype(np.float64) - ref).max() / scale
+    assert e3 <= ec and e3 < 1e-6, (e3, ec)
+
+
+def test_scale_exponent_edge_cases():
+    assert split2_exp(1.0) == 14 and split2_exp(1.9999999) == 14 and split2_exp(2.0) == 13
+    assert split2_exp(3.0e38) == 14 - 127                      # the largest finite fp32 still lands below 2^15
+    assert np.float32(3.4e38) * np.float32(2.0) ** split2_exp(3.4e38) < 2.0 ** 15
+    assert split2_exp(0.0) == 126 and split2_exp(1e-45) == 126 # zero / subnormal maxima: the largest normal scale
+    assert split2_exp(np.float32(np.inf)) == 14 - 128          # Inf / NaN maxima: a normal scale, the pieces come out Inf / NaN

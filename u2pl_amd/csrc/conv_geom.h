@@ -67,17 +67,22 @@ __device__ __forceinline__ void split3_bf16(float4 v, uint2& p0, uint2& p1, uint
 
 
 // ---- "split-fp16" (round 6): fp32 products from THREE fp16 piece products -------------------------------------------------
-// An fp32 value scaled by a power of two into the fp16 range is the sum of TWO fp16 pieces to within 2^-25 of itself:
-// h0 = fp16(x s) carries 11 significant bits (error <= 2^-12 |x s|), the residual x s - h0 is exact in fp32 and
-// h1 = fp16(x s - h0) carries the next 11 (round to nearest: the sign bit of the residual is the "23rd" bit), so
-// |x s - h0 - h1| <= 2^-12 * 2^-12 * |x s| / 2.  A product a b is accumulated in fp32 from a1 b0 + a0 b1 + a0 b0 (the dropped
-// a1 b1 is <= 2^-24 |a b|: one fp32 rounding, what the six-product bf16 form drops too) -- three v_mfma_f32_32x32x16_f16
-// instead of six v_mfma_f32_32x32x16_bf16 per 32x32x16 block, two piece planes per operand in LDS instead of three.  fp16 has
-// 5 exponent bits, so the operands are scaled PER TENSOR by a power of two (exact) chosen from max|x| (split2_exp: the largest
-// magnitude lands in [2^14, 2^15)), and the accumulators are scaled back by ldexp in the epilogue (exact).  gfx950's matrix
-// cores and v_cvt_pk_f16_f32 honour fp16 subnormals (tools/micro/f16_denorm.hip), so an element far below the tensor's maximum
-// degrades gracefully: its absolute error is <= 2^-25 in scaled units = 2^-40 max|x|, i.e. elements down to 2^-16 of the
-// maximum keep full fp32 accuracy and no element contributes more error than 2^-40 max|x| |b|.
+// An fp32 value scaled by a power of two into the fp16 range is the sum of TWO fp16 pieces to within one fp32 ulp:
+// h0 = fp16(x s) carries 11 significant bits (|x s - h0| <= 2^-11 |x s|), the residual is exact in fp32 and h1 = fp16(x s - h0)
+// carries 11 bits of IT, so |x s - h0 - h1| <= 2^-23 |x s| -- twice fp32's own rounding bound, unbiased, rms 2^-24.4 (fp32:
+// 2^-25.2; tests/test_split_fp32_cpu.py).  A product a b is accumulated in fp32 from a1 b0 + a0 b1 + a0 b0 (the dropped a1 b1 is
+// <= 2^-22 |a b|): per term at most ~2^-21 |a b| in the worst case and ~2^-24 |a b| rms, against <= 2^-23 worst / ~2^-25 rms for
+// the six-product bf16 form -- both far below what the fp32 ACCUMULATION of a K-term sum commits (sqrt(K) .. K roundings), which
+// is why the two forms measure the same against float64 on every layer shape (tools/bench_igemm_wsh.py, tests/test_gpu_igemm_ws.py;
+// the fp16 form is usually the closer one).  Three v_mfma_f32_32x32x16_f16 instead of six v_mfma_f32_32x32x16_bf16 per 32x32x16
+// block, two piece planes per operand in LDS instead of three.  fp16 has 5 exponent bits, so the operands are scaled PER TENSOR by
+// a power of two (exact) chosen from max|x| (split2_exp_bits: the largest magnitude lands in [2^14, 2^15)), and the accumulators
+// are scaled back by ldexp in the epilogue (exact).  gfx950's matrix cores and v_cvt_pk_f16_f32 honour fp16 subnormals
+// (tools/micro/f16_denorm.hip), so an element far below the tensor's maximum degrades gracefully: its absolute error is <= 2^-25
+// in scaled units = 2^-40 max|x|, i.e. elements down to 2^-17 of the maximum keep the accuracy above and no element contributes
+// more error than 2^-40 max|x| |b|.  What this gives up against the bf16 form: operands whose elements span more than ~2^26 INSIDE
+// one tensor with the small ones mattering (tests/test_gpu_conv_stack.py: the twelve-decade case) -- U2PL_CONV_H=0 selects the
+// six-product form for such data.
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned pack2_f16(float lo, float hi) {        // ONE v_cvt_pk_f16_f32 (round to nearest even)

@@ -159,7 +159,7 @@ __global__ void k_weight_amax_clear(const SplitJob* __restrict__ jobs, int njobs
     if (t >= njobs) return;
     const SplitJob j = jobs[t];
     unsigned* slot = (unsigned*)((char*)j.out + ws2_plane_bytes(j.Np, j.K, j.batch));
-    for (int z = 0; z < j.batch; ++z) slot[z] = 0u;
+    for (int z = 0; z < ((j.batch + 3) & ~3); ++z) slot[z] = 0u;        // (the whole 16-byte-rounded tail: no uninitialised bytes)
 }
 // block b covers the contiguous segments [b * WS_AMAX_SPAN, (b + 1) * WS_AMAX_SPAN): a thread keeps a running maximum for the
 // matrix it is in and publishes when it crosses into another (rare) and at its end -- per wave one atomic where the lanes agree on

@@ -367,7 +367,10 @@ def main():
 
     # the roofline leg runs ONE extra (un-timed) step with per-call HIP events; it contains the step's
     # collectives, so every rank executes it
+    KN.AMAX_STATS.update(fused=0, standalone=0)
     roof = RL.measure(trainer, batches[0], args, ms)
+    # split-fp16 operand maxima of that (eager) step: how many came out of their producers' own launches, how many needed a pass
+    roof["operand_maxima_per_step"] = dict(KN.AMAX_STATS, conv_h=bool(KN.CONV_H["on"]))
     _progress()
     if world > 1:
         dist.barrier()

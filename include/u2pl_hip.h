@@ -316,6 +316,7 @@ int u2pl_gemm_batched_ws_f32(const float* x, long ldx, long zx, const void* wspl
  *     shards (bit patterns of |x|: NaN if any element is NaN).  Every x_amax / dy_amax / *_amax argument below is one.
  *   u2pl_absmax_f32: out <- max |x| over [M][C] (C % 4 == 0, ld % 4 == 0); clear != 0 zeroes the object first.  Any upper bound
  *     within ~2^8 of the true maximum keeps fp32-class accuracy; a value BELOW the maximum overflows fp16.
+ *   u2pl_conv2d_fwd_bnact_wsh_f32's y_amax: NULL or an amax object for max |y| of the fused output (the next layer's x_amax).
  *   u2pl_weight_split2h_*: planes [K/32][2][Np][32] fp16 + one uint32 per matrix (bit pattern of its max |w|) behind them.
  *     job_scratch: 48 device bytes (the job record of the one-weight call).  The multi call takes the SplitJob table of
  *     u2pl_weight_split3_multi_f32 with out = u2pl_weight_split2h_bytes buffers. */
@@ -336,6 +337,9 @@ int u2pl_bn_bwd_apply_amax_f32(const float* dy, long lddy, const float* x, long 
                                float* gsink, float* bsink, int accumulate, float* dx_amax, float* dres_amax, hipStream_t stream);
 int u2pl_wino_input_amax_f32(const float* x, long ldx, int N, int H, int W, int C, int dil, int mt, float* V, float* v_amax,
                              hipStream_t stream);
+int u2pl_wino_output_bnact_amax_f32(const float* Mb, int N, int H, int W, int O, int dil, int mt, const float* bias, float* y,
+                                    long ldy, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                    const float* res, long ldr, int relu, float* y_amax, hipStream_t stream);
 int u2pl_wino_gy_amax_f32(const float* gy, long ldg, int N, int H, int W, int O, int dil, int mt, float* Mg, float* mg_amax,
                           hipStream_t stream);
 int u2pl_conv2d_fwd_wsh_f32(const float* x, long ldx, const float* x_amax, const void* wsplit, const float* bias, float* y, long ldy,
@@ -347,7 +351,7 @@ int u2pl_conv2d_fwd_bnstats_wsh_f32(const float* x, long ldx, const float* x_ama
 int u2pl_conv2d_fwd_bnact_wsh_f32(const float* x, long ldx, const float* x_amax, const void* wsplit, const float* bias, float* y,
                                   long ldy, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S,
                                   int stride, int pad, int dil, const float* mean, const float* invstd, const float* gamma,
-                                  const float* beta, const float* res, long ldr, int relu, hipStream_t stream);
+                                  const float* beta, const float* res, long ldr, int relu, float* y_amax, hipStream_t stream);
 int u2pl_conv2d_dgrad_wsh_f32(const float* dy, long lddy, const float* dy_amax, const void* wTsplit, float* dx, long lddx, int N,
                               int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int S, int stride, int pad, int dil,
                               hipStream_t stream);

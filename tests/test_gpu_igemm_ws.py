@@ -531,6 +531,27 @@ def test_fused_operand_maxima_equal_the_tensors_maxima(wsh_switch):
     assert float(value(slot2)) == float(Mg.abs().max())
 
 
+@pytest.mark.parametrize("k,Cout,H", [(1, 384, 27), (1, 256, 140), (3, 256, 33)])
+def test_eval_epilogue_leaves_the_outputs_maximum(k, Cout, H, wsh_switch):
+    """conv + eval-mode BatchNorm in one launch (GEMM epilogue / Winograd output transform): the amax object holds max |y| of what
+    was STORED -- rows past M and columns past Cout of the last tiles do not count (persistent blocks, several tiles per block at
+    H = 140)"""
+    Kn = wsh_switch
+    Kn.CONV_ALGO.update(wino=4 if k == 3 else 0, min_gain=0.0)
+    torch.manual_seed(6 + k)
+    conv = Kn.Conv2d(256, Cout, k, padding=k // 2, bias=False).to(DEV)
+    bn = Kn.BatchNorm2d(Cout).to(DEV).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.2)
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.bias.normal_(0, 5.0)             # (a large shift: a zero-filled padding row would read |beta|, not 0)
+        x = torch.randn(2, 256, H, H - 4, device=DEV).contiguous(memory_format=CL)
+        y = Kn.conv_bn_eval(conv, bn, x, relu=False)
+    obj, ver = y._u2pl_amax
+    assert ver == y._version
+    assert float(obj.view(torch.int32).max().view(torch.float32)) == float(y.abs().max())
+
+
 def test_wsh_eval_batchnorm_epilogue_has_the_two_kernel_forms_bits(wsh_switch):
     Kn = wsh_switch
     Kn.CONV_ALGO.update(wino=0)

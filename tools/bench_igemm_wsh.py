@@ -105,7 +105,7 @@ def main():
             fn(y)
         torch.cuda.synchronize()
         row = dict(kind=kind, N=N, H=H, Cin=Cin, Cout=Cout, k=k, d=dil, s=stride, gflop=round(flops / 1e9, 1),
-                   rel_diff=float(((ys[0] - ys[1]).abs().max() / ys[0].abs().max()).item()), amax=float(amax.item()))
+                   rel_diff=float(((ys[0] - ys[1]).abs().max() / ys[0].abs().max()).item()), amax=float(amax.max().item()))
         if ref is not None:
             y64, pick = ref
             sc = y64.abs().max()

@@ -224,5 +224,6 @@ struct BnEpi {
     const float *mean, *invstd, *gamma, *beta, *res;
     long ldr;
     int relu;
+    unsigned* y_amax;       // split-fp16: amax object that receives max |y| of the fused output (NULL: not wanted)
 };
 

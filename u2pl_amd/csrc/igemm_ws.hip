@@ -789,6 +789,7 @@ __device__ __forceinline__ void igemm_ws_body(
     };
     c_tile_setup();
     float* red = (float*)(smem + 2 * ST);   // [4][2][BN] statistics scratch BEHIND the two stages (stage `nxt` already holds the next tile)
+    unsigned y_am = 0u;                     // fused eval-BN epilogue: running max |y| over this block's tiles (published once, at the end)
 #ifdef U2PL_WS_STAMPS
     int te_n = 0;
 #endif
@@ -880,6 +881,9 @@ __device__ __forceinline__ void igemm_ws_body(
                         if (epi.res) v += rv[a][e];
                         if (epi.relu) v = fmaxf(v, 0.f);
                         acc[a][b][e] = v;
+                        // (elements outside the matrix -- rows past M, columns past Cout -- are dropped by the store; their values
+                        //  come from zero-filled operands and the epilogue's parameters: masked out of the maximum)
+                        if (epi.y_amax && col < g.Cout && (long)(mrow + a * 32 + (e & 3) + 8 * (e >> 2)) < M) y_am = amax_bits(y_am, v);
                     }
             }
             __builtin_amdgcn_sched_barrier(0);      // (no store may move in front of a load)
@@ -969,6 +973,7 @@ __device__ __forceinline__ void igemm_ws_body(
         }
         tile_end();
     }
+    if (epi.y_amax) amax_wave_publish(y_am, epi.y_amax);      // (wave-uniform branch; every wave of the block gets here)
 #ifdef U2PL_WS_STAMPS
     ph[2] = ph[3] = __builtin_readcyclecounter();
     if (d_ws_stamps && blockIdx.x < 1024 && tid == 0)
@@ -1029,7 +1034,7 @@ static int launch_igemm_ws(const float* x, long ldx, const float* x_amax, const 
     const long M = (long)g.N * g.Hout * g.Wout;
     if (M <= 0) return 0;
     const int K = g.R * g.S * g.Cin, Np = ws_pad_rows(g.Cout);
-    const BnEpi ep = epi ? *epi : BnEpi{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    const BnEpi ep = epi ? *epi : BnEpi{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr};
     const size_t lds = (size_t)2 * NP * (BM + BN) * WS_ROW_B + (size_t)8 * BN * sizeof(float);      // two stages + statistics scratch
     static bool attr_set = false;
     if (!attr_set) {
@@ -1068,7 +1073,7 @@ static int launch_igemm_ws_mix(const float* x, long ldx, const float* x_amax, co
                                long zy, const BnEpi* epi, long wide_tiles, long narrow_tiles) {
     const long M = (long)g.N * g.Hout * g.Wout;
     const int K = g.R * g.S * g.Cin, Np = ws_pad_rows(g.Cout);
-    const BnEpi ep = epi ? *epi : BnEpi{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    const BnEpi ep = epi ? *epi : BnEpi{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr};
     const size_t lds = (size_t)2 * NP * (128 + 256) * WS_ROW_B + (size_t)8 * 256 * sizeof(float);       // the wide body's
     static bool attr_set = false;
     if (!attr_set) {
@@ -1201,7 +1206,7 @@ U2PL_API int u2pl_conv2d_fwd_bnact_ws_f32(const float* x, long ldx, const void* 
                                           hipStream_t stream) {
     if (!mean || !invstd || !gamma || !beta || (Cout & 3) || (res && (ldr & 3))) return U2PL_EINVAL;
     ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
-    const BnEpi epi = {mean, invstd, gamma, beta, res, ldr, relu};
+    const BnEpi epi = {mean, invstd, gamma, beta, res, ldr, relu, nullptr};
     return run_igemm_ws(x, ldx, wsplit, bias, y, ldy, g, stream, nullptr, nullptr, 1, 0, 0, &epi);
 }
 U2PL_API int u2pl_conv2d_dgrad_ws_f32(const float* dy, long lddy, const void* wTsplit, float* dx, long lddx, int N, int Hin,
@@ -1245,10 +1250,10 @@ U2PL_API int u2pl_conv2d_fwd_bnact_wsh_f32(const float* x, long ldx, const float
                                            long ldy, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R,
                                            int S, int stride, int pad, int dil, const float* mean, const float* invstd,
                                            const float* gamma, const float* beta, const float* res, long ldr, int relu,
-                                           hipStream_t stream) {
+                                           float* y_amax, hipStream_t stream) {
     if (!x_amax || !mean || !invstd || !gamma || !beta || (Cout & 3) || (res && (ldr & 3))) return U2PL_EINVAL;
     ConvGeom g = {N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, -pad, -pad, dil, 0};
-    const BnEpi epi = {mean, invstd, gamma, beta, res, ldr, relu};
+    const BnEpi epi = {mean, invstd, gamma, beta, res, ldr, relu, (unsigned*)y_amax};
     return run_igemm_ws(x, ldx, wsplit, bias, y, ldy, g, stream, nullptr, nullptr, 1, 0, 0, &epi, x_amax);
 }
 U2PL_API int u2pl_conv2d_dgrad_wsh_f32(const float* dy, long lddy, const float* dy_amax, const void* wTsplit, float* dx, long lddx, int N,

@@ -264,6 +264,7 @@ __global__ __launch_bounds__(256) U2PL_HBM_KERNEL void k_wino_output(const float
         live = t < g.tiles;
     }
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    unsigned am = 0u;
     if (live) {
         int n, py, px, ty, tx;
         tile_coords(g, t, n, py, px, ty, tx);
@@ -313,6 +314,7 @@ __global__ __launch_bounds__(256) U2PL_HBM_KERNEL void k_wino_output(const float
                         if (epi.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     }
                     *(float4*)(y + pix * ldy + o4 * 4) = v;
+                    am = amax_bits4(am, v);
                     const float4 dv = f4sub(v, pv);
                     s1 = f4add(s1, dv);
                     s2 = f4add(s2, make_float4(dv.x * dv.x, dv.y * dv.y, dv.z * dv.z, dv.w * dv.w));
@@ -320,6 +322,7 @@ __global__ __launch_bounds__(256) U2PL_HBM_KERNEL void k_wino_output(const float
             }
         }
     }
+    if (epi.y_amax) amax_wave_publish(am, epi.y_amax);      // (every thread of the block gets here)
     if (!stats) return;
     *(float4*)red[0][threadIdx.x] = s1;
     *(float4*)red[1][threadIdx.x] = s2;
@@ -528,7 +531,7 @@ static int run_wino_output(const float* Mb, int N, int H, int W, int O, int dil,
 }
 U2PL_API int u2pl_wino_output_f32(const float* Mb, int N, int H, int W, int O, int dil, int mt, const float* bias,
                                   float* y, long ldy, float* stats_partial, const float* pivot, hipStream_t stream) {
-    const BnEpi off = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    const BnEpi off = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr};
     return run_wino_output(Mb, N, H, W, O, dil, mt, bias, y, ldy, stats_partial, pivot, off, stream);
 }
 // output transform fused with the eval-mode BatchNorm (+residual, ReLU) that follows the convolution
@@ -537,7 +540,16 @@ U2PL_API int u2pl_wino_output_bnact_f32(const float* Mb, int N, int H, int W, in
                                         float* y, long ldy, const float* mean, const float* invstd, const float* gamma,
                                         const float* beta, const float* res, long ldr, int relu, hipStream_t stream) {
     if (!mean || !invstd || !gamma || !beta || (O & 3) || (ldy & 3) || (res && (ldr & 3))) return U2PL_EINVAL;
-    const BnEpi epi = {mean, invstd, gamma, beta, res, ldr, relu};
+    const BnEpi epi = {mean, invstd, gamma, beta, res, ldr, relu, nullptr};
+    return run_wino_output(Mb, N, H, W, O, dil, mt, bias, y, ldy, nullptr, nullptr, epi, stream);
+}
+// the same + max |y| into the caller-zeroed amax object y_amax (split-fp16: y is the next convolution's operand)
+U2PL_API int u2pl_wino_output_bnact_amax_f32(const float* Mb, int N, int H, int W, int O, int dil, int mt, const float* bias,
+                                             float* y, long ldy, const float* mean, const float* invstd, const float* gamma,
+                                             const float* beta, const float* res, long ldr, int relu, float* y_amax,
+                                             hipStream_t stream) {
+    if (!mean || !invstd || !gamma || !beta || (O & 3) || (ldy & 3) || (res && (ldr & 3))) return U2PL_EINVAL;
+    const BnEpi epi = {mean, invstd, gamma, beta, res, ldr, relu, (unsigned*)y_amax};
     return run_wino_output(Mb, N, H, W, O, dil, mt, bias, y, ldy, nullptr, nullptr, epi, stream);
 }
 

@@ -464,7 +464,7 @@ def wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W):
     return mt if gain >= CONV_ALGO["min_gain"] else 0
 
 
-def _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, mt, transposed, pivot=None, epi=None):
+def _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, mt, transposed, pivot=None, epi=None, y_amax=None):
     """y <- conv3x3(x) in Winograd form; transposed: data-gradient (x = dY with Cout channels, y = dX with Cin).
     Returns the fused BatchNorm partial sums (or None).  epi = (mean, invstd, gamma, beta, res, ldr, relu): eval-mode
     BatchNorm applied by the output transform."""
@@ -494,7 +494,9 @@ def _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, mt, transposed,
     if pivot is not None:
         nblk = query("u2pl_wino_stat_blocks", tiles, Co)
         part = torch.empty((nblk, 2, Co), dtype=torch.float32, device=dev)
-    if epi is not None:
+    if epi is not None and y_amax is not None:      # split-fp16: the fused output is the next convolution's operand
+        call("u2pl_wino_output_bnact_amax_f32", Mb, N, H, W, Co, dil, mt, bias, y, Co, *epi, y_amax)
+    elif epi is not None:
         call("u2pl_wino_output_bnact_f32", Mb, N, H, W, Co, dil, mt, bias, y, Co, *epi)
     else:
         call("u2pl_wino_output_f32", Mb, N, H, W, Co, dil, mt, bias, y, Co, part, pivot)
@@ -631,7 +633,7 @@ class _ConvFn(torch.autograd.Function):
                 # block input (46 adds, 3.2 ms per step before round 5)
                 if CONV_H["on"]:
                     call("u2pl_conv2d_fwd_bnact_wsh_f32", gy, ldg, amax_of(gy_in, gy, ldg), ws_dgrad(weight, True), None, dx, Cin, N,
-                         H, W, Cout, H, W, Cin, 1, 1, 1, 0, 1, *epi)
+                         H, W, Cout, H, W, Cin, 1, 1, 1, 0, 1, *epi, None)
                 else:
                     call("u2pl_conv2d_fwd_bnact_ws_f32", gy, ldg, ws_dgrad(weight, False), None, dx, Cin, N, H, W, Cout, H, W, Cin, 1, 1,
                          1, 0, 1, *epi)
@@ -1289,11 +1291,16 @@ def conv_bn_eval(conv, bn, x, res=None, relu=False):
         wp[:, : R * S * Cin] = weight.permute(0, 2, 3, 1).reshape(Cout, R * S * Cin)
         call("u2pl_conv2d_fwd_bnact_f32", col, Kp, wp, bias, y, Cout, N, Ho, Wo, Kp, Ho, Wo, Cout, 1, 1, 1, 0, 1, *epi)
     elif wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W):
+        y_amax = amax_slot(dev) if CONV_H["on"] else None
         _wino_conv(x, ldx, weight, bias, y, N, H, W, Cin, Cout, dil, wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W),
-                   False, None, epi)
+                   False, None, epi, y_amax)
+        if y_amax is not None:
+            set_amax(y, y_amax)
     elif _ws_ok(Cout, R * S * Cin) and CONV_H["on"]:
+        y_amax = amax_slot(dev)
         call("u2pl_conv2d_fwd_bnact_wsh_f32", x, ldx, amax_of(x_in, x, ldx), ws_forward(weight, True), bias, y, Cout, N, H, W, Cin, Ho,
-             Wo, Cout, R, S, stride, pad, dil, *epi)
+             Wo, Cout, R, S, stride, pad, dil, *epi, y_amax)
+        set_amax(y, y_amax)
     elif _ws_ok(Cout, R * S * Cin):
         call("u2pl_conv2d_fwd_bnact_ws_f32", x, ldx, ws_forward(weight, False), bias, y, Cout, N, H, W, Cin, Ho, Wo, Cout, R, S,
              stride, pad, dil, *epi)

@@ -18,7 +18,17 @@ _CONV_GEOM = {
     "u2pl_conv2d_fwd_bf16op_f32": 6, "u2pl_conv2d_fwd_bnstats_bf16op_f32": 6, "u2pl_conv2d_dgrad_bf16op_f32": 5,
     "u2pl_conv2d_wgrad_bf16op_f32": 7,
     "u2pl_conv2d_fwd_ws_f32": 6, "u2pl_conv2d_fwd_bnstats_ws_f32": 6, "u2pl_conv2d_fwd_bnact_ws_f32": 6, "u2pl_conv2d_dgrad_ws_f32": 5,
+    # split-fp16 (round 6): the operand-maximum pointer shifts the geometry by one (two in the weight gradient)
+    "u2pl_conv2d_fwd_wsh_f32": 7, "u2pl_conv2d_fwd_bnstats_wsh_f32": 7, "u2pl_conv2d_fwd_bnact_wsh_f32": 7, "u2pl_conv2d_dgrad_wsh_f32": 6,
+    "u2pl_conv2d_wgrad_h_f32": 9,
 }
+# entry points whose fp32 products are THREE fp16 piece products (csrc/conv_geom.h "split-fp16"); every other split entry point: six
+H_NAMES = ("u2pl_conv2d_fwd_wsh_f32", "u2pl_conv2d_fwd_bnstats_wsh_f32", "u2pl_conv2d_fwd_bnact_wsh_f32", "u2pl_conv2d_dgrad_wsh_f32",
+           "u2pl_gemm_batched_wsh_f32", "u2pl_conv2d_wgrad_h_f32", "u2pl_wgrad_batched_h_f32")
+
+
+def piece_products(name):
+    return 3 if name in H_NAMES else 6
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense
 # split fp32 (csrc/conv.hip BF == 3): one fp32 product = six bf16 piece products -> the matrix-pipe bound of the algorithm in
 # fp32-equivalent FLOP/s
@@ -29,14 +39,24 @@ def conv_split_on():
     return bool(_lib.lib().cdll.u2pl_conv_get_split())
 
 
-def _mfma_fields(ach):
-    """roofline fields of an fp32 GEMM-like group: against the pipe its instructions actually run on"""
+def _mfma_fields(ach, pipe_flops=None, flops=None):
+    """roofline fields of an fp32 GEMM-like group: against the pipe its instructions actually run on.  pipe_flops / flops: the
+    matrix-pipe FLOPs the group's launches issue (executed fp32 FLOPs x piece products per product: 3 for the fp16 split, 6 for
+    the bf16 split) over their executed fp32 FLOPs -- the group's fp32-equivalent bound is 2500 / that ratio"""
     if conv_split_on():
-        return {"peak": round(PEAK_SPLIT_F32_TFLOPS, 1), "frac": round(ach / PEAK_SPLIT_F32_TFLOPS, 4),
+        ratio = (pipe_flops / flops) if (pipe_flops and flops) else 6.0
+        peak = PEAK_BF16_MFMA_TFLOPS / ratio
+        return {"peak": round(peak, 1), "frac": round(ach / peak, 4),
                 "frac_vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                "arithmetic": "fp32 products as six bf16 piece products of an exact three-way operand split, fp32 accumulate "
-                              "(v_mfma_f32_32x32x16_bf16; U2PL_CONV_SPLIT=0: v_mfma_f32_32x32x2_f32).  achieved = fp32-equivalent "
-                              "FLOP/s; peak = 2500 TF bf16 dense / 6 piece products; frac_vs_fp32_mfma_peak = achieved / 157.3"}
+                "piece_products_per_fp32_product": round(ratio, 3),
+                "matrix_pipe_tflops": round(ach * ratio, 1),
+                "arithmetic": "fp32 products on the 16-bit matrix cores, fp32 accumulate: THREE fp16 piece products of a two-piece "
+                              "split of the power-of-two-scaled operands (v_mfma_f32_32x32x16_f16; default since round 6, "
+                              "csrc/conv_geom.h) or SIX bf16 piece products of an exact three-piece split "
+                              "(v_mfma_f32_32x32x16_bf16: U2PL_CONV_H=0, and the <= 64-channel layers); U2PL_CONV_SPLIT=0: "
+                              "v_mfma_f32_32x32x2_f32.  achieved = fp32-equivalent FLOP/s; peak = 2500 TF (bf16 = fp16 dense) / "
+                              "piece_products_per_fp32_product of the launches; frac = matrix-pipe FLOP/s over 2500; "
+                              "frac_vs_fp32_mfma_peak = achieved / 157.3"}
     return {"peak": PEAK_F32_MFMA_TFLOPS, "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
             "arithmetic": "v_mfma_f32_32x32x2_f32 (U2PL_CONV_SPLIT=0)"}
 
@@ -48,8 +68,14 @@ def _conv_flops(name, args):
     if name == "u2pl_gemm_batched_ws_f32":   # (x, ldx, zx, wsplit, y, ldy, zy, M, K, Nn, batch)
         M, K, Nn, batch = args[7:11]
         return 2.0 * M * K * Nn * batch
+    if name == "u2pl_gemm_batched_wsh_f32":  # (x, ldx, zx, x_amax, wsplit, y, ldy, zy, M, K, Nn, batch)
+        M, K, Nn, batch = args[8:12]
+        return 2.0 * M * K * Nn * batch
     if name == "u2pl_wgrad_batched_f32":     # (dy, lddy, zdy, x, ldx, zx, part, M, Cin, Cout, batch)
         M, Cin, Cout, batch = args[7:11]
+        return 2.0 * M * Cin * Cout * batch
+    if name == "u2pl_wgrad_batched_h_f32":   # (dy, lddy, zdy, dy_amax, x, ldx, zx, x_amax, part, M, Cin, Cout, batch)
+        M, Cin, Cout, batch = args[9:13]
         return 2.0 * M * Cin * Cout * batch
     i = _CONV_GEOM[name]
     N, Hin, Win, Cin, Hout, Wout, Cout, R, S = args[i:i + 9]
@@ -61,9 +87,9 @@ def _conv_bytes(name, args):
     pixels from cache, not from memory), the B operand once (fp32 weights: 4 B/element; pre-split planes: 6 B), the
     output written once.  What the kernel moves above this figure is re-reads of A across column tiles / of B across
     row tiles that L2 / MALL did not absorb."""
-    if name in ("u2pl_gemm_batched_f32", "u2pl_gemm_batched_ws_f32"):
-        M, K, Nn, batch = args[8:12] if name == "u2pl_gemm_batched_f32" else args[7:11]
-        wb = 6 if name.endswith("_ws_f32") else 4
+    if name in ("u2pl_gemm_batched_f32", "u2pl_gemm_batched_ws_f32", "u2pl_gemm_batched_wsh_f32"):
+        M, K, Nn, batch = args[7:11] if name == "u2pl_gemm_batched_ws_f32" else args[8:12]
+        wb = 6 if name.endswith("_ws_f32") else 4           # (three bf16 planes: 6 B per weight; two fp16 planes or fp32: 4 B)
         return batch * (4.0 * M * K + wb * Nn * K + 4.0 * M * Nn)
     i = _CONV_GEOM[name]
     N, Hin, Win, Cin, Hout, Wout, Cout, R, S = args[i:i + 9]
@@ -85,7 +111,8 @@ def profile_step(step_fn):
         d = agg.setdefault(name, dict(ms=0.0, calls=0, flops=0.0, kernels=0, bytes=0.0))
         if name in MFMA_GROUPS["igemm"]:
             d["bytes"] += _conv_bytes(name, args)
-            if "_bnact" in name and len(full) > 22 and full[22] is not None:
+            ri = 23 if "_wsh_" in name else 22
+            if "_bnact" in name and len(full) > ri and full[ri] is not None:
                 # the epilogue's residual operand is read once too (eval-mode identity; round 5: the residual GRADIENT that the
                 # pointwise data-gradient launch adds)
                 i = _CONV_GEOM[name]
@@ -94,12 +121,12 @@ def profile_step(step_fn):
         d["ms"] += ms
         d["calls"] += 1
         d["kernels"] += nk
-        if name == "u2pl_wgrad_batched_f32":
+        if name in ("u2pl_wgrad_batched_f32", "u2pl_wgrad_batched_h_f32"):
             d["flops"] += _conv_flops(name, args)
-        elif name in ("u2pl_gemm_batched_f32", "u2pl_gemm_batched_ws_f32"):
+        elif name in ("u2pl_gemm_batched_f32", "u2pl_gemm_batched_ws_f32", "u2pl_gemm_batched_wsh_f32"):
             fl = _conv_flops(name, args)
             d["flops"] += fl
-            o = 8 if name == "u2pl_gemm_batched_f32" else 7
+            o = 7 if name == "u2pl_gemm_batched_ws_f32" else 8
             key = ("wino_gemm", args[o + 3], args[o], 1, args[o + 1], args[o], 1, args[o + 2], 1, 1, 1, 0, 1)
             sd = shapes.setdefault(key, dict(ms=0.0, calls=0, flops=0.0))
             sd["ms"] += ms
@@ -109,7 +136,7 @@ def profile_step(step_fn):
             fl = _conv_flops(name, args)
             d["flops"] += fl
             i = _CONV_GEOM[name]
-            key = (name[12:-4].replace("fwd_bnstats", "fwd").replace("fwd_bnact", "fwd").replace("_bf16op", "@bf16").replace("_ws", "@ws"),) + tuple(args[i:i + 9]) + tuple(args[i + 9:i + 12])
+            key = (name[12:-4].replace("fwd_bnstats", "fwd").replace("fwd_bnact", "fwd").replace("_bf16op", "@bf16").replace("_wsh", "@wsh").replace("_ws", "@ws"),) + tuple(args[i:i + 9]) + tuple(args[i + 9:i + 12])
             sd = shapes.setdefault(key, dict(ms=0.0, calls=0, flops=0.0))
             sd["ms"] += ms
             sd["calls"] += 1
@@ -121,8 +148,10 @@ def profile_step(step_fn):
 MFMA_GROUPS = {
     "igemm": ("u2pl_conv2d_fwd_f32", "u2pl_conv2d_fwd_bnstats_f32", "u2pl_conv2d_fwd_bnact_f32", "u2pl_conv2d_dgrad_f32",
               "u2pl_gemm_batched_f32", "u2pl_conv2d_fwd_ws_f32", "u2pl_conv2d_fwd_bnstats_ws_f32", "u2pl_conv2d_fwd_bnact_ws_f32",
-              "u2pl_conv2d_dgrad_ws_f32", "u2pl_gemm_batched_ws_f32"),
-    "wgrad": ("u2pl_conv2d_wgrad_f32", "u2pl_wgrad_batched_f32"),
+              "u2pl_conv2d_dgrad_ws_f32", "u2pl_gemm_batched_ws_f32",
+              "u2pl_conv2d_fwd_wsh_f32", "u2pl_conv2d_fwd_bnstats_wsh_f32", "u2pl_conv2d_fwd_bnact_wsh_f32",
+              "u2pl_conv2d_dgrad_wsh_f32", "u2pl_gemm_batched_wsh_f32"),
+    "wgrad": ("u2pl_conv2d_wgrad_f32", "u2pl_wgrad_batched_f32", "u2pl_conv2d_wgrad_h_f32", "u2pl_wgrad_batched_h_f32"),
     "bf16": ("u2pl_conv2d_fwd_bf16op_f32", "u2pl_conv2d_fwd_bnstats_bf16op_f32", "u2pl_conv2d_dgrad_bf16op_f32",
              "u2pl_conv2d_wgrad_bf16op_f32"),
 }
@@ -281,15 +310,16 @@ def measure(trainer, batch, args, ms_per_step):
         out["conv_shapes"] = [dict(op=k[0], N=k[1], Hin=k[2], Cin=k[4], Hout=k[5], Cout=k[7], k=k[8], s=k[10], d=k[12],
                                    calls=v["calls"], ms=round(v["ms"], 2),
                                    tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)) for k, v in top]
-    ig = [agg.get(n_) for n_ in MFMA_GROUPS["igemm"]]
-    ig = [x for x in ig if x]
+    ig = [(n_, agg.get(n_)) for n_ in MFMA_GROUPS["igemm"]]
+    pipe = sum(x["flops"] * piece_products(n_) for n_, x in ig if x)
+    ig = [x for _, x in ig if x]
     if ig:
         fl, t_ev, n = sum(x["flops"] for x in ig), sum(x["ms"] for x in ig), sum(x["calls"] for x in ig)
         nker = sum(x["kernels"] for x in ig)
         t = dense.get("igemm", t_ev)      # sustained-load time (dense replay); the gapped per-call events read shorter
         ach = fl / (t * 1e-3) / 1e12
         out["roofline"] = {"kernel": "k_igemm_ws / k_conv_igemm (direct conv fwd [+BN-stat / eval-BN epilogue] + dgrad, and the batched Winograd component GEMMs; executed fp32 FLOPs)", "bound": "mfma",
-                           "achieved": round(ach, 2), **_mfma_fields(ach), "unit": "TFLOP/s", "traffic": None,
+                           "achieved": round(ach, 2), **_mfma_fields(ach, pipe, fl), "unit": "TFLOP/s", "traffic": None,
                            "abi_calls_per_step": n, "kernel_launches_per_step": nker, "avg_launch_ms": round(t / max(nker, 1), 4),
                            "avg_abi_call_ms": round(t / n, 4),
                            "executed_tflop_per_step": round(fl / 1e12, 3), "ms_per_step": round(t, 2),
@@ -325,14 +355,16 @@ def measure(trainer, batch, args, ms_per_step):
                                 "ms_per_step": round(t, 2), "executed_tflop_per_step": round(fl / 1e12, 3),
                                 "note": "fp32 activations / weights are read from HBM and rounded on the way into LDS: these "
                                         "launches are HBM / LDS bound long before the 2.5 PFLOP/s matrix-core peak"}
-    wgs = [x for x in (agg.get("u2pl_conv2d_wgrad_f32"), agg.get("u2pl_wgrad_batched_f32")) if x]
+    wgs = [(n_, agg.get(n_)) for n_ in MFMA_GROUPS["wgrad"]]
+    wpipe = sum(x["flops"] * piece_products(n_) for n_, x in wgs if x)
+    wgs = [x for _, x in wgs if x]
     wg = dict(flops=sum(x["flops"] for x in wgs), ms=sum(x["ms"] for x in wgs), calls=sum(x["calls"] for x in wgs),
               kernels=sum(x["kernels"] for x in wgs)) if wgs else None
     if wg:
         wg["ms"] = dense.get("wgrad", wg["ms"])
         ach = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
         out["roofline_wgrad"] = {"kernel": "k_conv_wgrad (direct, + ordered slab reduce; and the batched Winograd component products; executed FLOPs)", "bound": "mfma",
-                                 "achieved": round(ach, 2), **_mfma_fields(ach), "unit": "TFLOP/s", "traffic": None,
+                                 "achieved": round(ach, 2), **_mfma_fields(ach, wpipe, wg["flops"]), "unit": "TFLOP/s", "traffic": None,
                                  "abi_calls_per_step": wg["calls"], "kernel_launches_per_step": wg["kernels"],
                                  "ms_per_step": round(wg["ms"], 2)}
     B, H, W = ll.shape
@@ -376,7 +408,7 @@ def measure(trainer, batch, args, ms_per_step):
         if tr.get("kernel_sources_sha") != sha:
             # a PMC record of OTHER kernel sources is not this build's traffic: refuse it rather than quote a stale number
             out["roofline"]["traffic_source"] = ("none: profiles/%s was taken with kernel sources %s (commit %s), this build is %s; "
-                                                 "re-run tools/run_r5_profiles.sh" % (os.path.basename(tj), tr.get("kernel_sources_sha", "?"),
+                                                 "re-run tools/run_r6_profiles.sh" % (os.path.basename(tj), tr.get("kernel_sources_sha", "?"),
                                                                                       tr.get("commit", "?"), sha))
             if "roofline_hbm" in out:
                 out["roofline_hbm"]["traffic_source"] = out["roofline"]["traffic_source"]

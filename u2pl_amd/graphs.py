@@ -20,6 +20,7 @@ Buffers a graph reads by address and that are rebuilt in place between replays (
 nn.presplit) need no handling; nn._derived refuses to (re)build or to wait on foreign events while capturing, which makes
 a stale operand abort the capture (the segment then runs eagerly and is captured at a later step)."""
 import os
+import warnings
 
 import torch
 import torch.distributed as dist
@@ -37,6 +38,25 @@ def enabled():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         return False
     return True
+
+
+_WARNED = set()
+
+
+def _capture_failed(name, ent, exc):
+    """a capture aborted: count it, say so ONCE per segment (with the exception: an OOM, an unjoined side stream or a real bug must
+    not disappear into a silent eager fallback -- ADVICE r5), and once more when the segment is pinned to eager for good"""
+    ent["failed"] = ent.get("failed", 0) + 1
+    STATS["aborted"] += 1
+    key = (name, ent["failed"] >= 2)
+    if key not in _WARNED:
+        _WARNED.add(key)
+        warnings.warn("u2pl_amd.graphs: capture of segment '%s' aborted (%s: %s); %s" % (
+            name, type(exc).__name__, str(exc)[:300],
+            "the segment stays eager from now on" if ent["failed"] >= 2 else "running it eagerly, one more capture attempt follows"),
+            RuntimeWarning, stacklevel=3)
+    if os.environ.get("U2PL_GRAPH_DEBUG"):
+        raise exc
 
 
 def _bns(modules):
@@ -94,8 +114,14 @@ def _refresh_operands(ent, modules, owner):
 def _key(xs, modules):
     """what a captured segment is valid for: input shapes, train / eval mode, and the convolution algorithm switches (a graph
     recorded with Winograd kernels must not be replayed after U2PL_CONV_WINO / _BF16 / _SPLIT / _WS changed)"""
-    algo = tuple(sorted(K.CONV_ALGO.items())) + (K.CONV_WS["on"], K.CONV_H["on"], _lib.query("u2pl_conv_get_split"), K.FUSE_EVAL_BN)
-    return tuple((tuple(x.shape), x.dtype, x.device.index) for x in xs) + tuple(m.training for m in modules) + algo
+    algo = tuple(sorted(K.CONV_ALGO.items())) + (K.CONV_WS["on"], K.CONV_H["on"], _lib.query("u2pl_conv_get_split"), K.FUSE_EVAL_BN,
+                                                 K._WGRAD["enabled"], K.FUSE_BN_FINISH, K.FUSE_RES_GRAD)
+    # per-submodule state a recorded launch sequence depends on (ADVICE r5): every BatchNorm's train / eval flag (a frozen BN
+    # takes the eval kernels) and which parameters record gradients (no weight-gradient launches for a frozen layer)
+    bn = tuple(b.training for mod in modules for b in mod.modules() if isinstance(b, K.BatchNorm2d))
+    rg = tuple(p.requires_grad for mod in modules for p in mod.parameters())
+    return (tuple((tuple(x.shape), x.dtype, x.device.index) for x in xs) + tuple(m.training for m in modules) + algo
+            + (hash(bn), hash(rg)))
 
 
 class GraphedNoGrad:
@@ -122,6 +148,7 @@ class GraphedNoGrad:
                 ent["count"] += 1
                 return self._eager(xs)
             static_in = [x.clone() for x in xs]
+            K.prewarm_globals(self.modules, xs[0].device)     # process-lifetime caches must not be born in the graph's private pool
             n = self.uniforms(xs) if self.uniforms else 0
             u = torch.empty(n, device=xs[0].device) if n else None
             g = torch.cuda.CUDAGraph()
@@ -129,11 +156,8 @@ class GraphedNoGrad:
             try:
                 with cap, K.dropout_pool(u):
                     outs = self.fn(*static_in)
-            except Exception:
-                ent["failed"] = ent.get("failed", 0) + 1
-                STATS["aborted"] += 1
-                if os.environ.get("U2PL_GRAPH_DEBUG"):
-                    raise
+            except (_lib.HipError, RuntimeError) as e:       # (torch.AcceleratorError / OutOfMemoryError are RuntimeErrors)
+                _capture_failed(self.name, ent, e)
                 return self._eager(xs)
             ent.update(graph=g, static_in=static_in, outs=outs, bumps=cap.bumps, u=u)
             STATS["captures"] += 1
@@ -196,6 +220,7 @@ class GraphedTrain:
                 ent["count"] += 1
                 return self._eager(x)
             static_x = x.clone()
+            K.prewarm_globals([self.model], x.device)
             bns = _bns([self.model])
             fwd, bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             pool = torch.cuda.graph_pool_handle()
@@ -211,12 +236,9 @@ class GraphedTrain:
                 cap_b = _Capture(bwd, bns, pool)
                 with cap_b:
                     torch.autograd.backward(souts, gouts)
-            except Exception:
-                ent["failed"] = ent.get("failed", 0) + 1
-                STATS["aborted"] += 1
+            except (_lib.HipError, RuntimeError) as e:
                 K.wgrad_stream_sync()
-                if os.environ.get("U2PL_GRAPH_DEBUG"):
-                    raise
+                _capture_failed(self.name, ent, e)
                 return self._eager(x)
             ent.update(fwd=fwd, bwd=bwd, static_x=static_x, keys=keys, outs=souts, gouts=gouts, bumps=cap.bumps, u=u)
             STATS["captures"] += 2

@@ -752,6 +752,15 @@ class _ConvFn(torch.autograd.Function):
 _IDENT_BN = {}
 
 
+def prewarm_globals(modules, dev):
+    """allocate the process-lifetime caches a pass may touch (identity BatchNorm parameters of the fused gradient joins) OUTSIDE a
+    HIP-graph capture: born inside one they would live in the graph's private memory pool"""
+    for mod in modules:
+        for m in mod.modules():
+            if isinstance(m, Conv2d):
+                _identity_bn(m.in_channels, dev)
+
+
 def _identity_bn(C, dev):
     k = (C, str(dev))
     v = _IDENT_BN.get(k)
@@ -772,13 +781,23 @@ FUSE_RES_GRAD = os.environ.get("U2PL_NO_RES_GRAD_FUSION") is None
 
 
 class GradJoin:
-    __slots__ = ("left", "acc")
+    __slots__ = ("left", "acc", "armed")
 
     def __init__(self, n):
-        self.left, self.acc = n, None
+        self.left, self.acc, self.armed = n, None, False
+
+    def _check(self):
+        """end of the backward pass: every wired consumer must have reported -- otherwise a parked partial sum was dropped
+        (torch.autograd.grad on a sub-graph, a caller back-propagating through one head only)"""
+        if self.left > 0 and self.acc is not None:
+            raise HipError("GradJoin: %d wired consumer(s) never ran their backward -- the gradient of the shared input is "
+                           "incomplete (set U2PL_NO_RES_GRAD_FUSION=1 for partial backward passes)" % self.left)
 
     def settle(self, t, included=False):
         """t: this consumer's contribution (already containing `acc` when included) -> the tensor to return to autograd"""
+        if not self.armed:
+            self.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._check)
         if self.acc is not None and not included:
             t.add_(self.acc)
         self.left -= 1
@@ -1205,6 +1224,8 @@ FUSE_EVAL_BN = os.environ.get("U2PL_NO_EVAL_BN_FUSION") is None
 # model in one launch (eval_invstd)
 FUSE_BN_FINISH = os.environ.get("U2PL_NO_BN_FINISH_FUSION") is None
 _EVAL_INVSTD = {}
+import weakref  # noqa: E402
+_EVAL_PREP = weakref.WeakKeyDictionary()
 
 
 def _eval_invstd(bn, C, dev):
@@ -1232,7 +1253,7 @@ class eval_invstd:
         m = self.model
         bns = [b for b in m.modules() if isinstance(b, BatchNorm2d)]
         key = tuple(b.running_var.data_ptr() for b in bns)
-        prep = m.__dict__.get("_u2pl_evalprep")
+        prep = _EVAL_PREP.get(m)
         if prep is None or prep["key"] != key:
             if not bns or not bns[0].running_var.is_cuda:
                 self.ids = []
@@ -1248,8 +1269,10 @@ class eval_invstd:
                 views.append(out[off:off + b.num_features])
                 off += b.num_features
             from .hipops import h2d
-            prep = m.__dict__["_u2pl_evalprep"] = dict(key=key, bns=bns, out=out, views=views, total=total,
-                                                       jobs=h2d(torch.from_numpy(jobs.view(np.uint8).copy()), dev))
+            # (kept OUTSIDE the module -- a WeakKeyDictionary: torch.save(model) / deepcopy must not serialise device pointers, and a
+            # copied model gets a prep of its own)
+            prep = _EVAL_PREP[m] = dict(key=key, bns=bns, out=out, views=views, total=total,
+                                        jobs=h2d(torch.from_numpy(jobs.view(np.uint8).copy()), dev))
         call("u2pl_bn_eval_invstd_multi_f32", prep["jobs"], len(prep["bns"]), prep["total"])
         self.ids = [id(b) for b in prep["bns"]]
         for b, v in zip(prep["bns"], prep["views"]):

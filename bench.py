@@ -240,6 +240,15 @@ def main():
         calib = [synth_batch(args.batch, args.crop, C, dev, gc) for _ in range(2)]
         batches = calibrate(model, teacher, calib, batches, args.sharpen)
 
+    # every train_step of this process is counted (tools/parse_pmc_traffic.py divides a profiled run's loss-path traffic by it)
+    n_steps_total = [0]
+    _ts = trainer.train_step
+
+    def _counted_step(*a, **k):
+        n_steps_total[0] += 1
+        return _ts(*a, **k)
+    trainer.train_step = _counted_step
+
     def step(i):
         il, ll, iu = batches[i % len(batches)]
         _progress(step=i)
@@ -499,6 +508,7 @@ def main():
         out["abi_calls_per_step"] = round(calls_timed, 1)
         out["kernel_launches_issued_by_host_per_step"] = round(launches_timed, 1)
         out["graph_replays_per_step"] = round(replays_timed, 2)
+        out["train_steps_in_process"] = n_steps_total[0]
         out["graphs"] = dict(GR.STATS, enabled=GR.enabled(), warm=GR.WARM, priming_steps_before_warmup=priming,
                              segments="teacher eval pass, teacher train pass, student forward, student backward")
         if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N=1 only (the checker's port, never the product)

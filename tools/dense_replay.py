@@ -47,6 +47,8 @@ def main():
     names = RL.MFMA_GROUPS["igemm"]
     calls = [r for r in rec if r[0] in names]
     flops = sum(RL._conv_flops(r[0], r[1]) for r in calls)
+    # matrix-pipe FLOPs: executed fp32 FLOPs x piece products per fp32 product (3: split-fp16 launches, 6: the bf16-split ones)
+    pipe = sum(RL._conv_flops(r[0], r[1]) * RL.piece_products(r[0]) for r in calls)
     nker = sum(r[7] for r in calls)
     out = {}
     for rep in range(2):           # the LAST repetition is the one tools/parse_dense_trace.py evaluates
@@ -59,7 +61,8 @@ def main():
             r[4](*r[5], sp)
         e1.record()
         torch.cuda.synchronize()
-        out = dict(executed_tflop=flops / 1e12, hip_event_ms=e0.elapsed_time(e1), kernel_launches=nker, abi_calls=len(calls))
+        out = dict(executed_tflop=flops / 1e12, matrix_pipe_tflop=pipe / 1e12, piece_products_per_fp32_product=pipe / flops,
+                   hip_event_ms=e0.elapsed_time(e1), kernel_launches=nker, abi_calls=len(calls))
     out["tflops"] = out["executed_tflop"] / out["hip_event_ms"] * 1e3
     out["frac_of_157.3"] = out["tflops"] / 157.3
     print(json.dumps(out))

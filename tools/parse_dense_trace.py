@@ -18,8 +18,10 @@ def main(trace, meta, out=None):
     res = dict(kernel_launches=n, igemm_rows_in_trace=len(rows), span_ms=span_ms, sum_of_durations_ms=busy / 1e6,
                executed_tflop=m["executed_tflop"], tflops_from_span=m["executed_tflop"] / span_ms * 1e3,
                frac_from_span=m["executed_tflop"] / span_ms * 1e3 / 157.3,
-               frac_of_split_bound_from_span=m["executed_tflop"] / span_ms * 1e3 / (2500.0 / 6.0),
-               frac_of_split_bound_from_sum_of_durations=m["executed_tflop"] / (busy / 1e6) * 1e3 / (2500.0 / 6.0),
+               # against the pipe the instructions run on: matrix-pipe FLOPs (executed x piece products per product) over 2500 TF
+               piece_products_per_fp32_product=m.get("piece_products_per_fp32_product", 6.0),
+               frac_of_split_bound_from_span=m.get("matrix_pipe_tflop", 6.0 * m["executed_tflop"]) / span_ms * 1e3 / 2500.0,
+               frac_of_split_bound_from_sum_of_durations=m.get("matrix_pipe_tflop", 6.0 * m["executed_tflop"]) / (busy / 1e6) * 1e3 / 2500.0,
                frac_from_sum_of_durations=m["executed_tflop"] / (busy / 1e6) * 1e3 / 157.3,
                hip_event_ms=m["hip_event_ms"], frac_from_hip_events=m["frac_of_157.3"])
     print(json.dumps(res, indent=1))

@@ -101,8 +101,24 @@ __host__ __device__ static inline int split2_exp_bits(unsigned amax_bits) {
     return e > 126 ? 126 : e;          // (ex = 255 gives -114: a normal scale)
 }
 __device__ __forceinline__ float split2_scale(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+// The two pieces of a pair of values in FIVE instructions: written as fused multiply-adds with the power-of-two scale, the
+// compiler selects v_fma_mixlo_f16 / v_fma_mixhi_f16 -- fp32 sources, ONE rounding to fp16 -- for "fp16(x s)" and, with the first
+// piece as the fp16 addend, for "fp16(x s - h0)" (x s and the residual are exact, so these are the bits of the separate scale /
+// convert / subtract / convert sequence: 8 instructions).
+__device__ __forceinline__ unsigned split2_first(float lo, float hi, float s) {
+    f16x2_t v;
+    v[0] = (_Float16)__builtin_fmaf(lo, s, 0.0f);
+    v[1] = (_Float16)__builtin_fmaf(hi, s, 0.0f);
+    return *(unsigned*)&v;
+}
+__device__ __forceinline__ unsigned split2_second(float lo, float hi, float s, unsigned h0) {
+    const f16x2_t a = *(f16x2_t*)&h0;
+    f16x2_t v;
+    v[0] = (_Float16)__builtin_fmaf(lo, s, -(float)a[0]);
+    v[1] = (_Float16)__builtin_fmaf(hi, s, -(float)a[1]);
+    return *(unsigned*)&v;
+}
 __device__ __forceinline__ void split2_f16(float4 v, float s, uint2& p0, uint2& p1) {
-    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
-    p0 = make_uint2(pack2_f16(v.x, v.y), pack2_f16(v.z, v.w));
-    p1 = make_uint2(pack2_f16(v.x - f16_lo_f(p0.x), v.y - f16_hi_f(p0.x)), pack2_f16(v.z - f16_lo_f(p0.y), v.w - f16_hi_f(p0.y)));
+    p0 = make_uint2(split2_first(v.x, v.y, s), split2_first(v.z, v.w, s));
+    p1 = make_uint2(split2_second(v.x, v.y, s, p0.x), split2_second(v.z, v.w, s, p0.y));
 }

@@ -707,16 +707,12 @@ __device__ __forceinline__ void igemm_ws_body(
                     const float4 v = ra[nxt][k >> 1];
                     sp_l = (k & 1) ? v.z : v.x;
                     sp_h = (k & 1) ? v.w : v.y;
-                    if constexpr (NP == 2) { sp_l *= sa; sp_h *= sa; }
                 }
                 unsigned w;
                 if constexpr (ABL & 1) w = (__float_as_uint(sp_h) & 0xffff0000u) | (__float_as_uint(sp_l) >> 16);
-                else if constexpr (NP == 2) {
-                    w = pack2_f16(sp_l, sp_h);
-                    if constexpr (step == 0) {
-                        sp_l = sp_l - f16_lo_f(w);
-                        sp_h = sp_h - f16_hi_f(w);
-                    }
+                else if constexpr (NP == 2) {       // (conv_geom.h: v_fma_mixlo / mixhi, 2 + 3 instructions per value pair)
+                    if constexpr (step == 0) w = split2_first(sp_l, sp_h, sa);
+                    else w = split2_second(sp_l, sp_h, sa, (k & 1) ? pc[0].y : pc[0].x);
                 } else {
                     if constexpr (step == 0) w = pack2_bf16_first(sp_l, sp_h);      // (first piece: overflow guard, conv_geom.h)
                     else w = pack2_bf16(sp_l, sp_h);

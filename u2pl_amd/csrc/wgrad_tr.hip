@@ -232,19 +232,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_tr(const float* __restrict__ d
                         const float4 v = r[nxt][k >> 1];
                         sp_l = (k & 1) ? v.z : v.x;
                         sp_h = (k & 1) ? v.w : v.y;
-                        if constexpr (NP == 2) {
-                            const float sc = (k >> 1) < NLA ? s_dy : s_x;
-                            sp_l *= sc;
-                            sp_h *= sc;
-                        }
                     }
                     unsigned w;
                     if constexpr (NP == 2) {
-                        w = pack2_f16(sp_l, sp_h);
-                        if constexpr (step == 0) {
-                            sp_l = sp_l - f16_lo_f(w);
-                            sp_h = sp_h - f16_hi_f(w);
-                        }
+                        const float sc = (k >> 1) < NLA ? s_dy : s_x;
+                        if constexpr (step == 0) w = split2_first(sp_l, sp_h, sc);
+                        else w = split2_second(sp_l, sp_h, sc, (k & 1) ? pc[0].y : pc[0].x);
                     } else {
                         w = step == 0 ? pack2_bf16_first(sp_l, sp_h) : pack2_bf16(sp_l, sp_h);
                         if constexpr (step < 2) {

@@ -21,108 +21,12 @@ import torch.nn as nn
 from . import _lib
 from ._lib import HipError, call, query
 
-_CL = torch.channels_last
-# collectives issued by this process since the last reset (bench.py reports them per step)
-COMM_STATS = {"syncbn_allreduce": 0, "bucket_allreduce": 0}
-# U2PL_COMM_DEBUG=1: every collective this process issues is logged as (kind, elements, group id) in issue order; a rank
-# whose sequence differs from rank 0's would deadlock or corrupt an RCCL communicator (collectives of one communicator must
-# be issued in the same order everywhere), so check_comm_sequence() compares the ranks' logs once per step and raises with the
-# first differing entry instead.
-COMM_DEBUG = {"on": os.environ.get("U2PL_COMM_DEBUG", "0") not in ("", "0"), "log": [], "issued": 0}
-
-
-def _all_reduce(t, kind, group=None, async_op=False, op=None):
-    """every all-reduce of this package (the memory bank's all-gathers in utils/utils.py are logged through note_collective)"""
-    COMM_STATS[kind] = COMM_STATS.get(kind, 0) + 1
-    COMM_DEBUG["issued"] += 1
-    if COMM_DEBUG["on"]:
-        COMM_DEBUG["log"].append((kind, int(t.numel()), 0 if group is None else id(group) & 0xffff))
-    kw = {} if op is None else {"op": op}
-    return dist.all_reduce(t, group=group, async_op=async_op, **kw)
-
-
-def note_collective(kind, numel):
-    """bookkeeping for a collective issued elsewhere in the package (the memory bank's key all-gathers)"""
-    COMM_STATS[kind] = COMM_STATS.get(kind, 0) + 1
-    COMM_DEBUG["issued"] += 1
-    if COMM_DEBUG["on"]:
-        COMM_DEBUG["log"].append((kind, int(numel), 0))
-
-
-def comm_sequence_digest():
-    """order-sensitive 62-bit hash of (kind, elements) of the logged collectives (the group id is process-local: left out)"""
-    h = 1469598103934665603
-    for kind, n, _ in COMM_DEBUG["log"]:
-        for b in (kind + ":" + str(n)).encode():
-            h = ((h ^ b) * 1099511628211) & ((1 << 62) - 1)
-    return h
-
-
-def check_comm_sequence(clear=True):
-    """(debug mode) all ranks must have issued the same sequence of collectives since the last check"""
-    if not (COMM_DEBUG["on"] and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-        if clear:
-            COMM_DEBUG["log"].clear()
-        return True
-    log = list(COMM_DEBUG["log"])
-    if clear:
-        COMM_DEBUG["log"].clear()
-    mine = torch.tensor([comm_sequence_digest() if not clear else _digest_of(log), len(log)], dtype=torch.int64)
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    mine = mine.to(dev)
-    allv = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
-    dist.all_gather(allv, mine)
-    vals = [tuple(int(v) for v in a.cpu()) for a in allv]
-    if any(v != vals[0] for v in vals):
-        logs = [None] * dist.get_world_size()
-        dist.all_gather_object(logs, [(k, n) for k, n, _ in log])
-        ref = logs[0]
-        for r, lg in enumerate(logs):
-            for i in range(max(len(ref), len(lg))):
-                a = ref[i] if i < len(ref) else None
-                b = lg[i] if i < len(lg) else None
-                if a != b:
-                    raise RuntimeError(f"collective sequence of rank {r} differs from rank 0 at #{i}: {b} vs {a} "
-                                       f"({len(lg)} vs {len(ref)} collectives this step)")
-    return True
-
-
-def _digest_of(log):
-    h = 1469598103934665603
-    for kind, n, _ in log:
-        for b in (kind + ":" + str(n)).encode():
-            h = ((h ^ b) * 1099511628211) & ((1 << 62) - 1)
-    return h
-
-
-# ------------------------------------------------------------------ layout helpers
-def as_rows(t):
-    """logical (N,C,H,W) -> (tensor, ld) such that pixel p / channel c lives at
-    base + p*ld + c.  Accepts channels_last tensors and channel slices of them
-    (ld = row pitch of the parent buffer); anything else is re-laid-out once."""
-    if t.dtype != torch.float32 or not t.is_cuda:
-        raise HipError("u2pl_amd layers need float32 GPU tensors (no CPU fallback)")
-    N, C, H, W = t.shape
-    if H * W == 1:
-        return t.reshape(N, C).contiguous().reshape(N, C, 1, 1), C
-    ld = t.stride(3)
-    ok = t.stride(1) == 1 and ld >= C and t.stride(2) == W * ld and t.stride(0) == H * W * ld
-    if not ok:
-        t = t.contiguous(memory_format=_CL)
-        ld = C
-    return t, ld
-
-
-def new_act(N, C, H, W, device):
-    return torch.empty((N, C, H, W), dtype=torch.float32, device=device, memory_format=_CL)
-
-
-def _ws(nbytes, device):
-    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
-
-
-def _world():
-    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+from .comm import (COMM_DEBUG, COMM_STATS, _all_reduce, _digest_of, _world, check_comm_sequence, comm_sequence_digest,  # noqa: F401
+                   note_collective)
+from .layout import _CL, _ws, as_rows, new_act  # noqa: F401
+from .operands import (AMAX_STATS, CONV_H, CONV_WS, PRESPLIT, WEIGHT_EPOCH, _AMAX_POOL, _DerivedCache, _derived, _split_of,  # noqa: F401
+                       _weight_stamp, _ws_ok, amax_of, amax_pool_reset, amax_slot, bump_weight_epoch, invalidate_weights, presplit,
+                       set_amax, ws_dgrad, ws_forward, ws_wino)
 
 
 # Weight-gradient kernels are leaves of the backward graph: they run on a side HIP stream so the
@@ -179,278 +83,6 @@ def _mark_ready(sink):
 # teacher (no_grad calls) and the 3-channel stem stay fp32.  Never the default: the headline is the reference's fp32.
 CONV_ALGO = {"wino": int(os.environ.get("U2PL_CONV_WINO", "4")), "min_gain": float(os.environ.get("U2PL_WINO_MIN_GAIN", "1.7")),
              "wgrad": int(os.environ.get("U2PL_WINO_WGRAD", "1")), "bf16": int(os.environ.get("U2PL_CONV_BF16", "0"))}
-
-
-# ---- weight operands derived once per step ------------------------------------------------------------------
-# The convolutions read each weight ~14 times per step (two student + two teacher passes, the backward) but the weights
-# change ONCE per step (optimizer / EMA update on the flat arenas): the operands the kernels want -- the three bf16 piece
-# planes of the split-fp32 arithmetic (u2pl_weight_split3_f32, consumed by the *_ws entry points of csrc/igemm_ws.hip), of
-# the weight itself (forward), of its transpose (data gradient) and of its Winograd transforms -- are built on first use
-# and kept until the weights change.  A cached operand is valid for (WEIGHT_EPOCH, tensor._version): the arena updates
-# (ParamArena.sgd_step / adam_step / ema_from / copy_from write through raw pointers) bump the epoch, every torch in-place
-# op (load_state_dict, init) bumps the version.  U2PL_CONV_WS=0 keeps every layer on conv.hip's in-loop split.
-WEIGHT_EPOCH = [0]
-CONV_WS = {"on": os.environ.get("U2PL_CONV_WS", "1") != "0"}
-
-
-def bump_weight_epoch(arena=None):
-    """the weights changed through raw pointers: every weight (arena None) or the parameters of one ParamArena (each arena
-    counts its own updates: the student's optimizer step must not invalidate the teacher's operands and vice versa)"""
-    if arena is None:
-        WEIGHT_EPOCH[0] += 1
-    else:
-        arena.epoch[0] += 1
-
-
-def _weight_stamp(weight):
-    ep = getattr(weight, "_u2pl_epoch", None)
-    return (WEIGHT_EPOCH[0], ep[0] if ep is not None else 0, weight._version, weight.data_ptr())
-
-
-class _DerivedCache(dict):
-    """per-weight cache of derived operands (device buffers, HIP events, streams).  It hangs in the Parameter's __dict__, which
-    Parameter.__reduce_ex__ pickles: it pickles as EMPTY (torch.save(model) / multiprocessing keep working; the operands are
-    rebuilt on first use) -- ADVICE r4, low"""
-
-    def __reduce__(self):
-        return (_DerivedCache, ())
-
-
-def invalidate_weights(arena=None):
-    """Call after writing weights through a path the stamps cannot see -- ``p.data.<op>_()``, raw writes into ``arena.flat`` --
-    i.e. anything other than the arena's own sgd_step / adam_step / ema_from / copy_from (they do this themselves) and
-    ordinary torch in-place ops on the Parameter (they bump ``_version``): every cached bf16 plane of the arena's parameters
-    (all parameters when arena is None) is rebuilt on next use."""
-    bump_weight_epoch(arena)
-
-
-def _derived(weight, kind, nbytes, build):
-    """-> device buffer (uint8) of `nbytes`, filled by build(buf) when the weight changed since it was last built.  The
-    buffer hangs on the weight tensor OBJECT (it dies with it: a freed weight's address can be handed to another tensor),
-    is allocated once per (weight, kind) and rebuilt in place; readers on other streams wait for the build event, a
-    rebuild waits for the streams that read the previous contents."""
-    cache = weight.__dict__.get("_u2pl_derived")
-    if cache is None:
-        cache = weight.__dict__["_u2pl_derived"] = _DerivedCache()
-    stamp = _weight_stamp(weight)
-    ent = cache.get(kind)
-    cur = torch.cuda.current_stream()
-    if _lib.CAPTURING[0]:
-        # inside a HIP-graph capture (u2pl_amd.graphs): the operand must already be current -- it is rebuilt IN PLACE by presplit()
-        # right after every optimizer / EMA update, on the stream the replay is launched on, so the graph reads the fresh planes
-        # by address; an event of another stream cannot be waited for inside a capture and a rebuild recorded into the graph
-        # would leave the host-side stamps behind
-        if ent is None or ent["stamp"] != stamp:
-            raise HipError("derived weight operand '%s' is stale during graph capture (the segment runs eagerly once more)" % kind)
-        return ent["buf"]
-    if ent is None or ent["buf"].numel() != max(int(nbytes), 16) or ent["buf"].device != weight.device:
-        ent = cache[kind] = {"buf": torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=weight.device), "stamp": None,
-                             "event": torch.cuda.Event(), "stream": cur, "readers": set()}
-    if ent["stamp"] != stamp:
-        for st in ent["readers"]:
-            cur.wait_stream(st)
-        if ent["stream"] != cur and ent["stamp"] is not None:
-            cur.wait_stream(ent["stream"])
-        ent["readers"] = set()
-        build(ent["buf"])
-        ent["event"].record(cur)
-        ent["stream"], ent["stamp"] = cur, stamp
-    elif ent["stream"] != cur and cur not in ent["readers"]:
-        cur.wait_event(ent["event"])
-        ent["readers"].add(cur)
-    return ent["buf"]
-
-
-# ---- split-fp16 (round 6, csrc/conv_geom.h): the pre-split GEMMs with THREE fp16 piece products per fp32 product ------------------
-# Each operand is scaled per tensor by a power of two taken from its largest magnitude.  Weights: the split kernels compute the
-# maxima themselves.  Activations / gradients: the kernel that PRODUCES a GEMM operand (BatchNorm apply / backward apply, the
-# Winograd input and gradient transforms) leaves max |output| in a device scalar as it writes -- carried to the consumer as a
-# Python attribute of the tensor, valid for the tensor's version counter -- and any operand without a current maximum gets one
-# stand-alone pass (u2pl_absmax_f32).  U2PL_CONV_H=0: the six-product bf16 form of rounds 3-5 everywhere.
-CONV_H = {"on": os.environ.get("U2PL_CONV_H", "1") != "0"}
-AMAX_STATS = {"fused": 0, "standalone": 0}
-_AMAX_POOL = {}
-
-
-def amax_pool_reset():
-    """forget the current slot chunks (u2pl_amd.graphs calls this when a capture begins and ends: a captured segment must zero
-    the slots it uses inside the graph, eager code must not take slots from a graph's private pool)"""
-    _AMAX_POOL.clear()
-
-
-_AMAX_WORDS = [0]
-
-
-def amax_slot(dev):
-    """a zeroed "amax object" (include/u2pl_hip.h: u2pl_amax_words() floats, 64 shards on separate 128-byte lines); objects come
-    out of 128-object chunks zeroed by ONE fill on the stream that uses them (each object is written once; a chunk lives as long
-    as a tensor refers to one of its objects)"""
-    if not _AMAX_WORDS[0]:
-        _AMAX_WORDS[0] = query("u2pl_amax_words")
-    n = _AMAX_WORDS[0]
-    key = _lib.stream_ptr()
-    p = _AMAX_POOL.get(key)
-    if p is None or p[1] >= 128 or p[0].device != dev:
-        p = _AMAX_POOL[key] = [torch.zeros(128 * n, dtype=torch.float32, device=dev), 0]
-    s = p[0][p[1] * n:(p[1] + 1) * n]
-    p[1] += 1
-    return s
-
-
-def set_amax(t, slot):
-    t._u2pl_amax = (slot, t._version)
-    AMAX_STATS["fused"] += 1
-
-
-def amax_of(t, rows=None, ld=None):
-    """amax object holding max |t|: the producer's fused maximum when `t` carries a current one, else one pass over it"""
-    ent = getattr(t, "_u2pl_amax", None)
-    if ent is not None and ent[1] == t._version:
-        return ent[0]
-    if rows is None:
-        rows, ld = as_rows(t)
-    N, C, H, W = rows.shape
-    a = amax_slot(rows.device)
-    call("u2pl_absmax_f32", rows, ld, N * H * W, C, a, 0)
-    t._u2pl_amax = (a, t._version)
-    AMAX_STATS["standalone"] += 1
-    return a
-
-
-def _ws_ok(n_cols, k_depth):
-    """can this GEMM (n_cols output channels, reduction depth k_depth) take the pre-split-weight kernel?"""
-    # (config 5: the STUDENT's bf16-operand calls never ask -- their call sites test ctx.bf / use_bf first -- so the fp32 teacher
-    # keeps the pre-split kernels there too)
-    return CONV_WS["on"] and n_cols > 64 and k_depth % 32 == 0 and query("u2pl_conv_get_split") == 1
-
-
-def _split_of(weight, kind, rows, K, batch, src, spec, h=None):
-    """split planes of `batch` matrices [rows][K]; src() -> the fp32 source tensor (a temporary is fine); spec: how presplit()
-    rebuilds the same planes in its batched launches.  h (default CONV_H): two fp16 piece planes + the matrices' maxima
-    (u2pl_weight_split2h_f32) instead of three bf16 ones; cached under its own kind."""
-    h = CONV_H["on"] if h is None else h
-    nbytes = query("u2pl_weight_split2h_bytes" if h else "u2pl_weight_split3_bytes", rows, K, batch)
-
-    def build(buf):
-        w = src()
-        if h:
-            call("u2pl_weight_split2h_f32", w, rows * K, rows, K, batch, buf, torch.empty(64, dtype=torch.uint8, device=buf.device))
-        else:
-            call("u2pl_weight_split3_f32", w, rows * K, rows, K, batch, buf)
-    kind = kind + ("h" if h else "")
-    buf = _derived(weight, kind, nbytes, build)
-    ent = weight.__dict__["_u2pl_derived"][kind]
-    if "spec" not in ent:
-        ent["spec"] = dict(spec, rows=rows, K=K, batch=batch, h=bool(h))
-    return buf
-
-
-def ws_forward(weight, h=None):
-    Cout, Cin, R, S = weight.shape
-    return _split_of(weight, "f", Cout, R * S * Cin, 1, lambda: weight, dict(how="plain"), h)
-
-
-def ws_dgrad(weight, h=None):
-    Cout, Cin, R, S = weight.shape
-
-    def src():
-        wT = torch.empty(Cin * R * S * Cout, dtype=torch.float32, device=weight.device)
-        call("u2pl_weight_transpose_f32", weight, wT, Cout, R * S, Cin)
-        return wT
-    return _split_of(weight, "d", Cin, R * S * Cout, 1, src, dict(how="transposed", RS=R * S), h)
-
-
-def ws_wino(weight, transposed, mt, h=None):
-    Cout, Cin = weight.shape[:2]
-    a2 = (mt + 2) ** 2
-    rows, K = (Cin, Cout) if transposed else (Cout, Cin)
-
-    def src():
-        U = torch.empty(a2 * Cout * Cin, dtype=torch.float32, device=weight.device)
-        call("u2pl_wino_weight_f32", weight, Cout, Cin, int(transposed), mt, U)
-        return U
-    return _split_of(weight, ("wd" if transposed else "wf") + str(mt), rows, K, a2, src,
-                     dict(how="wino", transposed=int(transposed), mt=mt, O=Cout, C=Cin), h)
-
-
-# ---- all derived operands of a model rebuilt in two launches ----------------------------------------------------
-# The lazy path above costs two to four tiny launches per weight and step (~660 per step for student + teacher: transposes,
-# Winograd filter transforms, splits).  After the first step every operand a model uses is known: presplit(params), called
-# by the arena right after its optimizer / EMA kernel, rebuilds ALL stale ones with one u2pl_wino_weight_multi_f32 and one
-# u2pl_weight_split3_multi_f32 launch (job tables on the device, re-uploaded only when the set of operands changes) and
-# stamps them current, so the layer calls of the next step find them valid.  Same bits as the lazy path (tested).
-# U2PL_PRESPLIT=0: off.
-PRESPLIT = {"on": os.environ.get("U2PL_PRESPLIT", "1") != "0", "tables": {}}
-
-
-def presplit(params, owner=None):
-    import numpy as np
-    if not (PRESPLIT["on"] and CONV_WS["on"]):
-        return 0
-    todo = []
-    for w in params:
-        cache = w.__dict__.get("_u2pl_derived")
-        if not cache:
-            continue
-        stamp = _weight_stamp(w)
-        for kind, ent in cache.items():
-            if "spec" in ent and ent["stamp"] is not None and ent["stamp"] != stamp:
-                todo.append((w, ent, stamp))
-    if not todo:
-        return 0
-    cur = torch.cuda.current_stream()
-    for st in {s_ for _, e, _ in todo for s_ in (list(e["readers"]) + [e["stream"]]) if s_ != cur}:
-        cur.wait_stream(st)          # nobody reads the old planes any more, the previous build is complete
-    todo.sort(key=lambda t_: bool(t_[1]["spec"].get("h")))           # the bf16-plane jobs first, then the fp16-plane ones
-    n_plain = sum(1 for _, e, _ in todo if not e["spec"].get("h"))
-    key = tuple((w.data_ptr(), e["buf"].data_ptr(), e["spec"]["how"], bool(e["spec"].get("h"))) for w, e, _ in todo)
-    tab = PRESPLIT["tables"].get(id(owner))
-    if tab is None or tab["key"] != key:
-        dev = todo[0][0].device
-        sj = np.zeros(len(todo), dtype=np.dtype([("src", "<u8"), ("out", "<u8"), ("seg", "<i8"), ("rows", "<i4"), ("Np", "<i4"),
-                                                 ("K", "<i4"), ("kind", "<i4"), ("RS", "<i4"), ("batch", "<i4")]))
-        wino = [(w, e) for w, e, _ in todo if e["spec"]["how"] == "wino"]
-        wj = np.zeros(max(len(wino), 1), dtype=np.dtype([("w", "<u8"), ("U", "<u8"), ("begin", "<i8"), ("O", "<i4"), ("C", "<i4"),
-                                                         ("tr", "<i4"), ("mt", "<i4")]))
-        # one scratch arena for the Winograd-domain filters (read by the split launch right behind the transform launch)
-        u_off, acc = {}, 0
-        for w, e in wino:
-            sp = e["spec"]
-            u_off[id(e)] = acc
-            acc += sp["batch"] * sp["rows"] * sp["K"]
-        scratch = torch.empty(max(acc, 1), dtype=torch.float32, device=dev)
-        begin = 0
-        for i, (w, e) in enumerate(wino):
-            sp = e["spec"]
-            wj[i] = (w.data_ptr(), scratch.data_ptr() + 4 * u_off[id(e)], begin, sp["O"], sp["C"], sp["transposed"], sp["mt"])
-            begin += sp["O"] * sp["C"]
-        seg, segs = 0, [0, 0]
-        for i, (w, e, _) in enumerate(todo):
-            sp = e["spec"]
-            if i == n_plain:
-                seg = 0                 # (the fp16-plane jobs form a table of their own: segment numbers restart)
-            Np = query("u2pl_weight_split3_pad_rows", sp["rows"])
-            src = scratch.data_ptr() + 4 * u_off[id(e)] if sp["how"] == "wino" else w.data_ptr()
-            sj[i] = (src, e["buf"].data_ptr(), seg, sp["rows"], Np, sp["K"], 1 if sp["how"] == "transposed" else 0,
-                     sp.get("RS", 1), sp["batch"])
-            seg += sp["batch"] * Np * (sp["K"] // 8)
-            segs[int(i >= n_plain)] = seg
-        sj_dev = torch.from_numpy(sj.view(np.uint8).copy()).to(dev)
-        tab = PRESPLIT["tables"][id(owner)] = dict(
-            key=key, scratch=scratch, n_plain=n_plain, n_h=len(todo) - n_plain, seg=segs[0], seg_h=segs[1], n_wino=len(wino),
-            wino_total=begin, sj=sj_dev, sj_h=sj_dev[n_plain * sj.dtype.itemsize:],
-            wj=torch.from_numpy(wj.view(np.uint8).copy()).to(dev))
-    if tab["n_wino"]:
-        call("u2pl_wino_weight_multi_f32", tab["wj"], tab["n_wino"], tab["wino_total"])
-    if tab["n_plain"]:
-        call("u2pl_weight_split3_multi_f32", tab["sj"], tab["n_plain"], tab["seg"])
-    if tab["n_h"]:
-        call("u2pl_weight_split2h_multi_f32", tab["sj_h"], tab["n_h"], tab["seg_h"])
-    ev = torch.cuda.Event()
-    ev.record(cur)
-    for w, e, stamp in todo:
-        e["event"], e["stream"], e["stamp"], e["readers"] = ev, cur, stamp, set()
-    return len(todo)
 
 
 def wino_tile(Cin, Cout, R, S, stride, pad, dil, H, W):
@@ -797,7 +429,10 @@ class GradJoin:
         """t: this consumer's contribution (already containing `acc` when included) -> the tensor to return to autograd"""
         if not self.armed:
             self.armed = True
-            torch.autograd.Variable._execution_engine.queue_callback(self._check)
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self._check)
+            except RuntimeError:        # (called outside a backward pass -- host-logic tests: there is no pass whose end to check)
+                pass
         if self.acc is not None and not included:
             t.add_(self.acc)
         self.left -= 1
@@ -1613,180 +1248,4 @@ class _CatFn(torch.autograd.Function):
 
 def cat_channels(tensors):
     return _CatFn.apply(*tensors)
-
-
-# ------------------------------------------------------------------ flat parameter arena
-class ParamArena:
-    """All parameters of a model in ONE flat fp32 buffer (+ a same-shaped flat
-    gradient buffer) so the SGD step, the teacher EMA and the DDP gradient
-    all-reduce are single launches over 66.8 M elements instead of ~1100 tiny
-    ones.  Parameter tensors become views of the arena; their
-    layer kernels accumulate weight gradients straight into the gradient view."""
-
-    def __init__(self, groups, with_grad=True):
-        """groups: list of lists of nn.Parameter (each group = one lr segment, kept contiguous)."""
-        self.params = [p for g in groups for p in g]
-        dev = self.params[0].device
-        ALIGN = 64          # every parameter starts on a 256-byte boundary (b128 loads/stores on weight views)
-        offs, self.bounds, acc = [], [], 0
-        for g in groups:
-            for p in g:
-                offs.append(acc)
-                acc += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
-            self.bounds.append(acc)
-        self.n = acc
-        # padding stays zero in every arena (zero grad, zero weight => SGD / EMA keep it zero)
-        self.flat = torch.zeros(self.n, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(self.n, dtype=torch.float32, device=dev) if with_grad else None
-        self._pidx = []
-        self.epoch = [0]            # raw-pointer updates of this arena (see bump_weight_epoch)
-        for p, off in zip(self.params, offs):
-            p._u2pl_epoch = self.epoch
-            n = p.numel()
-            view = self.flat[off:off + n].as_strided(p.shape, p.stride())
-            view.copy_(p.data)
-            p.data = view
-            if with_grad:
-                gv = self.grad[off:off + n].as_strided(p.shape, p.stride())
-                gv._u2pl_ready = (self, len(self._pidx))
-                self._pidx.append(off)
-                p._u2pl_grad = gv
-                p.grad = gv
-        self._build_buckets(offs, float(os.environ.get("U2PL_BUCKET_MB", "32")))
-        self.momentum_buf = None
-        self.steps = 0
-        self._offs = {id(p): off for p, off in zip(self.params, offs)}
-
-    def __getstate__(self):
-        # (reachable from a pickled Parameter through its gradient view: streams / in-flight collectives do not travel)
-        d = dict(self.__dict__)
-        d["_works"], d["_streams"] = [None] * len(d.get("_works", [])), ()
-        return d
-
-    def momentum_view(self, p):
-        """view of the momentum arena shaped / strided like parameter p (allocated on first use)"""
-        if self.momentum_buf is None:
-            self.momentum_buf = torch.zeros_like(self.flat)
-        off = self._offs[id(p)]
-        return self.momentum_buf[off:off + p.numel()].as_strided(p.shape, p.stride())
-
-    # ---- bucketed, overlapped gradient all-reduce (the reference gets this from DDP: train_semi.py:114-120) ----
-    def _build_buckets(self, offs, bucket_mb):
-        """contiguous slices of the gradient arena of ~bucket_mb each; backward produces gradients roughly from the end
-        of the arena towards its start, so the buckets complete one after the other while backward is still running"""
-        self.buckets, self._bucket_of = [], []
-        if self.grad is None:
-            return
-        lim = max(1, int(bucket_mb * (1 << 20) / 4))
-        lo, count = 0, 0
-        ends = offs[1:] + [self.n]
-        for i, end in enumerate(ends):
-            self._bucket_of.append(len(self.buckets))
-            count += 1
-            if end - lo >= lim or i == len(ends) - 1:
-                self.buckets.append([lo, end, count])
-                lo, count = end, 0
-        self._pending = [b[2] for b in self.buckets]
-        self._works = [None] * len(self.buckets)
-        self._next = len(self.buckets) - 1
-        self._streams = ()
-
-    def zero_grad(self):
-        self.grad.zero_()
-        if self.buckets:
-            self._pending = [b[2] for b in self.buckets]
-            self._works = [None] * len(self.buckets)
-            self._next = len(self.buckets) - 1
-            if self.grad.is_cuda:
-                # the stream the step (and therefore autograd's backward) runs on; the weight-gradient side stream is
-                # looked up LIVE in _launch -- it is created lazily by the first conv backward, i.e. after this call
-                self._streams = (torch.cuda.current_stream(),)
-
-    def _producer_streams(self):
-        """every stream that may still be writing into the gradient arena: the step's stream (BN / bias gradients,
-        autograd's accumulations) and the weight-gradient side stream, if it exists by now"""
-        ws = _WGRAD["stream"]
-        return tuple(self._streams) + ((ws,) if ws is not None else ())
-
-    def _launch(self, b):
-        lo, hi, _ = self.buckets[b]
-        if self.grad.is_cuda:       # the bucket's producers ran on the main stream (BN, bias) and on the wgrad side stream
-            cur = torch.cuda.current_stream()
-            for st in self._producer_streams():
-                if st != cur:
-                    cur.wait_stream(st)
-        self._works[b] = _all_reduce(self.grad[lo:hi], "bucket_allreduce", async_op=True)
-        _lib.SIDE_WORK.add("buckets")
-
-    def mark_ready(self, pidx):
-        if _world() <= 1 or not self.buckets or os.environ.get("U2PL_NO_BUCKET_OVERLAP") is not None:
-            return
-        self._pending[self._bucket_of[pidx]] -= 1
-        # Buckets go out in ONE fixed order (last bucket first, the order backward fills them), like DDP's reducer: the
-        # sequence of collectives on the communicator is then the same on every rank even when the ranks' autograd
-        # graphs differ at the top (a rank without contrastive anchors back-propagates 0 * rep.sum(), Q13).
-        while self._next >= 0 and self._pending[self._next] == 0:
-            self._launch(self._next)
-            self._next -= 1
-
-    def finish_allreduce(self):
-        """after backward: reduce whatever was not launched from the hooks (parameters without a gradient this step,
-        overlap disabled) and make the current stream wait for every bucket.  SUM; the mean is folded into sgd_step."""
-        if _world() <= 1:
-            return
-        if not self.buckets:
-            _all_reduce(self.grad, "bucket_allreduce")
-            return
-        while self._next >= 0:      # same descending order as the hooks
-            self._launch(self._next)
-            self._next -= 1
-        for w in self._works:
-            w.wait()
-        _lib.SIDE_WORK.discard("buckets")
-
-    def sgd_step(self, lrs, momentum, weight_decay, grad_scale=1.0):
-        """torch.optim.SGD(momentum, weight_decay) semantics with per-group lr."""
-        if self.momentum_buf is None:
-            self.momentum_buf = torch.zeros_like(self.flat)
-        b = self.bounds + [self.n] * 3
-        lr = list(lrs) + [lrs[-1]] * 3
-        bump_weight_epoch(self)
-        call("u2pl_sgd_step_f32", self.flat, self.grad, self.momentum_buf, self.n, b[0], b[1], float(lr[0]),
-             float(lr[1]), float(lr[2]), float(momentum), float(weight_decay), int(self.steps == 0),
-             float(grad_scale))
-        self.steps += 1
-        presplit(self.params, self)
-
-    def adam_step(self, lrs, betas, eps, weight_decay, grad_scale=1.0):
-        """torch.optim.Adam(betas, eps, weight_decay; amsgrad off) semantics with per-group lr (lr_helper.py:20-21)."""
-        if getattr(self, "exp_avg", None) is None:
-            self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
-        self.steps += 1
-        b = self.bounds + [self.n] * 3
-        lr = list(lrs) + [lrs[-1]] * 3
-        bc1 = 1.0 - betas[0] ** self.steps
-        bc2s = math.sqrt(1.0 - betas[1] ** self.steps)
-        bump_weight_epoch(self)
-        call("u2pl_adam_step_f32", self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.n, b[0], b[1], float(lr[0]),
-             float(lr[1]), float(lr[2]), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), float(bc1),
-             float(bc2s), float(grad_scale))
-        presplit(self.params, self)
-
-    def adam_views(self, p):
-        """(exp_avg, exp_avg_sq) views shaped / strided like parameter p (allocated on first use)"""
-        if getattr(self, "exp_avg", None) is None:
-            self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
-        off, n = self._offs[id(p)], p.numel()
-        return (self.exp_avg[off:off + n].as_strided(p.shape, p.stride()),
-                self.exp_avg_sq[off:off + n].as_strided(p.shape, p.stride()))
-
-    def ema_from(self, other, decay):
-        """self = decay*self + (1-decay)*other  (train_semi.py:543-548)."""
-        bump_weight_epoch(self)
-        call("u2pl_ema_update_f32", self.flat, other.flat, self.n, float(decay), float(1 - decay))
-        presplit(self.params, self)
-
-    def copy_from(self, other):
-        bump_weight_epoch(self)
-        self.flat.copy_(other.flat)
-        presplit(self.params, self)
+from .arena import ParamArena  # noqa: E402,F401

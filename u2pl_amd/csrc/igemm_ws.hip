@@ -609,7 +609,15 @@ __device__ __forceinline__ void igemm_ws_body(
 
     constexpr int PER = TM * TN, NMF = 2 * NPROD * PER;     // matrix instructions per 16-deep block product / per chunk
     constexpr int NRD = NP * (TM + TN);                     // operand reads per 16-deep block
-    constexpr int TAIL = 2 * PER;
+#ifndef U2PL_WS_TAILQ2
+#define U2PL_WS_TAILQ2 2
+#endif
+#ifndef U2PL_WS_F0PRE2
+#define U2PL_WS_F0PRE2 (TM + TN)
+#endif
+    // products of a chunk issued BEHIND its barrier, in front of the next chunk's (they cover the latency of the next chunk's first
+    // operand reads): two of the six piece products' worth at NP = 3; NP = 2: U2PL_WS_TAILQ2 x PER (<= 3 PER = all of k block 1)
+    constexpr int TAIL = (NP == 2 ? U2PL_WS_TAILQ2 : 2) * PER;
     Frag f[2];
     // matrix instruction I of a chunk: k block I / (6 PER), product (I / PER) % 6, accumulator I % PER
     auto do_mfma = [&](auto i_c) __attribute__((always_inline)) {
@@ -677,7 +685,7 @@ __device__ __forceinline__ void igemm_ws_body(
         //   NP == 2 (half the matrix instructions for 2/3 of the memory operations): the split starts at slot 0 (two steps per
         //   value pair: 7 + 1 VALU), the operand reads share its slots; where the plan would overrun the chunk the loads move up
         //   beside the weight-piece stores (a store precedes the load that refills its register in the same slot)
-        constexpr int F0_PRE = TM + TN, F0_PER = (NRD - F0_PRE + TAIL - 1) / TAIL;
+        constexpr int F0_PRE = NP == 2 ? (U2PL_WS_F0PRE2) : TM + TN, F0_PER = (NRD - F0_PRE + TAIL - 1) / TAIL;
         constexpr int SPS = NP, SP_N = SPS * 2 * RA;          // split steps per value pair; slots of the split
         constexpr int F1_START = TAIL, SP_START = NP == 3 ? TAIL : 0, BS_START = SP_START + SP_N;
         constexpr int LD_START = (BS_START + RBU + RBU + RA <= NMF) ? BS_START + RBU : NMF - RBU - RA;

@@ -50,6 +50,8 @@ def _mfma_fields(ach, pipe_flops=None, flops=None):
                 "frac_vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                 "piece_products_per_fp32_product": round(ratio, 3),
                 "matrix_pipe_tflops": round(ach * ratio, 1),
+                # the same fp32-equivalent rate against the bound rounds 3-5 quoted (six bf16 piece products: 2500 / 6 = 416.7 TF)
+                "frac_vs_six_product_bound": round(ach / PEAK_SPLIT_F32_TFLOPS, 4),
                 "arithmetic": "fp32 products on the 16-bit matrix cores, fp32 accumulate: THREE fp16 piece products of a two-piece "
                               "split of the power-of-two-scaled operands (v_mfma_f32_32x32x16_f16; default since round 6, "
                               "csrc/conv_geom.h) or SIX bf16 piece products of an exact three-piece split "

@@ -624,6 +624,16 @@ class _BNFn(torch.autograd.Function):
 # bottleneck of every ResNet stage, bn3 and the downsample BatchNorm (resnet.py:120-140).  Each group exchanges ONE packed
 # buffer forward and one backward instead of one all-reduce per layer.  Only used in train mode under a
 # process group with sync=True; everything else goes through _BNFn unit by unit (the single-GPU path is untouched).
+def _bn_apply(x, ldx, mean, invstd, gamma, beta, res, ldr, relu, drop, hw, y, ldy, M, C):
+    """u2pl_bn_apply_f32; with split-fp16 on, the form that leaves max |y| for the convolutions that read y"""
+    if CONV_H["on"]:
+        y_amax = amax_slot(y.device)
+        call("u2pl_bn_apply_amax_f32", x, ldx, mean, invstd, gamma, beta, res, ldr, relu, drop, hw, y, ldy, M, C, y_amax)
+        set_amax(y, y_amax)
+    else:
+        call("u2pl_bn_apply_f32", x, ldx, mean, invstd, gamma, beta, res, ldr, relu, drop, hw, y, ldy, M, C)
+
+
 def _bn_local_sums(x, ldx, M, C, mod, pre_sums, out):
     """pivot-shifted sums of one BatchNorm into out (double [2C+1], slot 2C = the local row count)"""
     if pre_sums is not None:
@@ -690,7 +700,7 @@ class _BNGroupFn(torch.autograd.Function):
             mean, invstd = _bn_finalize(packed[off:off + 2 * C + 1], count, mod, C, dev)
             off += 2 * C + 1
             y = new_act(N, C, H, W, dev)
-            call("u2pl_bn_apply_f32", x, ldx, mean, invstd, gamma, None if beta is None else beta, None, 0, int(relu), drop, H * W, y, C, M, C)
+            _bn_apply(x, ldx, mean, invstd, gamma, None if beta is None else beta, None, 0, int(relu), drop, H * W, y, C, M, C)
             outs.append(y)
             saved += [x, y if relu else None, mean, invstd, gamma, drop]
             ctx.meta.append((N, C, H, W, ldx, count, gs, bs))
@@ -751,7 +761,7 @@ class _BNResPairFn(torch.autograd.Function):
         ident = new_act(N, C, H, W, dev)
         call("u2pl_bn_apply_f32", xb, ldb, mean_b, inv_b, gb, bb, None, 0, 0, None, H * W, ident, C, M, C)
         y = new_act(N, C, H, W, dev)
-        call("u2pl_bn_apply_f32", xa, lda, mean_a, inv_a, ga, ba, ident, C, 1, None, H * W, y, C, M, C)
+        _bn_apply(xa, lda, mean_a, inv_a, ga, ba, ident, C, 1, None, H * W, y, C, M, C)
         ctx.save_for_backward(xa, xb, y, mean_a, inv_a, mean_b, inv_b, ga, gb)
         ctx.meta = (N, C, H, W, lda, ldb, count, gsa, bsa, gsb, bsb, mod_a.group)
         return y

@@ -334,7 +334,13 @@ int u2pl_bn_apply_amax_f32(const float* x, long ldx, const float* mean, const fl
 int u2pl_bn_bwd_apply_amax_f32(const float* dy, long lddy, const float* x, long ldx, const float* y, long ldy, const float* mean,
                                const float* invstd, const float* gamma, const float* drop, long rows_per_image, const double* sums,
                                double count, float* dx, long lddx, float* dres, long lddr, long M, int C, const double* psums,
-                               float* gsink, float* bsink, int accumulate, float* dx_amax, float* dres_amax, hipStream_t stream);
+                               float* gsink, float* bsink, int accumulate, float* dx_amax, float* dres_amax, const float* relu_beta,
+                               hipStream_t stream);
+/* y = relu(BN(x)) without a residual: the backward's ReLU mask recomputed from x with the forward's own expression (same bits as
+ * [y > 0]) instead of read from y -- u2pl_bn_bwd_sums_f32 / the apply above with y == NULL and relu_beta = the layer's beta */
+int u2pl_bn_bwd_sums_mx_f32(const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* invstd,
+                            const float* gamma, const float* beta, const float* drop, long rows_per_image, long M, int C,
+                            void* workspace, double* sums, hipStream_t stream);
 int u2pl_wino_input_amax_f32(const float* x, long ldx, int N, int H, int W, int C, int dil, int mt, float* V, float* v_amax,
                              hipStream_t stream);
 int u2pl_wino_output_bnact_amax_f32(const float* Mb, int N, int H, int W, int O, int dil, int mt, const float* bias, float* y,

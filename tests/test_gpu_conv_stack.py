@@ -274,6 +274,44 @@ def test_split_fp16_twelve_decades_inside_one_tensor_meet_the_documented_absolut
         Kn.CONV_H.update(saved_h)
 
 
+@pytest.mark.parametrize("drop", [False, True])
+@pytest.mark.parametrize("conv_h", [True, False])
+def test_batchnorm_backward_relu_mask_recomputed_from_x_has_the_saved_masks_bits(drop, conv_h):
+    """y = relu(BN(x)) [* dropout scale] without a residual: the backward recomputes [y > 0] from x with the forward's own
+    expression instead of reading y (round 6) -- input gradient, dgamma, dbeta identical to the saved-y form, train and eval mode"""
+    Kn = K()
+    saved = (Kn.RELU_MASK_FROM_X, dict(Kn.CONV_H))
+    torch.manual_seed(12)
+    C, N, H, W = 96, 3, 21, 19
+    x0 = (torch.randn(N, C, H, W, device=DEV) * 2).contiguous(memory_format=CL)
+    gy = torch.randn(N, C, H, W, device=DEV).contiguous(memory_format=CL)
+    dscale = ((torch.rand(N, C, device=DEV) > 0.2).float() / 0.8) if drop else None
+    res = {}
+    try:
+        Kn.CONV_H["on"] = conv_h
+        for mode in ("train", "eval"):
+            for flag in (True, False):
+                Kn.RELU_MASK_FROM_X = flag
+                torch.manual_seed(13)               # (the same parameters in both runs)
+                bn = Kn.BatchNorm2d(C).to(DEV)
+                with torch.no_grad():
+                    bn.weight.normal_(1.0, 0.3)
+                    bn.bias.normal_(0.0, 0.5)
+                    bn.running_mean.normal_(0, 0.3)
+                    bn.running_var.uniform_(0.5, 2.0)
+                bn.train(mode == "train")
+                x = x0.clone().requires_grad_(True)
+                y = bn(x, relu=True, drop=dscale)
+                y.backward(gy)
+                torch.cuda.synchronize()
+                res[(mode, flag)] = (y.detach().clone(), x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
+            for a, b in zip(res[(mode, True)], res[(mode, False)]):
+                assert torch.equal(a, b), mode
+    finally:
+        Kn.RELU_MASK_FROM_X = saved[0]
+        Kn.CONV_H.update(saved[1])
+
+
 def test_conv_large_pixel_count_splitk():
     """many pixels (split-K wgrad with several slabs) and M not a multiple of the tile"""
     Kn = K()

@@ -31,18 +31,32 @@ struct SumOp {  // v0 = x, v1 = 0     (global average pool / bias gradient)
         v0 = *(const float4*)(x + row * ld + c4 * 4); v1 = f4zero();
     }
 };
+// the ReLU mask of y = relu((x - mean) * invstd * gamma + beta) recomputed from x: the forward's own expression (k_bn_apply, no
+// contraction), so the same bits and the same mask as [y > 0] -- without reading y (round 6: BatchNorms without a residual)
+__device__ __forceinline__ float4 relu_mask_from_x(float4 g, float4 xv, const float* mean, const float* invstd, const float* gamma,
+                                                   const float* beta, int c) {
+    const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c), ga = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
+    g.x = ((xv.x - mu.x) * is.x * ga.x + be.x) > 0.f ? g.x : 0.f;
+    g.y = ((xv.y - mu.y) * is.y * ga.y + be.y) > 0.f ? g.y : 0.f;
+    g.z = ((xv.z - mu.z) * is.z * ga.z + be.z) > 0.f ? g.z : 0.f;
+    g.w = ((xv.w - mu.w) * is.w * ga.w + be.w) > 0.f ? g.w : 0.f;
+    return g;
+}
 struct BnBwdOp {  // g = dy*[y>0]*drop ; v0 = g, v1 = g * xhat     (BN backward sums)
     const float* dy; long lddy; const float* x; long ldx; const float* y; long ldy;
     const float* mean; const float* invstd; const float* drop; long rows_per_image; int C;
+    const float* gamma; const float* relu_beta;         // y == NULL and relu_beta != NULL: the mask from x
     __device__ __forceinline__ void get(long row, int c4, float4& v0, float4& v1) const {
         float4 g = *(const float4*)(dy + row * lddy + c4 * 4);
+        float4 xv = *(const float4*)(x + row * ldx + c4 * 4);
         if (y) {
             float4 yy = *(const float4*)(y + row * ldy + c4 * 4);
             g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
             g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+        } else if (relu_beta) {
+            g = relu_mask_from_x(g, xv, mean, invstd, gamma, relu_beta, c4 * 4);
         }
         if (drop) g = f4mul(g, *(const float4*)(drop + (row / rows_per_image) * C + c4 * 4));
-        float4 xv = *(const float4*)(x + row * ldx + c4 * 4);
         float4 xh = f4mul(f4sub(xv, *(const float4*)(mean + c4 * 4)), *(const float4*)(invstd + c4 * 4));
         v0 = g; v1 = f4mul(g, xh);
     }
@@ -187,7 +201,15 @@ U2PL_API int u2pl_colsum_f32(const float* x, long ld, long Mseg, int nseg, int C
 U2PL_API int u2pl_bn_bwd_sums_f32(const float* dy, long lddy, const float* x, long ldx, const float* y, long ldy,
                                   const float* mean, const float* invstd, const float* drop, long rows_per_image,
                                   long M, int C, void* workspace, double* sums, hipStream_t stream) {
-    BnBwdOp op = {dy, lddy, x, ldx, y, ldy, mean, invstd, drop, rows_per_image, C};
+    BnBwdOp op = {dy, lddy, x, ldx, y, ldy, mean, invstd, drop, rows_per_image, C, nullptr, nullptr};
+    return run_colreduce(op, M, 1, C, workspace, sums, stream);
+}
+// the same for y = relu(BN(x)) WITHOUT reading y: the mask is recomputed from x (gamma, beta: the forward's parameters)
+U2PL_API int u2pl_bn_bwd_sums_mx_f32(const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* invstd,
+                                     const float* gamma, const float* beta, const float* drop, long rows_per_image, long M, int C,
+                                     void* workspace, double* sums, hipStream_t stream) {
+    if (!gamma || !beta) return U2PL_EINVAL;
+    BnBwdOp op = {dy, lddy, x, ldx, nullptr, 0, mean, invstd, drop, rows_per_image, C, gamma, beta};
     return run_colreduce(op, M, 1, C, workspace, sums, stream);
 }
 
@@ -370,7 +392,7 @@ __global__ U2PL_HBM_KERNEL void k_bn_bwd_apply(const float* __restrict__ dy, lon
                                const double* __restrict__ sums, double count, float* __restrict__ dx, long lddx,
                                float* __restrict__ dres, long lddr, long M, int C, const double* __restrict__ psums,
                                float* __restrict__ gsink, float* __restrict__ bsink, int accumulate,
-                               unsigned* __restrict__ dx_amax, unsigned* __restrict__ dres_amax) {
+                               unsigned* __restrict__ dx_amax, unsigned* __restrict__ dres_amax, const float* __restrict__ relu_beta) {
     unsigned am_x = 0u, am_r = 0u;
     if (psums) {   // (u2pl_bn_bwd_apply_pg_f32) the parameter gradients ride along: k_sums_to_f32's arithmetic, dgamma = S1, dbeta = S0
         for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < C; i += (long)gridDim.x * blockDim.x) {
@@ -388,6 +410,8 @@ __global__ U2PL_HBM_KERNEL void k_bn_bwd_apply(const float* __restrict__ dy, lon
             const float4 yy = *(const float4*)(y + r * ldy + c);
             g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
             g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+        } else if (relu_beta) {       // (y = relu(BN(x)) without a residual: the mask from x, see relu_mask_from_x)
+            g = relu_mask_from_x(g, *(const float4*)(x + r * ldx + c), mean, invstd, gamma, relu_beta, c);
         }
         if (drop) g = f4mul(g, *(const float4*)(drop + (r / rows_per_image) * C + c));
         if (dres) *(float4*)(dres + r * lddr + c) = g;
@@ -420,7 +444,7 @@ U2PL_API int u2pl_bn_bwd_apply_f32(const float* dy, long lddy, const float* x, l
     if (C % 4) return U2PL_EINVAL;
     U2PL_LAUNCH(k_bn_bwd_apply, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, dy, lddy, x, ldx, y, ldy,
                        mean, invstd, gamma, drop, rows_per_image, sums, count, dx, lddx, dres, lddr, M, C, (const double*)nullptr,
-                       (float*)nullptr, (float*)nullptr, 0, (unsigned*)nullptr, (unsigned*)nullptr);
+                       (float*)nullptr, (float*)nullptr, 0, (unsigned*)nullptr, (unsigned*)nullptr, (const float*)nullptr);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -434,7 +458,7 @@ U2PL_API int u2pl_bn_bwd_apply_pg_f32(const float* dy, long lddy, const float* x
     if (C % 4 || !psums || !gsink || !bsink) return U2PL_EINVAL;
     U2PL_LAUNCH(k_bn_bwd_apply, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, dy, lddy, x, ldx, y, ldy,
                        mean, invstd, gamma, drop, rows_per_image, sums, count, dx, lddx, dres, lddr, M, C, psums, gsink, bsink,
-                       accumulate, (unsigned*)nullptr, (unsigned*)nullptr);
+                       accumulate, (unsigned*)nullptr, (unsigned*)nullptr, (const float*)nullptr);
     U2PL_LAUNCH_CHECK();
     return 0;
 }
@@ -444,11 +468,11 @@ U2PL_API int u2pl_bn_bwd_apply_amax_f32(const float* dy, long lddy, const float*
                                         const float* mean, const float* invstd, const float* gamma, const float* drop,
                                         long rows_per_image, const double* sums, double count, float* dx, long lddx,
                                         float* dres, long lddr, long M, int C, const double* psums, float* gsink, float* bsink,
-                                        int accumulate, float* dx_amax, float* dres_amax, hipStream_t stream) {
-    if (C % 4 || (psums && (!gsink || !bsink))) return U2PL_EINVAL;
+                                        int accumulate, float* dx_amax, float* dres_amax, const float* relu_beta, hipStream_t stream) {
+    if (C % 4 || (psums && (!gsink || !bsink)) || (relu_beta && y)) return U2PL_EINVAL;
     U2PL_LAUNCH(k_bn_bwd_apply, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, stream, dy, lddy, x, ldx, y, ldy,
                        mean, invstd, gamma, drop, rows_per_image, sums, count, dx, lddx, dres, lddr, M, C, psums, gsink, bsink,
-                       accumulate, (unsigned*)dx_amax, (unsigned*)dres_amax);
+                       accumulate, (unsigned*)dx_amax, (unsigned*)dres_amax, relu_beta);
     U2PL_LAUNCH_CHECK();
     return 0;
 }

@@ -115,7 +115,7 @@ def _key(xs, modules):
     """what a captured segment is valid for: input shapes, train / eval mode, and the convolution algorithm switches (a graph
     recorded with Winograd kernels must not be replayed after U2PL_CONV_WINO / _BF16 / _SPLIT / _WS changed)"""
     algo = tuple(sorted(K.CONV_ALGO.items())) + (K.CONV_WS["on"], K.CONV_H["on"], _lib.query("u2pl_conv_get_split"), K.FUSE_EVAL_BN,
-                                                 K._WGRAD["enabled"], K.FUSE_BN_FINISH, K.FUSE_RES_GRAD)
+                                                 K._WGRAD["enabled"], K.FUSE_BN_FINISH, K.FUSE_RES_GRAD, K.RELU_MASK_FROM_X)
     # per-submodule state a recorded launch sequence depends on (ADVICE r5): every BatchNorm's train / eval flag (a frozen BN
     # takes the eval kernels) and which parameters record gradients (no weight-gradient launches for a frozen layer)
     bn = tuple(b.training for mod in modules for b in mod.modules() if isinstance(b, K.BatchNorm2d))

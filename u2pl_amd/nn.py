@@ -558,21 +558,28 @@ class _BNFn(torch.autograd.Function):
             set_amax(y, y_amax)
         else:
             call("u2pl_bn_apply_f32", x, ldx, mean, invstd, gamma, beta, rr, ldr or 0, int(relu), drop, H * W, y, C, M, C)
-        ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma, drop)
+        # backward's ReLU mask: [y > 0] read from y, or -- no residual -- recomputed from x with the forward's own expression (same
+        # bits; y is then neither saved nor read: 4 of 12-16 bytes per element in each of the two backward passes)
+        ctx.mask_from_x = bool(relu and res is None and RELU_MASK_FROM_X and beta is not None)
+        ctx.save_for_backward(x, y if (relu and not ctx.mask_from_x) else None, mean, invstd, gamma, drop,
+                              beta if ctx.mask_from_x else None)
         ctx.meta = (N, C, H, W, ldx, training, sync, count, res is not None)
         ctx.gsink, ctx.bsink, ctx.group = gsink, bsink, mod.group
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, y, mean, invstd, gamma, drop = ctx.saved_tensors
+        x, y, mean, invstd, gamma, drop, rbeta = ctx.saved_tensors
         N, C, H, W, ldx, training, sync, count, has_res = ctx.meta
         M = N * H * W
         gy, ldg = as_rows(gy)
         dev = gy.device
         sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
         wsb = _ws(query("u2pl_colreduce_workspace_bytes", M, 1, C), dev)
-        call("u2pl_bn_bwd_sums_f32", gy, ldg, x, ldx, y, C, mean, invstd, drop, H * W, M, C, wsb, sums)
+        if rbeta is not None:
+            call("u2pl_bn_bwd_sums_mx_f32", gy, ldg, x, ldx, mean, invstd, gamma, rbeta, drop, H * W, M, C, wsb, sums)
+        else:
+            call("u2pl_bn_bwd_sums_f32", gy, ldg, x, ldx, y, C, mean, invstd, drop, H * W, M, C, wsb, sums)
         dgamma = dbeta = None
         # single rank, gradients into the arena: the two parameter-gradient writes ride in the apply launch (same arithmetic)
         pg_fused = (FUSE_BN_FINISH and ctx.needs_input_grad[1] and ctx.gsink is not None and ctx.needs_input_grad[0]
@@ -593,14 +600,16 @@ class _BNFn(torch.autograd.Function):
             _all_reduce(sums, "syncbn_allreduce", group=ctx.group)
         dx = new_act(N, C, H, W, dev) if ctx.needs_input_grad[0] else None
         dres = new_act(N, C, H, W, dev) if has_res and ctx.needs_input_grad[3] else None
-        if CONV_H["on"] and dx is not None:      # split-fp16: max |dx| / max |dres| for the data / weight gradients that read them
-            dx_amax = amax_slot(dev)
-            dres_amax = amax_slot(dev) if dres is not None else None
+        if (CONV_H["on"] or rbeta is not None) and dx is not None:
+            # split-fp16: max |dx| / max |dres| for the data / weight gradients that read them; rbeta: the mask from x
+            dx_amax = amax_slot(dev) if CONV_H["on"] else None
+            dres_amax = amax_slot(dev) if (dres is not None and CONV_H["on"]) else None
             call("u2pl_bn_bwd_apply_amax_f32", gy, ldg, x, ldx, y, C, mean, invstd, gamma, drop, H * W,
                  sums if training else None, count, dx, C, dres, C, M, C, sums if pg_fused else None,
-                 ctx.gsink if pg_fused else None, ctx.bsink if pg_fused else None, 1, dx_amax, dres_amax)
-            set_amax(dx, dx_amax)
-            if dres is not None:
+                 ctx.gsink if pg_fused else None, ctx.bsink if pg_fused else None, 1, dx_amax, dres_amax, rbeta)
+            if dx_amax is not None:
+                set_amax(dx, dx_amax)
+            if dres_amax is not None:
                 set_amax(dres, dres_amax)
             if pg_fused:
                 _mark_ready(ctx.gsink)
@@ -864,6 +873,8 @@ class BatchNorm2d(nn.Module):
 
 
 FUSE_EVAL_BN = os.environ.get("U2PL_NO_EVAL_BN_FUSION") is None
+# round 6: a BatchNorm + ReLU without a residual recomputes its backward's ReLU mask from x instead of reading y (same bits)
+RELU_MASK_FROM_X = os.environ.get("U2PL_NO_RELU_MASK_FROM_X") is None
 # round 5: fewer tiny launches on the conv -> statistics -> normalise chain (same arithmetic, same bits; U2PL_NO_BN_FINISH_FUSION=1:
 # the separate launches): finish + finalize in one, parameter gradients inside the backward apply, eval-mode invstd of a whole
 # model in one launch (eval_invstd)

@@ -212,14 +212,22 @@ __global__ __launch_bounds__(256) void k_weight_absmax_multi(const SplitJob* __r
         atomicMax(slot, m);
     }
 }
-__global__ void k_weight_split2h_multi(const SplitJob* __restrict__ jobs, int njobs, long total) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int lo = 0, hi = njobs - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (jobs[mid].seg_begin <= i) lo = mid; else hi = mid - 1;
+// (block b covers the contiguous segments [b * WS_AMAX_SPAN, (b + 1) * WS_AMAX_SPAN) like the maxima kernel: the job record is
+// looked up -- ~9 dependent L2 round trips of a binary search -- when a thread crosses into another job, not per segment)
+__global__ __launch_bounds__(256) void k_weight_split2h_multi(const SplitJob* __restrict__ jobs, int njobs, long total) {
+    const long begin = (long)blockIdx.x * WS_AMAX_SPAN, end = begin + WS_AMAX_SPAN < total ? begin + WS_AMAX_SPAN : total;
+    SplitJob j = jobs[0];
+    bool have = false;
+    for (long i = begin + threadIdx.x; i < end; i += 256) {
+        if (!have || i < j.seg_begin || i >= j.seg_begin + (long)j.batch * j.Np * (j.K / 8)) {
+            int lo = 0, hi = njobs - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (jobs[mid].seg_begin <= i) lo = mid; else hi = mid - 1;
+            }
+            j = jobs[lo];
+            have = true;
         }
-        const SplitJob j = jobs[lo];
         const int nseg = j.K / 8;
         const long per = (long)j.Np * nseg;
         long r = i - j.seg_begin;
@@ -255,10 +263,10 @@ __global__ void k_weight_split2h_multi(const SplitJob* __restrict__ jobs, int nj
         uint2 a0, a1, b0, b1;
         split2_f16(v0, sc, a0, a1);
         split2_f16(v1, sc, b0, b1);
-        const int c = sg >> 2, s = sg & 3;
+        const int c = sg >> 2, s_ = sg & 3;
         const long pl = (long)j.Np * 32;
         unsigned short* out = j.out + (long)z * (j.K / 32) * 2 * pl;
-        const long base = (((long)c * 2) * j.Np + n) * 32 + ((s ^ ((n >> 2) & 3)) << 3);       // in fp16 elements
+        const long base = (((long)c * 2) * j.Np + n) * 32 + ((s_ ^ ((n >> 2) & 3)) << 3);       // in fp16 elements
         *(uint4*)(out + base) = make_uint4(a0.x, a0.y, b0.x, b0.y);
         *(uint4*)(out + base + pl) = make_uint4(a1.x, a1.y, b1.x, b1.y);
     }
@@ -274,7 +282,7 @@ U2PL_API int u2pl_weight_split2h_multi_f32(const void* jobs, int njobs, long tot
     U2PL_LAUNCH_CHECK();
     U2PL_LAUNCH(k_weight_absmax_multi, dim3((unsigned)cdiv(total, WS_AMAX_SPAN)), dim3(256), 0, stream, (const SplitJob*)jobs, njobs, total);
     U2PL_LAUNCH_CHECK();
-    U2PL_LAUNCH(k_weight_split2h_multi, dim3(grid_for(total, 256, 4096)), dim3(256), 0, stream, (const SplitJob*)jobs, njobs, total);
+    U2PL_LAUNCH(k_weight_split2h_multi, dim3((unsigned)cdiv(total, WS_AMAX_SPAN)), dim3(256), 0, stream, (const SplitJob*)jobs, njobs, total);
     U2PL_LAUNCH_CHECK();
     return 0;
 }

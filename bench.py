@@ -191,7 +191,16 @@ def main():
     local_rank %= ndev   # (tests share one GPU between two gloo ranks; production: one GPU per rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # U2PL_DIST_SINGLE=1 at N = 1: a process group of ONE rank on RCCL -- the step takes every multi-rank code path (SyncBatchNorm
+    # exchanges, bucketed gradient all-reduce from the backward hooks, count / key all-gathers, meter reductions, no HIP graphs)
+    # with every collective really issued and equal to the identity (u2pl_amd.comm.dist_active): what the N > 1 path costs in
+    # launches and latency, measurable on a one-GPU box (the bandwidth terms of a real exchange are not in it)
+    single_rccl = world == 1 and os.environ.get("U2PL_DIST_SINGLE", "0") == "1"
+    multi = world > 1 or single_rccl
+    if single_rccl:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if multi:
         import datetime
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # a first run on RCCL must not be able to hang the lease silently: collectives time out, RCCL reports what it was doing,
@@ -267,7 +276,7 @@ def main():
     from u2pl_amd import nn as KN
     from u2pl_amd import hipops as HO
     rccl_ranks = None
-    if world > 1:
+    if multi:
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)                      # an ACTUAL collective on the process group: the ranks it reached
         rccl_ranks = int(ones.item())
@@ -296,13 +305,13 @@ def main():
     host_tail = time.perf_counter() - host_tail      # GPU work still queued when the host left the last step
     own_dt = time.perf_counter() - t0                # this rank alone: its K steps + its own queue drained, before the barrier
     _progress("timed-barrier")
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     per_rank_ms = [round(own_dt / args.steps * 1e3, 3)]
-    if world > 1:
+    if multi:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         own = torch.tensor([own_dt / args.steps * 1e3], device=dev, dtype=torch.float64)
         allv = [torch.empty_like(own) for _ in range(world)]
@@ -321,24 +330,24 @@ def main():
         """n more steps, bracketed like the timed region (diagnostic lines below: not the headline)"""
         fn = fn or step
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         ta = time.perf_counter()
         for i in range(n):
             fn(first + i)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         _progress()
         tb = torch.tensor([time.perf_counter() - ta], device=dev, dtype=torch.float64)
-        if world > 1:
+        if multi:
             dist.all_reduce(tb, op=dist.ReduceOp.MAX)
         return float(tb) / n * 1e3
 
     diag = {}
-    if world > 1:
+    if multi:
         # exposed communication of the bucketed gradient all-reduce: the same steps with every bucket launched AFTER backward
         os.environ["U2PL_NO_BUCKET_OVERLAP"] = "1"
         diag["ms_per_step_no_bucket_overlap"] = round(timed_steps(3, args.warmup + args.steps), 3)
@@ -376,7 +385,7 @@ def main():
                              "supervised loss heads, contrastive = unsupervised CE + bank + InfoNCE forward, bwd = whole backward incl. "
                              "weight gradients [+ bucket all-reduce launches], opt_ema = all-reduce join + SGD + EMA + operand re-split")
     _progress()
-    if world > 1:
+    if multi:
         dist.barrier()
 
     # the roofline leg runs ONE extra (un-timed) step with per-call HIP events; it contains the step's
@@ -386,7 +395,7 @@ def main():
     # split-fp16 operand maxima of that (eager) step: how many came out of their producers' own launches, how many needed a pass
     roof["operand_maxima_per_step"] = dict(KN.AMAX_STATS, conv_h=bool(KN.CONV_H["on"]))
     _progress()
-    if world > 1:
+    if multi:
         dist.barrier()
     if not args.no_calibrate:
         # the timed steps ran at lr 1e-6 (see above).  FIVE steps at the configuration's lr 0.01, each from the re-instated
@@ -486,7 +495,7 @@ def main():
             "losses_last_step": [round(float(x), 5) for x in meters.cpu()],
             # collectives issued per step by this rank (0 at N = 1: SyncBatchNorm exchanges only happen under a process group)
             "syncbn_collectives_per_step": comm["syncbn_allreduce"], "bucket_allreduces_per_step": comm["bucket_allreduce"],
-            "rccl_ranks": rccl_ranks,
+            "rccl_ranks": rccl_ranks, "rccl_world_of_one": bool(single_rccl),
             "split_launches_timed": route1[0] - route0[0], "split_second_barrier_launches_timed": route1[1] - route0[1],
             "split_ledger_fallbacks": HO.SPLIT_FALLBACKS["ledger"],
             # host side of the timed steps (rank 0): wall time inside train_step per step -- the enqueue of ~3000 C-ABI calls plus
@@ -558,7 +567,7 @@ def main():
         out = {**{k: out[k] for k in front}, **{k: v for k, v in out.items() if k not in front}}
         print(json.dumps(out))
     _WD["done"] = True
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -322,3 +322,48 @@ def test_two_rank_step_matches_the_reference_run_under_world_2():
     # double its update
     err, upd = r0["student__decoder.representation.8.bias"]
     assert upd > 0 and err <= 0.1 * upd
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# RCCL, for real, on the one GPU: a process group of ONE rank with backend "nccl" (= RCCL) and U2PL_DIST_SINGLE=1
+# (comm.dist_active): the step takes every multi-rank code path -- SyncBatchNorm statistics exchanges (packed and per layer),
+# the bucketed gradient all-reduce launched from the backward hooks on the producer streams, the count / key all-gathers in
+# front of the step's one host read, the loss / meter reductions, eager launches instead of HIP graphs, the PERSISTENT
+# reliability split next to RCCL's kernels -- with every collective executed by RCCL on the device and equal to the identity.
+# What the gloo tests above cannot show (collectives on RCCL's own stream, work.wait() as a stream wait, async handles under the
+# hooks) runs here; the result must be the plain single-process step, bit for bit.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _rccl_single_worker(rank, world, port, mode, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["U2PL_GRAPHS"] = "0"             # (the plain run eager too: the same launches on both sides)
+    torch.cuda.set_device(0)
+    if mode == "rccl":
+        import datetime
+        os.environ["U2PL_DIST_SINGLE"] = "1"
+        dist.init_process_group("nccl", rank=0, world_size=1, timeout=datetime.timedelta(seconds=120))
+    try:
+        from u2pl_amd import nn as K
+        out = _train_case(0, 1, S=97, steps=3)
+        out["active"] = bool(K.dist_active())
+        out["buckets"] = K.COMM_STATS["bucket_allreduce"]
+        ret[mode] = out
+    finally:
+        if mode == "rccl":
+            dist.destroy_process_group()
+
+
+def test_world_of_one_on_rccl_takes_the_multi_rank_path_and_reproduces_the_plain_step():
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    for mode in ("plain", "rccl"):
+        mp.spawn(_rccl_single_worker, args=(1, _free_port(), mode, ret), nprocs=1, join=True)
+    a, b = ret["plain"], ret["rccl"]
+    assert not a["active"] and b["active"]
+    # the multi-rank path really ran: SyncBatchNorm exchanges, gradient buckets and the other collectives were issued on RCCL
+    assert a["syncbn"] == 0 and b["syncbn"] > 100 and b["buckets"] > 0 and b["collectives"] > b["syncbn"]
+    assert np.isfinite(b["meters"]).all() and np.array_equal(a["meters"], b["meters"])
+    for k in ("w", "w2", "t", "rm", "bank_len", "bank_sum"):
+        assert a[k] == b[k], k

@@ -18,6 +18,13 @@ from u2pl_amd.trainer import SemiTrainer  # noqa: E402
 from u2pl_amd.utils.loss_helper import get_criterion  # noqa: E402
 
 dev = torch.device("cuda", 0)
+if os.environ.get("U2PL_DIST_SINGLE", "0") == "1":      # the N > 1 path on one GPU: a world of one on RCCL (u2pl_amd.comm.dist_active)
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29544")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
 torch.manual_seed(2); np.random.seed(2)
 cfg = configs.cityscapes_semi(arch="resnet101", crop=769, batch_size=2, sync_bn=True)
 model, teacher = ModelBuilder(cfg["net"]).to(dev), ModelBuilder(cfg["net"]).to(dev)

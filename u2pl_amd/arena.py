@@ -21,6 +21,12 @@ def _world():
     return K._world()
 
 
+def _multi():
+    """the gradient all-reduce is issued: more than one rank (nn._world, substitutable) or a forced world of one (comm.dist_active)"""
+    from . import nn as K
+    return K._world() > 1 or K.dist_active()
+
+
 
 
 # ------------------------------------------------------------------ flat parameter arena
@@ -127,7 +133,7 @@ class ParamArena:
         _lib.SIDE_WORK.add("buckets")
 
     def mark_ready(self, pidx):
-        if _world() <= 1 or not self.buckets or os.environ.get("U2PL_NO_BUCKET_OVERLAP") is not None:
+        if not _multi() or not self.buckets or os.environ.get("U2PL_NO_BUCKET_OVERLAP") is not None:
             return
         self._pending[self._bucket_of[pidx]] -= 1
         # Buckets go out in ONE fixed order (last bucket first, the order backward fills them), like DDP's reducer: the
@@ -140,7 +146,7 @@ class ParamArena:
     def finish_allreduce(self):
         """after backward: reduce whatever was not launched from the hooks (parameters without a gradient this step,
         overlap disabled) and make the current stream wait for every bucket.  SUM; the mean is folded into sgd_step."""
-        if _world() <= 1:
+        if not _multi():
             return
         if not self.buckets:
             _all_reduce(self.grad, "bucket_allreduce")

@@ -45,7 +45,7 @@ def comm_sequence_digest():
 
 def check_comm_sequence(clear=True):
     """(debug mode) all ranks must have issued the same sequence of collectives since the last check"""
-    if not (COMM_DEBUG["on"] and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if not (COMM_DEBUG["on"] and dist_active()):
         if clear:
             COMM_DEBUG["log"].clear()
         return True
@@ -78,6 +78,17 @@ def _digest_of(log):
         for b in (kind + ":" + str(n)).encode():
             h = ((h ^ b) * 1099511628211) & ((1 << 62) - 1)
     return h
+
+
+def dist_active():
+    """do the multi-rank code paths run?  A process group of more than one rank -- or, with U2PL_DIST_SINGLE=1, ANY initialised
+    group: in a world of ONE every collective of the step is still issued for real (on RCCL when the backend is "nccl") and is the
+    identity, so the single-GPU box can execute the N > 1 path -- SyncBatchNorm exchanges, bucketed gradient all-reduce from the
+    backward hooks, key / count all-gathers, meter reductions, no HIP graphs -- and must reproduce the plain step bit for bit
+    (tests/test_gpu_dist.py).  Arithmetic that depends on the number of ranks keeps using _world()."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("U2PL_DIST_SINGLE", "0") == "1"
 
 
 def _world():

@@ -63,7 +63,8 @@ def validate(model, loader, cfg, device):
         large = H.bilinear_up(out, labels.shape[1:])
         N, _, Hh, Ww = large.shape
         call("u2pl_confusion_hist_f32", large, labels, ign, N, C, Hh, Ww, hist)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    from .nn import dist_active
+    if dist_active():
         from .nn import _all_reduce
         _all_reduce(hist, "validate_allreduce")      # one all-reduce at the end instead of three per batch
     hist = hist.cpu().double().reshape(3, C)

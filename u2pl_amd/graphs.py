@@ -35,7 +35,7 @@ STATS = {"captures": 0, "replays": 0, "eager": 0, "aborted": 0}
 def enabled():
     if os.environ.get("U2PL_GRAPHS", "1") == "0" or _lib.PROFILE is not None or K.DROPOUT_HOOK is not None:
         return False
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if K.dist_active():
         return False
     return True
 

@@ -22,7 +22,7 @@ from . import _lib
 from ._lib import HipError, call, query
 
 from .comm import (COMM_DEBUG, COMM_STATS, _all_reduce, _digest_of, _world, check_comm_sequence, comm_sequence_digest,  # noqa: F401
-                   note_collective)
+                   dist_active, note_collective)
 from .layout import _CL, _ws, as_rows, new_act  # noqa: F401
 from .operands import (AMAX_STATS, CONV_H, CONV_WS, PRESPLIT, WEIGHT_EPOCH, _AMAX_POOL, _DerivedCache, _derived, _split_of,  # noqa: F401
                        _weight_stamp, _ws_ok, amax_of, amax_pool_reset, amax_slot, bump_weight_epoch, invalidate_weights, presplit,
@@ -524,7 +524,7 @@ class _BNFn(torch.autograd.Function):
             rr, ldr = as_rows(res)
         y = new_act(N, C, H, W, dev)
         training = mod.training
-        sync = mod.sync and _world() > 1
+        sync = mod.sync and dist_active()
         if training:
             pivot = mod.running_mean
             mean = torch.empty(C, dtype=torch.float32, device=dev)
@@ -542,9 +542,11 @@ class _BNFn(torch.autograd.Function):
                     wsb = _ws(query("u2pl_colreduce_workspace_bytes", M, 1, C), dev)
                     call("u2pl_bn_stats_f32", x, ldx, M, C, pivot, wsb, sums)
                 if sync:
-                    sums[2 * C] = float(M)
-                    _all_reduce(sums, "syncbn_allreduce", group=mod.group)
-                    count = float(M * _world())  # equal per-rank shapes (drop_last loaders)
+                    # (2C doubles travel; the row count does not: equal per-rank shapes -- drop_last loaders -- make it
+                    #  M * world on every rank.  Writing it into a slot of the buffer from the host cost a torch setitem per layer:
+                    #  ~100 us of host time, 21 ms per step -- measured on RCCL in a world of one, tools/host_overhead.py)
+                    _all_reduce(sums[:2 * C], "syncbn_allreduce", group=mod.group)
+                    count = float(M * _world())
                 call("u2pl_bn_finalize_f32", sums, count, pivot, C, mod.eps, mod.momentum, mean, invstd, mod.running_mean,
                      mod.running_var)
             mod._nbt += 1   # host counter; the buffer is materialised lazily (see BatchNorm2d)
@@ -583,7 +585,10 @@ class _BNFn(torch.autograd.Function):
         dgamma = dbeta = None
         # single rank, gradients into the arena: the two parameter-gradient writes ride in the apply launch (same arithmetic)
         pg_fused = (FUSE_BN_FINISH and ctx.needs_input_grad[1] and ctx.gsink is not None and ctx.needs_input_grad[0]
-                    and not (sync and training))
+                    and (not (sync and training) or CONV_H["on"] or rbeta is not None))
+        # (SyncBN: the parameter gradients are the LOCAL sums, the apply needs the all-reduced ones -- one device copy of the local
+        #  sums rides into the apply launch instead of two parameter-gradient launches in front of the exchange)
+        psums = sums
         # parameter gradients are LOCAL sums (DDP averages them later), like torch SyncBN
         if ctx.needs_input_grad[1] and not pg_fused:
             if ctx.gsink is not None:
@@ -597,6 +602,8 @@ class _BNFn(torch.autograd.Function):
                 call("u2pl_sums_to_f32", sums[C:], C, 1.0, 0, dgamma)
                 call("u2pl_sums_to_f32", sums, C, 1.0, 0, dbeta)
         if sync and training:
+            if pg_fused:
+                psums = sums.clone()
             _all_reduce(sums, "syncbn_allreduce", group=ctx.group)
         dx = new_act(N, C, H, W, dev) if ctx.needs_input_grad[0] else None
         dres = new_act(N, C, H, W, dev) if has_res and ctx.needs_input_grad[3] else None
@@ -605,7 +612,7 @@ class _BNFn(torch.autograd.Function):
             dx_amax = amax_slot(dev) if CONV_H["on"] else None
             dres_amax = amax_slot(dev) if (dres is not None and CONV_H["on"]) else None
             call("u2pl_bn_bwd_apply_amax_f32", gy, ldg, x, ldx, y, C, mean, invstd, gamma, drop, H * W,
-                 sums if training else None, count, dx, C, dres, C, M, C, sums if pg_fused else None,
+                 sums if training else None, count, dx, C, dres, C, M, C, psums if pg_fused else None,
                  ctx.gsink if pg_fused else None, ctx.bsink if pg_fused else None, 1, dx_amax, dres_amax, rbeta)
             if dx_amax is not None:
                 set_amax(dx, dx_amax)
@@ -650,7 +657,8 @@ def _bn_local_sums(x, ldx, M, C, mod, pre_sums, out):
     else:
         wsb = _ws(query("u2pl_colreduce_workspace_bytes", M, 1, C), x.device)
         call("u2pl_bn_stats_f32", x, ldx, M, C, mod.running_mean, wsb, out)
-    out[2 * C] = float(M)
+    # (slot 2C -- the row count of the packed protocol -- stays what the caller's zero fill left: the count is M * world by
+    #  construction and a host-side setitem per unit costs ~100 us)
 
 
 def _bn_finalize(sums, count, mod, C, dev):
@@ -695,7 +703,7 @@ class _BNGroupFn(torch.autograd.Function):
             total += 2 * C + 1
         dev = units[0][0].device
         group = meta[0][0].group
-        packed = torch.empty(total, dtype=torch.float64, device=dev)
+        packed = torch.zeros(total, dtype=torch.float64, device=dev)
         off = 0
         for (x, ldx, N, C, H, W, gamma, beta, drop, pre), (mod, relu, gs, bs) in zip(units, meta):
             _bn_local_sums(x, ldx, N * H * W, C, mod, pre, packed[off:off + 2 * C + 1])
@@ -760,7 +768,7 @@ class _BNResPairFn(torch.autograd.Function):
         xb, ldb = as_rows(xb)
         N, C, H, W = xa.shape
         M, dev = N * H * W, xa.device
-        packed = torch.empty(2 * (2 * C + 1), dtype=torch.float64, device=dev)
+        packed = torch.zeros(2 * (2 * C + 1), dtype=torch.float64, device=dev)
         _bn_local_sums(xa, lda, M, C, mod_a, pre_a, packed[:2 * C + 1])
         _bn_local_sums(xb, ldb, M, C, mod_b, pre_b, packed[2 * C + 1:])
         _all_reduce(packed, "syncbn_allreduce", group=mod_a.group)
@@ -801,7 +809,7 @@ class _BNResPairFn(torch.autograd.Function):
 
 
 def _packable(bns):
-    return (_world() > 1 and os.environ.get("U2PL_NO_SYNCBN_PACK") is None
+    return (dist_active() and os.environ.get("U2PL_NO_SYNCBN_PACK") is None
             and all(b.training and b.sync for b in bns) and len({id(b.group) for b in bns}) == 1)
 
 

@@ -119,8 +119,7 @@ class SemiTrainer:
         self.t_arena = K.ParamArena(tgroups, with_grad=False)
         for p in model_teacher.parameters():
             p.requires_grad = False
-        if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-                and os.environ.get("U2PL_TEACHER_COMM", "0") == "1"):
+        if K.dist_active() and os.environ.get("U2PL_TEACHER_COMM", "0") == "1":
             # OPT-IN (U2PL_TEACHER_COMM=1): the teacher's train-mode forward runs on the side HIP stream next to the student's
             # forward; its ~105 SyncBN all-reduces then get their own communicator so that they do not queue in front of the
             # student's.  Two communicators driven concurrently from one process are a documented NCCL / RCCL deadlock hazard
@@ -419,7 +418,7 @@ class SemiTrainer:
             self.t_arena.ema_from(self.arena, d)
         self._mark("opt_ema")
         meters = torch.stack((sup_loss.detach(), unsup_loss.detach(), contra_loss.detach()))
-        if _world() > 1:
+        if K.dist_active():
             cv = contra_loss.detach().clone()
             K._all_reduce(cv, "loss_allreduce")        # contra value = cross-rank mean (train_semi.py:514-519)
             meters[2] = cv
@@ -472,7 +471,7 @@ class SupTrainer:
         self._optimizer_step(lrs, 1.0 / W)
         z = torch.zeros((), device=loss.device)
         meters = torch.stack((loss.detach(), z, z))
-        if W > 1:
+        if K.dist_active():
             K._all_reduce(meters, "meter_allreduce")
             K.check_comm_sequence()
         return meters

@@ -68,7 +68,8 @@ def contra_memobank_core(rep, lbits, num_labeled, prob_l, prob_u, low_mask, high
     with torch.no_grad():
         ph1 = H.contra_phase1(rep_t_rows, D, D, prob, pstr, lbits, low_mask.contiguous(), high_mask.contiguous(),
                               num_labeled, C, h, w, cfg)
-        device_enqueue = _world() == 1 and rep.is_cuda and isinstance(memobank, H.DeviceMemoryBank) and DEVICE_ENQUEUE
+        from .. import nn as K      # (late: nn imports nothing from here, but keep the module graph acyclic at import time)
+        device_enqueue = not K.dist_active() and rep.is_cuda and isinstance(memobank, H.DeviceMemoryBank) and DEVICE_ENQUEUE
         if device_enqueue:
             # single rank: the keys are appended by the device-resident bank from the list lengths ON THE DEVICE, i.e.
             # before (and under) the host synchronisation below instead of after it

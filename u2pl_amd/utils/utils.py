@@ -17,6 +17,12 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _single():
+    """no key / count exchange: one rank and not a forced world of one (comm.dist_active)"""
+    from .. import nn as K
+    return not K.dist_active()
+
+
 def _note(kind, numel):
     from .. import nn as K      # (collective bookkeeping / U2PL_COMM_DEBUG sequence log)
     K.note_collective(kind, numel)
@@ -26,7 +32,7 @@ def gather_keys(keys):
     """Rank-major concatenation of variable-length key blocks (utils.py:16-24,31-32)
     as ONE padded device all-gather instead of barrier + pickled all_gather_object."""
     W = _world()
-    if W == 1:
+    if _single():
         return keys
     n = H.h2d(torch.tensor([keys.shape[0]], dtype=torch.int64), keys.device)
     ns = [torch.zeros_like(n) for _ in range(W)]
@@ -55,7 +61,7 @@ def exchange_counts(counts_dev, C):
     W = _world()
     t0 = time.perf_counter()
     try:
-        if W == 1:
+        if _single():
             return counts_dev.cpu().numpy(), None
         outs = [torch.empty_like(counts_dev) for _ in range(W)]
         _note("key_allgather", counts_dev.numel())
@@ -74,7 +80,7 @@ def enqueue_all_classes(bank, rows, ld, idx, counts_c, C, all_counts=None):
     W = _world()
     D = bank.D
     n_loc = [int(counts_c[c]) for c in range(C)]
-    if W == 1:
+    if _single():
         bank.append_multi([(c, rows, n_loc[c], idx[c]) for c in range(C)], ld)
         return n_loc
     dev = rows.device
@@ -114,7 +120,7 @@ def enqueue_all_classes(bank, rows, ld, idx, counts_c, C, all_counts=None):
 
 def dequeue_and_enqueue_device(bank, c, rows, ld, idx_list, n_local):
     """utils.py:27-47 on the device ring; returns the gathered batch size."""
-    if _world() == 1:
+    if _single():
         bank.append_rows(c, rows, ld, n_local, idx_list)
         return n_local
     keys = torch.empty((n_local, bank.D), dtype=torch.float32, device=rows.device)

@@ -496,6 +496,7 @@ def main():
             # collectives issued per step by this rank (0 at N = 1: SyncBatchNorm exchanges only happen under a process group)
             "syncbn_collectives_per_step": comm["syncbn_allreduce"], "bucket_allreduces_per_step": comm["bucket_allreduce"],
             "rccl_ranks": rccl_ranks, "rccl_world_of_one": bool(single_rccl),
+            "emulated_collective_latency_us": float(os.environ.get("U2PL_EMULATE_COLL_US", "0") or 0) if multi else 0.0,
             "split_launches_timed": route1[0] - route0[0], "split_second_barrier_launches_timed": route1[1] - route0[1],
             "split_ledger_fallbacks": HO.SPLIT_FALLBACKS["ledger"],
             # host side of the timed steps (rank 0): wall time inside train_step per step -- the enqueue of ~3000 C-ABI calls plus

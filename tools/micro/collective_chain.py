@@ -40,6 +40,12 @@ def run(mode):
     return e0.elapsed_time(e1) / N * 1e3, (t1 - t0) / N * 1e6
 
 
+# calibration of torch.cuda._sleep's unit (u2pl_amd.comm.U2PL_EMULATE_COLL_US)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda._sleep(1000); torch.cuda.synchronize()      # (the first launch loads the kernel: not part of the unit)
+e0.record(); torch.cuda._sleep(1_000_000); e1.record(); torch.cuda.synchronize()
+print(f"torch.cuda._sleep(1e6) = {e0.elapsed_time(e1) * 1e3:.0f} us -> {1e6 / (e0.elapsed_time(e1) * 1e3):.1f} ticks per us")
 s = torch.cuda.Stream()
 for mode in ("none", "sync", "async", "hop", "none", "sync"):
     run(mode)

@@ -16,6 +16,10 @@ COMM_STATS = {"syncbn_allreduce": 0, "bucket_allreduce": 0}
 COMM_DEBUG = {"on": os.environ.get("U2PL_COMM_DEBUG", "0") not in ("", "0"), "log": [], "issued": 0}
 
 
+_EMULATE_US = float(os.environ.get("U2PL_EMULATE_COLL_US", "0") or 0)
+_SPIN_CYCLES_PER_US = 2440.0     # torch.cuda._sleep counts shader-clock ticks on MI355X (measured warm: tools/micro/emulate_check.py)
+
+
 def _all_reduce(t, kind, group=None, async_op=False, op=None):
     """every all-reduce of this package (the memory bank's all-gathers in utils/utils.py are logged through note_collective)"""
     COMM_STATS[kind] = COMM_STATS.get(kind, 0) + 1
@@ -23,7 +27,13 @@ def _all_reduce(t, kind, group=None, async_op=False, op=None):
     if COMM_DEBUG["on"]:
         COMM_DEBUG["log"].append((kind, int(t.numel()), 0 if group is None else id(group) & 0xffff))
     kw = {} if op is None else {"op": op}
-    return dist.all_reduce(t, group=group, async_op=async_op, **kw)
+    w = dist.all_reduce(t, group=group, async_op=async_op, **kw)
+    if _EMULATE_US and not async_op and t.is_cuda:
+        # diagnostic (U2PL_EMULATE_COLL_US=<us>, with U2PL_DIST_SINGLE=1): a world of one has no network -- a spin of the given length
+        # behind every synchronous collective puts an exchange's latency on the critical path of its stream, so that the LATENCY
+        # part of an N-rank step can be projected on the one-GPU box (bench.py)
+        torch.cuda._sleep(int(_EMULATE_US * _SPIN_CYCLES_PER_US))
+    return w
 
 
 def note_collective(kind, numel):

@@ -566,7 +566,15 @@ def main():
         _WD["done"] = True
         front = [k for k in list(out)[:13]] + [k for k in ("roofline", "cpu_baseline", "roofline_hbm", "roofline_wgrad", "roofline_bf16") if k in out]
         out = {**{k: out[k] for k in front}, **{k: v for k, v in out.items() if k not in front}}
-        print(json.dumps(out))
+        # RCCL's version banner (NCCL_DEBUG=WARN above) sits in the C library's stdout buffer until the process exits: flush it
+        # first, so that the JSON line is the LAST line of rank 0's stdout
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     _WD["done"] = True
     if multi:
         dist.destroy_process_group()

@@ -3,7 +3,7 @@
 # L microseconds behind every synchronous collective (U2PL_EMULATE_COLL_US).  Writes gpurun_out/r06_latency_<L>.json.
 mkdir -p gpurun_out
 for L in ${LATS:-0 20 40}; do
-  U2PL_DIST_SINGLE=1 U2PL_EMULATE_COLL_US=$L python bench.py --gpus 1 --steps 10 --warmup 3 2>gpurun_out/r06_latency_$L.err | grep "^{" | tail -1 > gpurun_out/r06_latency_$L.json
+  U2PL_DIST_SINGLE=1 U2PL_EMULATE_COLL_US=$L python bench.py --gpus 1 --steps 10 --warmup 3 2>gpurun_out/r06_latency_$L.err | tail -1 > gpurun_out/r06_latency_$L.json
 done
 python - <<'PY'
 import json

@@ -658,3 +658,30 @@ def test_wsh_operand_range_semantics(wsh_switch):
     with torch.no_grad():
         y = conv(x)
     assert not torch.isfinite(y[1, :, 2, 2]).any()
+
+
+@pytest.mark.parametrize("Cin,Cout,k,dil,wino", [(1024, 256, 1, 1, 0), (256, 1024, 1, 1, 0), (256, 256, 3, 2, 4), (2048, 256, 3, 12, 0)])
+def test_wsh_power_of_two_homogeneity_is_exact_at_the_headline_sizes(Cin, Cout, k, dil, wino, wsh_switch):
+    """A size-independent property of the per-tensor power-of-two scaling, checked BIT-EXACTLY on layer3 / ASPP shapes of the 769^2
+    step (4 x 97^2 pixels): multiplying the activations by 2^a, the weights by 2^c and the incoming gradient by 2^b presents the
+    matrix cores with the very same scaled fp16 pieces, so y, dx, dw and the fused BatchNorm sums come back multiplied by exactly
+    2^(a+c), 2^(b+c), 2^(a+b) and 2^(a+c) / 2^(2(a+c)) -- through the direct kernels and through the Winograd transforms alike."""
+    Kn = wsh_switch
+    Kn.CONV_ALGO.update(wino=wino, min_gain=0.0)
+    torch.manual_seed(Cin + Cout + k)
+    N, H = 4, 97
+    conv = Kn.Conv2d(Cin, Cout, k, padding=dil * (k // 2), dilation=dil, bias=False).to(DEV)
+    x = torch.relu(torch.randn(N, Cin, H, H, device=DEV) + 0.2).contiguous(memory_format=CL)
+    gy = (torch.randn(N, Cout, H, H, device=DEV) * 1e-4).contiguous(memory_format=CL)
+    pivot = torch.randn(Cout, device=DEV) * 0.1
+    y0, dx0, dw0, s0 = _run_h(Kn, True, conv, x, gy, pivot)
+    a, b, c = 7, -5, 3
+    with torch.no_grad():
+        conv.weight.mul_(2.0 ** c)
+    y1, dx1, dw1, s1 = _run_h(Kn, True, conv, (x * 2.0 ** a).contiguous(memory_format=CL), (gy * 2.0 ** b).contiguous(memory_format=CL),
+                              pivot * 2.0 ** (a + c))
+    assert torch.equal(y1, y0 * 2.0 ** (a + c))
+    assert torch.equal(dx1, dx0 * 2.0 ** (b + c))
+    assert torch.equal(dw1, dw0 * 2.0 ** (a + b))
+    assert torch.equal(s1[:Cout], s0[:Cout] * 2.0 ** (a + c))
+    assert torch.equal(s1[Cout:2 * Cout], s0[Cout:2 * Cout] * 4.0 ** (a + c))
